@@ -1,0 +1,288 @@
+"""Generate the golden vectors under tests/golden/ from the ACTUAL reference implementation.
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py [which ...]
+Outputs (small .npz fixtures, committed):
+  c4_rules.npz   connect4 rule tables: random playouts -> valid_moves / board / win_state / observation
+  c4_tree.npz    single-tree MCTS traces (find_leaf paths, per-sim root stats, counts / probs / value)
+  c4_agent.npz   SelfPlayAgent lock-step self-play traces (actions, leaf-obs checksums, samples, results)
+Every run of the reference is under the random tape (refharness.Tape) and the synthetic evaluator
+(oracle azo_fake_eval), so the fixtures hold seeds + expected outputs only.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refharness as rh  # noqa: E402
+from refharness import ol  # noqa: E402
+
+OUT = HERE
+
+
+def c4_ref_to_cells(g):
+    return np.asarray(g._board.pieces, dtype=np.int8).reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------ rules
+def gen_c4_rules(n_games=120, seed=1234):
+    from alphazero.envs.connect4.connect4 import Game
+    rng = np.random.RandomState(seed)
+    moves, lens, valids, cells, ws, obs_crc, obs_sample = [], [], [], [], [], [], []
+    for gi in range(n_games):
+        g = Game()
+        seq = []
+        while True:
+            v = np.asarray(g.valid_moves())
+            w = np.asarray(g.win_state())
+            valids.append(v.astype(np.uint8)); cells.append(c4_ref_to_cells(g)); ws.append(w.astype(np.uint8))
+            o = g.observation()
+            obs_crc.append(rh.crc(o))
+            if len(obs_sample) < 64:
+                obs_sample.append(o.copy())
+            m = np.full(42, -1, np.int8); m[:len(seq)] = seq
+            moves.append(m); lens.append(len(seq))
+            if w.any():
+                break
+            a = int(rng.choice(np.flatnonzero(v)))
+            g.play_action(a); seq.append(a)
+    # Data held by the reference's own (uncollectable, old-API) test file envs/connect4/test_connect4.py,
+    # re-expressed for the fixed 6x7 new API: boards are embedded bottom-left into 6x7, the expected winner stone is
+    # the old test's `expected_end_state * player` (:99-151); move list -> board (:31-39); valid-move table (:58-64).
+    old = [
+        ([[0] * 7] * 5, 1, 0),
+        ([[0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1, 0], [0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 1, 0, 0, 0], [0, 0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0]], 1, 1),
+        ([[0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 1, 0, 0, 0], [0, 0, 1, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0]], -1, -1),
+        ([[0, 0, 0, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 1, 0]], -1, -1),
+        ([[0, 0, 0, -1], [0, 0, -1, 0], [0, -1, 0, 0], [-1, 0, 0, 0]], 1, -1),
+        ([[0, 0, 0, 0, 1], [0, 0, 0, 1, 0], [0, 0, 1, 0, 0], [0, 1, 0, 0, 0]], -1, -1),
+        ([[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 0, 1, 0]], -1, -1),
+        ([[0, 0, 0, 0, 0, 0, 0], [0, 0, 0, -1, 0, 0, 0], [0, 0, 0, -1, 0, 0, 1], [0, 0, 0, 1, 1, -1, -1], [0, 0, 0, -1, 1, 1, 1], [0, -1, 0, -1, 1, -1, 1]], -1, 0),
+        ([[0, 0, 0, 0, 0, 0, 0], [0, 0, 0, -1, 0, 0, 0], [1, 0, 1, -1, 0, 0, 0], [-1, -1, 1, 1, 0, 0, 0], [1, 1, 1, -1, 0, 0, 0], [1, -1, 1, -1, 0, -1, 0]], -1, -1),
+        ([[0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0], [0, 0, 0, -1, 0, 0, 0], [0, 0, 1, 1, -1, 0, -1], [0, 0, -1, 1, 1, 1, 1], [-1, 0, -1, 1, -1, -1, -1]], 1, 1),
+    ]
+    end_boards, end_ws, end_winner = [], [], []
+    for b, player, end_state in old:
+        b = np.array(b, np.int8)
+        full = np.zeros((6, 7), np.int8)
+        full[6 - b.shape[0]:, :b.shape[1]] = b
+        g = Game(); g._board.pieces = full.astype(np.intc)
+        w = np.asarray(g.win_state(), np.uint8)
+        winner = end_state * player
+        assert (w[0] == (winner == 1)) and (w[1] == (winner == -1)), (full, w, winner)   # reference vs its own test data
+        end_boards.append(full); end_ws.append(w); end_winner.append(winner)
+    end_boards = np.array(end_boards)
+    g = Game()
+    for a in [4, 5, 4, 3, 0, 6]:
+        g.play_action(a)
+    moves_board = c4_ref_to_cells(g).reshape(6, 7)
+    assert (moves_board == np.array([[0] * 7] * 4 + [[0, 0, 0, 0, 1, 0, 0], [1, 0, 0, -1, 1, -1, -1]])).all()
+    vm_moves = [[], [0, 1, 2, 3, 4, 5, 6], [0, 1, 2, 3, 4, 5, 6] * 5, [0, 1, 2, 3, 4, 5, 6] * 6, [0, 1, 2] * 3 + [3, 4, 5, 6] * 6]
+    vm_expected = [[1] * 7, [1] * 7, [1] * 7, [0] * 7, [1] * 3 + [0] * 4]
+    vm_tab = np.full((5, 42), -1, np.int8)
+    for i, (mv, ex) in enumerate(zip(vm_moves, vm_expected)):
+        g = Game()
+        for a in mv:
+            g._board.add_stone(a, 1)        # old API placed stones without win checks; valid_moves only needs occupancy
+        assert list(np.asarray(g.valid_moves())) == ex
+        vm_tab[i, :len(mv)] = mv
+    np.savez_compressed(os.path.join(OUT, 'c4_rules.npz'), moves=np.array(moves), lens=np.array(lens, np.int16),
+                        valids=np.array(valids), cells=np.array(cells), ws=np.array(ws),
+                        obs_crc=np.array(obs_crc, np.uint32), obs_sample=np.array(obs_sample, np.float32),
+                        end_boards=end_boards, end_ws=np.array(end_ws), end_winner=np.array(end_winner, np.int8),
+                        moves_board=moves_board, vm_moves=vm_tab, vm_expected=np.array(vm_expected, np.uint8))
+    print('c4_rules: %d positions' % len(lens))
+
+
+# ------------------------------------------------------------------------------------------------- tree
+TREE_CONFIGS = [
+    # name, cpuct, fpu, noise, temp, sims
+    ('default', 1.25, 0.2, False, False, 100),
+    ('c4train', 4.0, 0.4, False, False, 100),
+    ('noise', 1.25, 0.2, True, False, 60),
+    ('noise_temp', 4.0, 0.4, True, True, 60),
+]
+PROB_TEMPS = [1.0, 0.5, 0.25, 0.2, 0.0]
+
+
+def gen_tree(game_cls, game_id, name, n_roots, seed=7, configs=TREE_CONFIGS, max_prefix=30):
+    from alphazero.MCTS import MCTS
+    gi = ol.game_info(game_id)
+    A, NV = gi.action_size, gi.num_players + 1
+    rng = np.random.RandomState(seed)
+    out = {}
+    prefixes = []
+    for r in range(n_roots):                  # root positions = random legal prefixes (may include none)
+        g = game_cls(); seq = []
+        L = 0 if r == 0 else rng.randint(0, max_prefix)
+        for _ in range(L):
+            v = np.flatnonzero(np.asarray(g.valid_moves()))
+            a = int(rng.choice(v))
+            g2 = g.clone(); g2.play_action(a)
+            if np.asarray(g2.win_state()).any():
+                break
+            g = g2; seq.append(a)
+        prefixes.append(seq)
+    PL = max(len(p) for p in prefixes) + 1
+    pre = np.full((n_roots, PL), -1, np.int16)
+    for r, p in enumerate(prefixes):
+        pre[r, :len(p)] = p
+    out['prefix'] = pre
+    for (cname, cpuct, fpu, noise, temp, sims) in configs:
+        tape = rh.Tape(seed * 1000 + rh.crc(np.frombuffer(cname.encode(), np.uint8)) % 997)
+        tape.install()
+        try:
+            args = rh.ref_args(game_cls, cpuct=cpuct, fpu_reduction=fpu)
+            paths = np.full((n_roots, sims, 24), -1, np.int16)
+            depth = np.zeros((n_roots, sims), np.int16)
+            rootn = np.zeros((n_roots, sims, A), np.int16)
+            rootq = np.zeros((n_roots, sims, A), np.float32)
+            kmax = 64 if A > 64 else A
+            fin = {k: [] for k in ('a', 'n', 'q', 'p', 'v', 'counts', 'probs', 'vmax', 'vavg', 'root_n', 'maxdepth', 'ctr')}
+            for r in range(n_roots):
+                g = game_cls()
+                for a in prefixes[r]:
+                    g.play_action(a)
+                m = MCTS(args)
+                tape.stream = r
+                for s in range(sims):
+                    leaf = m.find_leaf(g)
+                    # leaf path = actions along the descent; recover from m._path + curnode
+                    acts = [n.a for n in m._path[1:]] + ([m._curnode.a] if m._path else [])
+                    depth[r, s] = m.depth
+                    paths[r, s, :min(len(acts), 24)] = acts[:24]
+                    p, v = ol.fake_eval(tape.seed, r, s, A, NV)
+                    m.process_results(leaf, v, p, noise, temp)
+                    for c in m._root._children:
+                        rootn[r, s, c.a] = c.n; rootq[r, s, c.a] = c.q
+                ch = m._root._children
+                fin['a'].append(np.array([c.a for c in ch] + [-1] * (kmax - len(ch)), np.int16)[:kmax])
+                fin['n'].append(np.array([c.n for c in ch] + [0] * (kmax - len(ch)), np.int32)[:kmax])
+                for f in ('q', 'p', 'v'):
+                    fin[f].append(np.array([getattr(c, f) for c in ch] + [0] * (kmax - len(ch)), np.float32)[:kmax])
+                fin['counts'].append(np.asarray(m.counts(g)).astype(np.int32))
+                fin['probs'].append(np.array([m.probs(g, t) for t in PROB_TEMPS], np.float32))
+                fin['vmax'].append(m.value(False)); fin['vavg'].append(m.value(True))
+                fin['root_n'].append(m._root.n); fin['maxdepth'].append(m.max_depth)
+                fin['ctr'].append(tape.ctr[r])
+            out[cname + '_seed'] = np.uint64(tape.seed)
+            out[cname + '_cfg'] = np.array([cpuct, fpu, float(noise), float(temp), sims], np.float64)
+            out[cname + '_paths'] = paths; out[cname + '_depth'] = depth
+            out[cname + '_rootn'] = rootn; out[cname + '_rootq'] = rootq
+            for k, v in fin.items():
+                out[cname + '_' + k] = np.array(v)
+        finally:
+            tape.uninstall()
+    out['prob_temps'] = np.array(PROB_TEMPS, np.float32)
+    np.savez_compressed(os.path.join(OUT, name + '_tree.npz'), **out)
+    print('%s_tree: %d roots x %s' % (name, n_roots, [c[0] for c in configs]))
+
+
+# ------------------------------------------------------------------------------------------------ agent
+AGENT_CONFIGS = [
+    # name, B, sims, games, kwargs
+    ('plain', 8, 25, 12, dict()),
+    ('noisy', 6, 20, 8, dict(add_root_noise=True, add_root_temp=True, cpuct=4.0, fpu_reduction=0.4)),
+    ('fastmix', 6, 16, 8, dict(probFastSim=0.5, numFastSims=6, symmetricSamples=False)),
+    ('reset', 4, 12, 5, dict(mctsResetThreshold=3)),
+    ('warmup', 6, 10, 8, dict(numWarmupSims=5)),
+]
+
+
+def run_ref_agent(game_cls, game_id, cname, B, sims, games, kw, seed, slot_base=0, is_arena=False, max_rounds=400):
+    import torch
+    gi = ol.game_info(game_id)
+    A, NV = gi.action_size, gi.num_players + 1
+    is_warmup = cname == 'warmup'
+    tape = rh.Tape(seed)
+    tape.install()
+    rec = dict(actions=[], counts=[], obs_crc=[], games_played=[], fast=[], sims=[])
+    try:
+        args = rh.ref_args(game_cls, numMCTSSims=sims, gamesPerIteration=games, **kw)
+        ag = rh.make_ref_agent(game_cls, game_id, B, args, tape, is_arena=is_arena, is_warmup=is_warmup,
+                               slot_base=slot_base)
+        step = 0
+        for rnd in range(max_rounds):
+            if ag.games_played.value >= args.gamesPerIteration:
+                break
+            tape.stream = rh.AGENT_STREAM + slot_base
+            ag.fast = np.random.random_sample() < args.probFastSim
+            nsims = args.numFastSims if ag.fast else (args.numMCTSSims if not is_warmup else args.numWarmupSims)
+            rec['fast'].append(int(ag.fast)); rec['sims'].append(nsims)
+            for s in range(nsims):
+                ag.generateBatch()
+                if not is_warmup:
+                    if is_arena:
+                        data = ag.output_queue.items.pop()
+                        rows = torch.cat([d for d in data if not isinstance(d, list)])
+                        rec['obs_crc'].append([rh.crc(rows[i].numpy()) for i in range(B)])
+                        rec.setdefault('row_game', []).append(list(ag.batch_indices))
+                        for row in range(B):
+                            p, v = ol.fake_eval(seed, slot_base + ag.batch_indices[row], step, A, NV)
+                            ag.policy_tensor[row] = torch.from_numpy(p); ag.value_tensor[row] = torch.from_numpy(v)
+                    else:
+                        rec['obs_crc'].append([rh.crc(ag.batch_tensor[i].numpy()) for i in range(B)])
+                        for i in range(B):
+                            p, v = ol.fake_eval(seed, slot_base + i, step, A, NV)
+                            ag.policy_tensor[i] = torch.from_numpy(p); ag.value_tensor[i] = torch.from_numpy(v)
+                ag.processBatch()
+                step += 1
+            cts = []
+            for i in range(B):
+                m = ag.mcts[i][ag.games[i].player] if is_arena else ag.mcts[i]
+                cts.append(np.asarray(m.counts(ag.games[i])).astype(np.int32))
+            rec['counts'].append(cts)
+            nlog = len(tape.choice_log)
+            ag.playMoves()
+            acts = [-1] * B
+            for (st, idx) in tape.choice_log[nlog:]:
+                acts[st - slot_base] = idx
+            rec['actions'].append(acts)
+            rec['games_played'].append(ag.games_played.value)
+        samples = ag.output_queue.items if not is_arena else []
+        results = ag.result_queue.items
+        out = {
+            'seed': np.uint64(seed), 'B': B, 'sims': sims, 'games': games,
+            'actions': np.array(rec['actions'], np.int16), 'counts': np.array(rec['counts'], np.int32),
+            'obs_crc': np.array(rec['obs_crc'], np.uint32).reshape(-1, B), 'games_played': np.array(rec['games_played'], np.int32),
+            'fast': np.array(rec['fast'], np.int8), 'round_sims': np.array(rec['sims'], np.int32),
+            's_obs': np.array([s[0] for s in samples], np.float32).reshape(len(samples), gi.obs_c, gi.obs_h, gi.obs_w),
+            's_pi': np.array([s[1] for s in samples], np.float32).reshape(len(samples), A),
+            's_z': np.array([s[2] for s in samples], np.float32).reshape(len(samples), NV),
+            'r_ws': np.array([np.asarray(r[1], np.uint8) for r in results]).reshape(len(results), NV),
+            'r_turns': np.array([r[0].turns for r in results], np.int32),
+        }
+        if is_arena:
+            out['row_game'] = np.array(rec['row_game'], np.int32)
+            out['player_to_index'] = np.array(ag.player_to_index, np.int32)
+        return out, args
+    finally:
+        tape.uninstall()
+
+
+def gen_agent(game_cls, game_id, name, configs=AGENT_CONFIGS, seed=99):
+    out = {}
+    for ci, (cname, B, sims, games, kw) in enumerate(configs):
+        o, args = run_ref_agent(game_cls, game_id, cname, B, sims, games, kw, seed + ci, slot_base=0 if ci % 2 == 0 else 1000)
+        for k, v in o.items():
+            out[cname + '_' + k] = v
+        out[cname + '_slot_base'] = 0 if ci % 2 == 0 else 1000
+        print('  %s/%s: rounds=%d samples=%d results=%d games=%d' % (name, cname, len(o['actions']), len(o['s_pi']), len(o['r_turns']), o['games_played'][-1]))
+    np.savez_compressed(os.path.join(OUT, name + '_agent.npz'), **out)
+
+
+def main():
+    which = sys.argv[1:] or ['c4_rules', 'c4_tree', 'c4_agent']
+    rh.import_reference()
+    from alphazero.envs.connect4.connect4 import Game as C4
+    if 'c4_rules' in which:
+        gen_c4_rules()
+    if 'c4_tree' in which:
+        gen_tree(C4, ol.GAME_CONNECT4, 'c4', n_roots=64)
+    if 'c4_agent' in which:
+        gen_agent(C4, ol.GAME_CONNECT4, 'c4')
+
+
+if __name__ == '__main__':
+    main()

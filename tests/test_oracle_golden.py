@@ -1,0 +1,241 @@
+"""Pin the CPU oracle (oracle/*.c) against golden vectors produced by the ACTUAL reference (tests/golden/*.npz,
+made by tests/golden/make_goldens.py).  Bit-exact on integers and float32 values unless a tolerance is stated."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+C4 = ol.GAME_CONNECT4
+
+
+def crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------ rules
+def test_c4_rules_playouts():
+    d = np.load(os.path.join(G, 'c4_rules.npz'))
+    n = len(d['lens'])
+    k = 0
+    for i in range(n):
+        g = ol.OGame(C4)
+        for a in d['moves'][i][:d['lens'][i]]:
+            g.play(a)
+        assert (g.cells() == d['cells'][i]).all()
+        assert (g.valid_moves() == d['valids'][i]).all()
+        assert (g.win_state() == d['ws'][i]).all()
+        o = g.observation()
+        assert crc(o) == d['obs_crc'][i]
+        if k < len(d['obs_sample']) and i == k:
+            assert (o == d['obs_sample'][k]).all()
+            k += 1
+
+
+def test_c4_reference_test_data():
+    """The reference's own test tables (envs/connect4/test_connect4.py:31-39,58-64,99-151) as data."""
+    d = np.load(os.path.join(G, 'c4_rules.npz'))
+    for b, ws, winner in zip(d['end_boards'], d['end_ws'], d['end_winner']):
+        g = ol.OGame(C4)
+        for i, v in enumerate(b.reshape(-1)):
+            g.s.cells[i] = int(v)
+        w = g.win_state()
+        assert (w == ws).all()
+        assert w[0] == (winner == 1) and w[1] == (winner == -1)
+    g = ol.OGame(C4)
+    for a in [4, 5, 4, 3, 0, 6]:
+        g.play(a)
+    assert (g.cells().reshape(6, 7) == d['moves_board']).all()
+    for mv, ex in zip(d['vm_moves'], d['vm_expected']):
+        g = ol.OGame(C4)
+        for a in mv[mv >= 0]:
+            g.play(a)
+        assert (g.valid_moves() == ex).all()
+    g = ol.OGame(C4)
+    for _ in range(6):
+        g.play(4)
+    with pytest.raises(ValueError):
+        g.play(4)
+
+
+# ------------------------------------------------------------------------------------- numpy restatements
+def test_np_sum_restatement():
+    rng = np.random.RandomState(0)
+    for n in [1, 3, 7, 8, 9, 25, 64, 127, 128, 129, 130, 200, 256, 588, 1280, 2420]:
+        for rep in range(20):
+            a = rng.rand(n).astype(np.float32)
+            if rep % 3 == 0:
+                a[rng.rand(n) < 0.8] = 0
+            if rep % 5 == 0:
+                a *= np.float32(10.0) ** rng.randint(-20, 5, n).astype(np.float32)
+            assert ol.lib().azo_np_sum_f32(a, n) == np.sum(a), n
+
+
+def test_np_pow_restatement_exact_tier():
+    rng = np.random.RandomState(1)
+    a = rng.rand(500).astype(np.float32)
+    for temp in [1.0, 0.5]:
+        ex = 1.0 / float(np.float32(temp))
+        ref = a ** ex
+        got = np.array([ol.lib().azo_np_pow_f32(x, ex) for x in a], np.float32)
+        assert (ref == got).all()
+
+
+def test_np_pow_restatement_ulp_tier():
+    rng = np.random.RandomState(2)
+    a = rng.rand(500).astype(np.float32)
+    for temp in [0.25, 0.2, 1.1]:
+        ex = 1.0 / float(np.float32(temp))
+        ref = a ** ex
+        got = np.array([ol.lib().azo_np_pow_f32(x, ex) for x in a], np.float32)
+        ulp = np.abs(ref.view(np.int32).astype(np.int64) - got.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1            # tolerance: 1 ulp (powf is not correctly rounded everywhere)
+
+
+def test_det_math_accuracy():
+    rng = np.random.RandomState(3)
+    xs = np.concatenate([rng.rand(2000), 10.0 ** rng.uniform(-300, 300, 2000)])
+    for x in xs:
+        assert abs(ol.lib().azo_det_log(x) - np.log(x)) <= 4e-15 * max(1.0, abs(np.log(x)))
+    for x in rng.uniform(-700, 700, 3000):
+        assert abs(ol.lib().azo_det_exp(x) / np.exp(x) - 1.0) <= 1e-14
+
+
+def test_dirichlet_statistics():
+    L = ol.lib()
+    for k, alpha in [(7, 10.83 / 7), (40, 10.83 / 40)]:
+        acc = np.zeros(k); acc2 = np.zeros(k)
+        n = 4000
+        out = np.zeros(k)
+        for i in range(n):
+            L.azo_tape_dirichlet(123, 5, i, k, alpha, out)
+            assert abs(out.sum() - 1) < 1e-12 and (out >= 0).all()
+            acc += out; acc2 += out * out
+        mean = acc / n
+        var = acc2 / n - mean ** 2
+        a0 = alpha * k
+        assert np.allclose(mean, 1.0 / k, rtol=0.15)
+        assert np.allclose(var, (1.0 / k) * (1 - 1.0 / k) / (a0 + 1), rtol=0.25)
+
+
+# ------------------------------------------------------------------------------------------------- tree
+TREE_CFGS = ['default', 'c4train', 'noise', 'noise_temp']
+
+
+@pytest.mark.parametrize('cname', TREE_CFGS)
+def test_c4_tree_vs_reference(cname):
+    d = np.load(os.path.join(G, 'c4_tree.npz'))
+    gi = ol.game_info(C4)
+    A, NV = gi.action_size, gi.num_players + 1
+    cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
+    noise, temp, sims = bool(noise), bool(temp), int(sims)
+    seed = int(d[cname + '_seed'])
+    exact = not temp       # root temperature goes through powf: 1-ulp tier
+    for r in range(d['prefix'].shape[0]):
+        g = ol.OGame(C4)
+        for a in d['prefix'][r]:
+            if a >= 0:
+                g.play(a)
+        m = ol.OMCTS(C4, cpuct=cpuct, fpu_reduction=fpu, seed=seed, stream=r)
+        for s in range(sims):
+            leaf, _ = m.find_leaf(g)
+            path = m.last_path()
+            assert len(path) == d[cname + '_depth'][r, s]
+            assert (path[:24] == d[cname + '_paths'][r, s][:len(path)]).all(), (r, s)
+            p, v = ol.fake_eval(seed, r, s, A, NV)
+            m.process_results(v, p, noise, temp)
+            ch = m.root_children()
+            n = np.zeros(A, np.int16); q = np.zeros(A, np.float32)
+            n[ch['a']] = ch['n']; q[ch['a']] = ch['q']
+            assert (n == d[cname + '_rootn'][r, s]).all(), (r, s)
+            if exact:
+                assert (q == d[cname + '_rootq'][r, s]).all(), (r, s)
+            else:
+                assert np.allclose(q, d[cname + '_rootq'][r, s], atol=1e-5)
+        ch = m.root_children()
+        k = len(ch['a'])
+        assert (ch['a'] == d[cname + '_a'][r][:k]).all() and (d[cname + '_a'][r][k:] == -1).all()
+        assert (ch['n'] == d[cname + '_n'][r][:k]).all()
+        for f in ('q', 'p', 'v'):
+            if exact:
+                assert (ch[f] == d[cname + '_' + f][r][:k]).all(), (f, r)
+            else:
+                assert np.allclose(ch[f], d[cname + '_' + f][r][:k], atol=1e-5)
+        assert (m.counts() == d[cname + '_counts'][r]).all()
+        for ti, t in enumerate(d['prob_temps']):
+            pr = m.probs(float(t))
+            ref = d[cname + '_probs'][r][ti]
+            if t in (1.0, 0.5, 0.0):
+                assert (pr == ref).all(), (r, t)
+            else:
+                assert np.allclose(pr, ref, rtol=3e-7, atol=1e-12), (r, t)
+        assert m.value(False) == d[cname + '_vmax'][r]
+        assert m.value(True) == d[cname + '_vavg'][r]
+        assert m.root_n == d[cname + '_root_n'][r]
+        assert m.max_depth == d[cname + '_maxdepth'][r]
+        assert ol.lib().azo_mcts_tape_ctr(m.h) == d[cname + '_ctr'][r]
+
+
+# ------------------------------------------------------------------------------------------------ agent
+AGENT_CFGS = {
+    'plain': dict(),
+    'noisy': dict(add_root_noise=True, add_root_temp=True, cpuct=4.0, fpu_reduction=0.4),
+    'fastmix': dict(prob_fast=0.5, fast_sims=6, symmetric=False),
+    'reset': dict(reset_threshold=3),
+    'warmup': dict(warmup_sims=5, is_warmup=True),
+}
+
+
+def run_oracle_agent(game, d, cname, kw):
+    gi = ol.game_info(game)
+    A, NV = gi.action_size, gi.num_players + 1
+    B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
+    seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
+    ag = ol.OAgent(game, B, sims=sims, games_per_iteration=games, seed=seed, slot_base=slot_base, **kw)
+    rec = dict(actions=[], counts=[], obs_crc=[], games_played=[], fast=[], sims=[])
+    step = 0
+    while ag.games_played < games:
+        ns = ag.begin_round()
+        rec['sims'].append(ns)
+        for s in range(ns):
+            obs, rg, rm = ag.generate_batch()
+            pol = np.zeros((B, A), np.float32); val = np.zeros((B, NV), np.float32)
+            if not kw.get('is_warmup'):
+                rec['obs_crc'].append([crc(obs[i]) for i in range(B)])
+                for row in range(B):
+                    pol[row], val[row] = ol.fake_eval(seed, slot_base + rg[row], step, A, NV)
+            ag.process_batch(pol, val)
+            step += 1
+        cts = []
+        for i in range(B):
+            ch = ag.root_children(i, ag.state(i).player)
+            c = np.zeros(A, np.int32); c[ch['a']] = ch['n']
+            cts.append(c)
+        rec['counts'].append(cts)
+        ag.play_moves()
+        rec['actions'].append(ag.last_actions())
+        rec['games_played'].append(ag.games_played)
+    return ag, rec
+
+
+@pytest.mark.parametrize('cname', list(AGENT_CFGS))
+def test_c4_agent_vs_reference(cname):
+    d = np.load(os.path.join(G, 'c4_agent.npz'))
+    kw = AGENT_CFGS[cname]
+    ag, rec = run_oracle_agent(C4, d, cname, kw)
+    assert (np.array(rec['sims']) == d[cname + '_round_sims']).all()
+    assert (np.array(rec['actions']) == d[cname + '_actions']).all()
+    assert (np.array(rec['counts']) == d[cname + '_counts']).all()
+    assert (np.array(rec['games_played']) == d[cname + '_games_played']).all()
+    if not kw.get('is_warmup'):
+        assert (np.array(rec['obs_crc'], np.uint32) == d[cname + '_obs_crc']).all()
+    obs, pi, z = ag.samples()
+    assert obs.shape == d[cname + '_s_obs'].shape
+    assert (obs == d[cname + '_s_obs']).all()
+    assert (pi == d[cname + '_s_pi']).all()          # history pi is probs(T=1): exact tier
+    assert (z == d[cname + '_s_z']).all()
+    ws, turns, slot = ag.results()
+    assert (ws == d[cname + '_r_ws']).all() and (turns == d[cname + '_r_turns']).all()
