@@ -1,0 +1,45 @@
+"""Compile libazg_hip.so (the HIP engine + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m alphazero_general_amd.build
+
+-ffp-contract=off is REQUIRED: bit-exact visit counts depend on unfused float arithmetic.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'csrc', 'azg_engine.hip')
+DEPS = [os.path.join(HERE, 'csrc', f) for f in ('azg_engine.hip', 'azg_kernels.h', 'azg_games.h', 'azg_device.h')] + \
+       [os.path.join(os.path.dirname(HERE), 'include', 'azg.h')]
+OUT = os.path.join(HERE, 'lib', 'libazg_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc()] + FLAGS + ['-o', OUT, SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,234 @@
+// azg_device.h -- device-side building blocks of the MI355X self-play engine (gfx950, wave64).
+//
+// Layout (DESIGN.md "Data layout in HBM"):
+//   Node      32-byte record, one per tree node; the k children of a node are k consecutive records in list order
+//             (the reference's shuffled Node._children, alphazero/MCTS.pyx:76-79), so one wavefront reads a whole
+//             child block with two coalesced dwordx4 loads per lane.
+//   TreeHdr   per tree: root index, arena cursor, leaf of the last find_leaf, depth bookkeeping.
+// Arithmetic follows the C that Cython generates from MCTS.pyx; this file must be compiled with
+// -ffp-contract=off (no FMA contraction) -- bit-exact visit counts depend on it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/azg.h"
+
+#define AZG_DEV __device__ __forceinline__
+#define AZG_HD __host__ __device__ __forceinline__
+
+namespace azg {
+
+// ------------------------------------------------------------------------------------------------ node store
+struct __attribute__((aligned(32))) Node {
+    int32_t  n;            // visits                      Node.n   (MCTS.pyx:55)
+    float    q;            // mean value, parent's mover   Node.q   (:53)
+    float    p;            // prior                        Node.p   (:56)
+    float    v;            // own-viewpoint first value    Node.v   (:54)
+    int32_t  first_child;  // index of child block in this tree's arena, -1 = no children   Node._children (:50)
+    uint16_t a;            // action                       Node.a   (:51)
+    uint16_t nchild;
+    uint8_t  player;       // player to move               Node.player (:57)
+    uint8_t  e;            // terminal flags bit j = e[j]  Node.e   (:52)
+    uint16_t pad0;
+    int32_t  pad1;
+};
+static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
+
+struct __attribute__((aligned(32))) TreeHdr {
+    int32_t root;          // MCTS._root
+    int32_t alloc;         // arena cursor (next free node index)
+    int32_t cur;           // MCTS._curnode after find_leaf
+    int32_t depth;         // MCTS.depth
+    int32_t max_depth;     // MCTS.max_depth
+    int32_t expanded;      // last find_leaf took the n == 0 branch
+    int32_t pad[2];
+};
+
+struct SumPlan {           // numpy float32 pairwise-sum structure for a length-n array (see np_sum_wave)
+    int32_t n, nleaves, nprog, pad;
+    int16_t leaf_off[64], leaf_len[64];
+    uint8_t prog[128];     // 0 = push next leaf sum, 1 = add top two
+};
+
+// Engine view passed by value to every kernel.
+struct View {
+    Node     *nodes;       // [trees][cap]
+    TreeHdr  *hdr;         // [trees]
+    uint32_t *path;        // [trees][maxd]  (node index | mover << 28) for X_1..X_depth
+    azg_state *states;     // [B] root states
+    azg_state *leaf_states;// [B]
+    uint64_t *tape_ctr;    // [B]
+    int32_t  *next_reset;  // [B]
+    int32_t  *hist_len;    // [B]
+    azg_state *hist_state; // [B][max_turns]
+    float    *hist_pi;     // [B][max_turns][A]
+    int32_t  *last_action; // [B]
+    int32_t  *fin_flag;    // [B] 0 none, 1 finished
+    int32_t  *fin_ridx;    // [B] result index
+    int32_t  *fin_counted; // [B]
+    int32_t  *fin_soff;    // [B] sample offset
+    int64_t  *slot_sims, *slot_exp;   // [B]
+    int32_t  *gcount;      // [8]: 0 games_played, 1 num_results, 2 num_examples, 3 error, 4 max_nodes
+    float    *ex_obs, *ex_pi, *ex_z;  // examples
+    uint8_t  *res_ws; int32_t *res_turns, *res_slot;
+    const float *temp_table; const SumPlan *plan;
+    int32_t B, T, cap, maxd, arena, ex_cap, res_cap, temp_len;
+    int32_t add_noise, add_temp, symmetric, reset_thr, games_cap, max_hist;
+    float cpuct, fpu_reduction, noise_frac, root_temp, arena_temp;
+    uint64_t seed, slot_base;
+};
+
+enum { GC_GAMES = 0, GC_RESULTS = 1, GC_EXAMPLES = 2, GC_ERROR = 3, GC_MAXNODES = 4 };
+
+// ------------------------------------------------------------------------------------------------ random tape
+// Definition in DESIGN.md "Random tape"; independent re-implementation of the spec (the oracle has its own).
+AZG_HD uint64_t sm64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31; return z;
+}
+AZG_HD uint64_t tape_u64(uint64_t seed, uint64_t stream, uint64_t ctr) {
+    uint64_t z = sm64(seed + 0x9E3779B97F4A7C15ULL * (stream + 1));
+    z = sm64(z ^ (0xD1B54A32D192ED03ULL * (ctr + 1)));
+    return sm64(z + 0x9E3779B97F4A7C15ULL);
+}
+AZG_HD double u53(uint64_t z) { return (double)(z >> 11) * (1.0 / 9007199254740992.0); }
+AZG_HD double u52_open(uint64_t z) { return ((double)(z >> 12) + 0.5) * (1.0 / 4503599627370496.0); }
+
+AZG_HD double det_log(double x) {
+    union { double d; uint64_t u; } c; c.d = x;
+    int e = (int)((c.u >> 52) & 0x7FF);
+    if (e == 0) { c.d = x * 18014398509481984.0; e = (int)((c.u >> 52) & 0x7FF) - 54; }
+    e -= 1023;
+    c.u = (c.u & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+    double m = c.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double f = m - 1.0, s = f / (2.0 + f), z = s * s;
+    double r = 1.0 / 23.0;
+    r = r * z + 1.0 / 21.0; r = r * z + 1.0 / 19.0; r = r * z + 1.0 / 17.0; r = r * z + 1.0 / 15.0;
+    r = r * z + 1.0 / 13.0; r = r * z + 1.0 / 11.0; r = r * z + 1.0 / 9.0;  r = r * z + 1.0 / 7.0;
+    r = r * z + 1.0 / 5.0;  r = r * z + 1.0 / 3.0;  r = r * z + 1.0;
+    double lm = 2.0 * s * r;
+    return (double)e * 0.6931471803691238 + ((double)e * 1.9082149292705877e-10 + lm);
+}
+AZG_HD double det_exp(double x) {
+    if (x < -745.0) return 0.0;
+    if (x > 709.0) x = 709.0;
+    double t = x * 1.4426950408889634;
+    long long k = (long long)(t + (t < 0 ? -0.5 : 0.5));
+    double r = (x - (double)k * 0.6931471803691238) - (double)k * 1.9082149292705877e-10;
+    double p = 1.0 / 87178291200.0;
+    p = p * r + 1.0 / 6227020800.0; p = p * r + 1.0 / 479001600.0; p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;    p = p * r + 1.0 / 362880.0;    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;       p = p * r + 1.0 / 720.0;       p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;         p = p * r + 1.0 / 6.0;         p = p * r + 0.5;
+    p = p * r + 1.0;                p = p * r + 1.0;
+    int k1 = (int)(k / 2), k2 = (int)k - k1;
+    union { double d; uint64_t u; } s1, s2;
+    s1.u = (uint64_t)(k1 + 1023) << 52; s2.u = (uint64_t)(k2 + 1023) << 52;
+    return p * s1.d * s2.d;
+}
+
+struct SubStream { uint64_t key, sub, j; };
+AZG_HD uint64_t ss_next(SubStream &s) { return tape_u64(s.key, s.sub, s.j++); }
+AZG_HD double ss_normal(SubStream &s) {
+    for (;;) {
+        double a = 2.0 * u52_open(ss_next(s)) - 1.0;
+        double b = 2.0 * u52_open(ss_next(s)) - 1.0;
+        double r = a * a + b * b;
+        if (r < 1.0 && r > 0.0) return a * sqrt(-2.0 * det_log(r) / r);
+    }
+}
+AZG_HD double ss_gamma(SubStream &s, double alpha) {
+    double boost = 1.0, a = alpha;
+    if (a < 1.0) { double u = u52_open(ss_next(s)); boost = det_exp(det_log(u) / a); a = a + 1.0; }
+    double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x, v;
+        do { x = ss_normal(s); v = 1.0 + c * x; } while (v <= 0.0);
+        v = v * v * v;
+        double u = u52_open(ss_next(s));
+        double x2 = x * x;
+        if (u < 1.0 - 0.0331 * (x2 * x2)) return d * v * boost;
+        if (det_log(u) < 0.5 * x2 + d * (1.0 - v + det_log(v))) return d * v * boost;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wave helpers
+AZG_DEV int   rl(int x, int lane)   { return __builtin_amdgcn_readlane(x, lane); }
+AZG_DEV float rl(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+AZG_DEV unsigned rl(unsigned x, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)x, lane); }
+AZG_DEV double rl(double x, int lane) {
+    union { double d; int i[2]; } c; c.d = x;
+    c.i[0] = __builtin_amdgcn_readlane(c.i[0], lane); c.i[1] = __builtin_amdgcn_readlane(c.i[1], lane);
+    return c.d;
+}
+AZG_DEV uint64_t rl(uint64_t x, int lane) {
+    union { uint64_t u; int i[2]; } c; c.u = x;
+    c.i[0] = __builtin_amdgcn_readlane(c.i[0], lane); c.i[1] = __builtin_amdgcn_readlane(c.i[1], lane);
+    return c.u;
+}
+AZG_DEV float wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+AZG_DEV int wave_sum_i(int m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    return m;
+}
+// exclusive prefix sum over lanes (int)
+AZG_DEV int wave_excl_scan(int x, int lane) {
+    int s = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(s, o); if (lane >= o) s += t; }
+    return s - x;
+}
+
+// numpy float32 `array ** python_float` (weak-scalar exponent -> float32; fast paths 1, 2, 0.5; else powf).
+// powf is evaluated as a double pow rounded to float: correctly rounded except in ~2^-29 of cases (1-ulp tier).
+AZG_DEV float np_pow_f32(float x, double e) {
+    if (e == 1.0) return x;
+    if (e == 2.0) return x * x;
+    if (e == 0.5) return sqrtf(x);
+    return (float)pow((double)x, (double)(float)e);
+}
+
+// numpy float32 pairwise np.sum over m[0..n) held in LDS, evaluated cooperatively by one wave with exactly
+// numpy's association order (loops_utils.h.src @TYPE@_pairwise_sum, PW_BLOCKSIZE 128): 8 strided accumulators per
+// <=128-element block, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail sequential, blocks combined by the
+// recursion tree encoded in `plan`.  Every lane returns the sum.  `scr` = 64 floats of LDS scratch.
+AZG_DEV float np_sum_wave(const float *m, const SumPlan *plan, float *scr, int lane) {
+    const int n = plan->n;
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res += m[i];
+        return res;
+    }
+    const int nl = plan->nleaves, g = lane >> 3, j = lane & 7;
+    for (int l0 = 0; l0 < nl; l0 += 8) {
+        int l = l0 + g;
+        float res = 0.f;
+        int off = 0, len = 8;
+        if (l < nl) { off = plan->leaf_off[l]; len = plan->leaf_len[l]; }
+        float r = m[off + j];
+        int lim = len - (len & 7);
+        for (int i = 8; i < lim; i += 8) r += m[off + i + j];
+        r = r + __shfl_xor(r, 1);
+        r = r + __shfl_xor(r, 2);
+        r = r + __shfl_xor(r, 4);
+        res = r;
+        for (int i = lim; i < len; i++) res += m[off + i];
+        if (l < nl && j == 0) scr[l] = res;
+    }
+    __syncthreads();
+    float st[8]; int sp = 0, li = 0;
+    for (int i = 0; i < plan->nprog; i++) {
+        if (plan->prog[i] == 0) st[sp++] = scr[li++];
+        else { st[sp - 2] = st[sp - 2] + st[sp - 1]; sp--; }
+    }
+    __syncthreads();
+    return st[0];
+}
+
+}  // namespace azg

@@ -1,0 +1,436 @@
+// azg_engine.hip -- host side of libazg_hip.so: the C ABI of include/azg.h over the kernels of azg_kernels.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC  (alphazero_general_amd/build.py)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "azg_kernels.h"
+
+using namespace azg;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(AZG_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+struct EvPair { hipEvent_t a, b; };
+
+struct azg_engine {
+    azg_config cfg;
+    azg_game_info gi;
+    View v;
+    std::vector<void *> allocs;
+    int32_t *d_p2i = nullptr, *d_ok = nullptr;
+    bool profile = false;
+    std::vector<EvPair> ev[3];
+    double ms[3] = {0, 0, 0};
+    int64_t launches[3] = {0, 0, 0};
+    std::vector<EvPair> pool;
+};
+
+static const azg_game_info k_info[] = {
+    // action_size, c,h,w, players, has_draw, max_turns, nsym, cells, max_children
+    {C4::A, C4::OBS_C, C4::H, C4::W, C4::P, C4::HAS_DRAW, C4::MAX_TURNS, C4::NSYM, C4::CELLS, C4::MAXK},
+};
+static const int k_num_games = 1;
+
+extern "C" int azg_abi_version(void) { return AZG_ABI_VERSION; }
+extern "C" const char *azg_last_error(void) { return g_err.c_str(); }
+extern "C" int azg_game_info_get(int game, azg_game_info *out) {
+    if (game < 0 || game >= k_num_games || !out) return fail(AZG_E_INVALID_ARG, "unknown game id");
+    *out = k_info[game];
+    return AZG_OK;
+}
+extern "C" int azg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+extern "C" uint64_t azg_tape_u64(uint64_t seed, uint64_t stream, uint64_t ctr) { return tape_u64(seed, stream, ctr); }
+extern "C" double azg_tape_uniform(uint64_t seed, uint64_t stream, uint64_t ctr) { return u53(tape_u64(seed, stream, ctr)); }
+extern "C" void azg_tape_shuffle_pos(uint64_t seed, uint64_t stream, uint64_t ctr, int k, int32_t *pos) {
+    std::vector<uint64_t> key((size_t)k);
+    for (int i = 0; i < k; i++) key[i] = tape_u64(seed, stream, ctr + (uint64_t)i);
+    for (int i = 0; i < k; i++) {
+        int r = 0;
+        for (int j = 0; j < k; j++) r += (key[j] < key[i]) || (key[j] == key[i] && j < i);
+        pos[i] = r;
+    }
+}
+
+// numpy pairwise-sum structure for length n (see np_sum_wave)
+static void plan_rec(int off, int n, SumPlan &p) {
+    if (n <= 128) { p.leaf_off[p.nleaves] = (int16_t)off; p.leaf_len[p.nleaves] = (int16_t)n; p.nleaves++; p.prog[p.nprog++] = 0; return; }
+    int n2 = n / 2; n2 -= n2 % 8;
+    plan_rec(off, n2, p); plan_rec(off + n2, n - n2, p);
+    p.prog[p.nprog++] = 1;
+}
+
+template <typename T> static int dalloc(azg_engine *e, T **p, size_t count) {
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    HIPCHK(hipMalloc(&q, bytes));
+    HIPCHK(hipMemset(q, 0, bytes));
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return AZG_OK;
+}
+#define DALLOC(ptr, count) do { int _r = dalloc(e, &(ptr), (size_t)(count)); if (_r != AZG_OK) return _r; } while (0)
+
+// dispatch a templated kernel launch on the game id
+#define GAME_SWITCH(e, CALL) \
+    switch ((e)->cfg.game) { \
+    case AZG_GAME_CONNECT4: { using G = C4; CALL; } break; \
+    default: return fail(AZG_E_UNSUPPORTED, "game has no device rules"); }
+
+static void prof_begin(azg_engine *e, hipStream_t s, int fam, EvPair &p) {
+    if (!e->profile) return;
+    if (!e->pool.empty()) { p = e->pool.back(); e->pool.pop_back(); }
+    else { hipEventCreate(&p.a); hipEventCreate(&p.b); }
+    hipEventRecord(p.a, s);
+    (void)fam;
+}
+static void prof_end(azg_engine *e, hipStream_t s, int fam, EvPair &p) {
+    if (!e->profile) return;
+    hipEventRecord(p.b, s);
+    e->ev[fam].push_back(p);
+    e->launches[fam]++;
+}
+static void prof_drain(azg_engine *e) {
+    for (int f = 0; f < 3; f++) {
+        for (auto &p : e->ev[f]) {
+            hipEventSynchronize(p.b);
+            float t = 0; hipEventElapsedTime(&t, p.a, p.b);
+            e->ms[f] += t;
+            e->pool.push_back(p);
+        }
+        e->ev[f].clear();
+    }
+}
+
+extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
+    if (!cfg || !out) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (cfg->abi_version != AZG_ABI_VERSION) return fail(AZG_E_INVALID_ARG, "ABI version mismatch");
+    if (cfg->game < 0 || cfg->game >= k_num_games) return fail(AZG_E_UNSUPPORTED, "game has no device rules");
+    if (cfg->num_slots <= 0) return fail(AZG_E_INVALID_ARG, "num_slots must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(AZG_E_HIP, "no HIP device: libazg_hip has no CPU fallback");
+    HIPCHK(hipSetDevice(cfg->device));
+    azg_engine *e = new azg_engine();
+    e->cfg = *cfg; e->gi = k_info[cfg->game];
+    const azg_game_info &gi = e->gi;
+    View &v = e->v;
+    memset(&v, 0, sizeof(v));
+    v.B = cfg->num_slots; v.arena = cfg->arena ? 1 : 0; v.T = v.arena ? gi.num_players : 1;
+    v.cap = cfg->nodes_per_tree > 0 ? cfg->nodes_per_tree : gi.max_turns * 100 * gi.max_children + 64;
+    if (v.cap >= (1 << 28)) { delete e; return fail(AZG_E_INVALID_ARG, "nodes_per_tree must be < 2^28"); }
+    v.maxd = gi.max_turns + 2; v.max_hist = gi.max_turns + 1;
+    v.ex_cap = cfg->example_capacity; v.res_cap = cfg->result_capacity > 0 ? cfg->result_capacity : 4 * v.B + 1024;
+    v.add_noise = (cfg->add_root_noise && !v.arena) ? 1 : 0; v.add_temp = (cfg->add_root_temp && !v.arena) ? 1 : 0;
+    v.symmetric = cfg->symmetric_samples; v.reset_thr = cfg->mcts_reset_threshold; v.games_cap = cfg->games_per_iteration;
+    v.cpuct = cfg->cpuct; v.fpu_reduction = cfg->fpu_reduction; v.noise_frac = cfg->root_noise_frac;
+    v.root_temp = cfg->root_policy_temp; v.arena_temp = cfg->arena_temp;
+    v.seed = cfg->tape_seed; v.slot_base = cfg->slot_base;
+    const size_t trees = (size_t)v.B * v.T;
+    const int A = gi.action_size, NV = gi.num_players + 1, O = gi.obs_c * gi.obs_h * gi.obs_w;
+    DALLOC(v.nodes, trees * (size_t)v.cap);
+    DALLOC(v.hdr, trees);
+    DALLOC(v.path, trees * (size_t)v.maxd);
+    DALLOC(v.states, v.B); DALLOC(v.leaf_states, v.B);
+    DALLOC(v.tape_ctr, v.B); DALLOC(v.next_reset, v.B); DALLOC(v.hist_len, v.B);
+    const bool hist = !v.arena && v.ex_cap > 0;
+    DALLOC(v.hist_state, hist ? (size_t)v.B * v.max_hist : 1);
+    DALLOC(v.hist_pi, hist ? (size_t)v.B * v.max_hist * A : 1);
+    if (!hist) v.max_hist = 0;
+    DALLOC(v.last_action, v.B); DALLOC(v.fin_flag, v.B); DALLOC(v.fin_ridx, v.B); DALLOC(v.fin_counted, v.B); DALLOC(v.fin_soff, v.B);
+    DALLOC(v.slot_sims, v.B); DALLOC(v.slot_exp, v.B);
+    DALLOC(v.gcount, 8);
+    DALLOC(v.ex_obs, (size_t)v.ex_cap * O); DALLOC(v.ex_pi, (size_t)v.ex_cap * A); DALLOC(v.ex_z, (size_t)v.ex_cap * NV);
+    DALLOC(v.res_ws, (size_t)v.res_cap * NV); DALLOC(v.res_turns, v.res_cap); DALLOC(v.res_slot, v.res_cap);
+    // temperature table (args.temp_scaling_fn iterated on the host)
+    std::vector<float> tt;
+    if (cfg->temp_table && cfg->temp_table_len > 0) tt.assign(cfg->temp_table, cfg->temp_table + cfg->temp_table_len);
+    else tt.assign(1, cfg->start_temp);
+    float *d_tt; DALLOC(d_tt, tt.size());
+    HIPCHK(hipMemcpy(d_tt, tt.data(), tt.size() * sizeof(float), hipMemcpyHostToDevice));
+    v.temp_table = d_tt; v.temp_len = (int)tt.size();
+    SumPlan plan; memset(&plan, 0, sizeof(plan)); plan.n = A;
+    if (A >= 8) plan_rec(0, A, plan);
+    SumPlan *d_plan; DALLOC(d_plan, 1);
+    HIPCHK(hipMemcpy(d_plan, &plan, sizeof(plan), hipMemcpyHostToDevice));
+    v.plan = d_plan;
+    DALLOC(e->d_p2i, 8); DALLOC(e->d_ok, 4);
+    *out = e;
+    int r = azg_engine_reset(e, nullptr);
+    if (r != AZG_OK) { azg_engine_destroy(e); *out = nullptr; return r; }
+    HIPCHK(hipDeviceSynchronize());
+    return AZG_OK;
+}
+
+extern "C" int azg_engine_destroy(azg_engine *e) {
+    if (!e) return AZG_OK;
+    hipDeviceSynchronize();
+    prof_drain(e);
+    for (auto &p : e->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (void *p : e->allocs) hipFree(p);
+    delete e;
+    return AZG_OK;
+}
+
+extern "C" int azg_engine_reset(azg_engine *e, void *stream) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    hipStream_t s = (hipStream_t)stream;
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_reset<G>), dim3(e->v.B), dim3(64), 0, s, e->v, 0, e->v.B, 1));
+    HIPCHK(hipMemsetAsync(e->v.tape_ctr, 0, sizeof(uint64_t) * e->v.B, s));
+    HIPCHK(hipMemsetAsync(e->v.gcount, 0, sizeof(int32_t) * 8, s));
+    HIPCHK(hipMemsetAsync(e->v.slot_sims, 0, sizeof(int64_t) * e->v.B, s));
+    HIPCHK(hipMemsetAsync(e->v.slot_exp, 0, sizeof(int64_t) * e->v.B, s));
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+static int check_range(azg_engine *e, int first, int count) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    if (first < 0 || count < 0 || first + count > e->v.B) return fail(AZG_E_INVALID_ARG, "slot range out of bounds");
+    return AZG_OK;
+}
+
+extern "C" int azg_set_states(azg_engine *e, void *stream, int first, int count, const azg_state *host, int reset_trees) {
+    int r = check_range(e, first, count); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(e->v.states + first, host, sizeof(azg_state) * count, hipMemcpyHostToDevice, s));
+    if (reset_trees) { GAME_SWITCH(e, hipLaunchKernelGGL((k_reset<G>), dim3(count), dim3(64), 0, s, e->v, first, count, 0)); }
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+extern "C" int azg_get_states(azg_engine *e, void *stream, int first, int count, azg_state *host) {
+    int r = check_range(e, first, count); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(host, e->v.states + first, sizeof(azg_state) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+extern "C" int azg_get_leaf_states(azg_engine *e, void *stream, int first, int count, azg_state *host) {
+    int r = check_range(e, first, count); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(host, e->v.leaf_states + first, sizeof(azg_state) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+extern "C" int azg_set_tape_counters(azg_engine *e, void *stream, int first, int count, const uint64_t *host) {
+    int r = check_range(e, first, count); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(e->v.tape_ctr + first, host, sizeof(uint64_t) * count, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+extern "C" int azg_get_tape_counters(azg_engine *e, void *stream, int first, int count, uint64_t *host) {
+    int r = check_range(e, first, count); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(host, e->v.tape_ctr + first, sizeof(uint64_t) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+
+extern "C" int azg_select(azg_engine *e, void *stream, void *obs, int obs_dtype, const int32_t *row_of_slot) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    if (obs_dtype != 0 && obs_dtype != 1) return fail(AZG_E_INVALID_ARG, "obs_dtype must be 0 (f32) or 1 (f16)");
+    hipStream_t s = (hipStream_t)stream;
+    EvPair p; prof_begin(e, s, 0, p);
+    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, float>), dim3(e->v.B), dim3(64), 0, s, e->v, (float *)obs, row_of_slot)); }
+    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, _Float16>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
+    prof_end(e, s, 0, p);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_arena_rows(azg_engine *e, void *stream, const int32_t *p2i_host, int32_t *row_of_slot, int32_t *rows_per_model) {
+    if (!e || !p2i_host || !row_of_slot || !rows_per_model) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(e->d_p2i, p2i_host, sizeof(int32_t) * e->gi.num_players, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_arena_rows, dim3(1), dim3(64), 0, s, e->v, e->d_p2i, row_of_slot, rows_per_model);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_backup(azg_engine *e, void *stream, const float *policy, const float *value, const int32_t *row_of_slot) {
+    if (!e || !policy || !value) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    EvPair p; prof_begin(e, s, 1, p);
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_backup<G>), dim3(e->v.B), dim3(64), 0, s, e->v, policy, value, row_of_slot));
+    prof_end(e, s, 1, p);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    hipStream_t s = (hipStream_t)stream;
+    EvPair p; prof_begin(e, s, 2, p);
+    GAME_SWITCH(e, {
+        hipLaunchKernelGGL((k_play<G>), dim3(e->v.B), dim3(64), 0, s, e->v, record_history);
+        hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v);
+        hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
+    });
+    prof_end(e, s, 2, p);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_root_counts(azg_engine *e, void *stream, int32_t *counts) {
+    if (!e || !counts) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_root_stats<G>), dim3(e->v.B), dim3(64), 0, s, e->v, 0, 1.0f, 0, counts, (float *)nullptr, (float *)nullptr));
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+extern "C" int azg_root_probs(azg_engine *e, void *stream, float temp, float *probs) {
+    if (!e || !probs) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_root_stats<G>), dim3(e->v.B), dim3(64), 0, s, e->v, 1, temp, 0, (int32_t *)nullptr, probs, (float *)nullptr));
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+extern "C" int azg_root_value(azg_engine *e, void *stream, int average, float *values) {
+    if (!e || !values) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_root_stats<G>), dim3(e->v.B), dim3(64), 0, s, e->v, 2, 1.0f, average, (int32_t *)nullptr, (float *)nullptr, values));
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_update_root(azg_engine *e, void *stream, int slot, int action) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_update_root<G>), dim3(1), dim3(64), 0, s, e->v, slot, action, e->d_ok));
+    int32_t ok = 0;
+    HIPCHK(hipMemcpyAsync(&ok, e->d_ok, sizeof(ok), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (!ok) return fail(AZG_E_INVALID_ACTION, "Invalid action encountered while updating root: " + std::to_string(action));
+    return AZG_OK;
+}
+
+static int tree_of(azg_engine *e, int slot, int tree) { return slot * e->v.T + tree; }
+
+extern "C" int azg_root_children(azg_engine *e, void *stream, int slot, int tree, int max_k, int32_t *a, int32_t *n, float *q, float *p, float *vv) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));
+    const int t = tree_of(e, slot, tree);
+    TreeHdr h; Node root;
+    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
+    Node *base = e->v.nodes + (size_t)t * e->v.cap;
+    HIPCHK(hipMemcpy(&root, base + h.root, sizeof(Node), hipMemcpyDeviceToHost));
+    int k = root.nchild;
+    if (k > max_k) return fail(AZG_E_INVALID_ARG, "max_k too small");
+    if (k == 0) return 0;
+    std::vector<Node> ch((size_t)k);
+    HIPCHK(hipMemcpy(ch.data(), base + root.first_child, sizeof(Node) * k, hipMemcpyDeviceToHost));
+    for (int i = 0; i < k; i++) { a[i] = ch[i].a; n[i] = ch[i].n; q[i] = ch[i].q; p[i] = ch[i].p; vv[i] = ch[i].v; }
+    return k;
+}
+
+extern "C" int azg_tree_info(azg_engine *e, void *stream, int slot, int tree, int32_t *out8) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    const int t = tree_of(e, slot, tree);
+    TreeHdr h; Node root;
+    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&root, e->v.nodes + (size_t)t * e->v.cap + h.root, sizeof(Node), hipMemcpyDeviceToHost));
+    out8[0] = root.n; memcpy(&out8[1], &root.q, 4); memcpy(&out8[2], &root.v, 4);
+    out8[3] = root.player; out8[4] = root.e; out8[5] = h.depth; out8[6] = h.max_depth; out8[7] = h.alloc;
+    return AZG_OK;
+}
+
+extern "C" int azg_last_path(azg_engine *e, void *stream, int slot, int tree, int max_len, int32_t *actions) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    const int t = tree_of(e, slot, tree);
+    TreeHdr h;
+    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.depth > max_len) return fail(AZG_E_INVALID_ARG, "max_len too small");
+    std::vector<uint32_t> path((size_t)(h.depth > 0 ? h.depth : 1));
+    if (h.depth > 0) HIPCHK(hipMemcpy(path.data(), e->v.path + (size_t)t * e->v.maxd, sizeof(uint32_t) * h.depth, hipMemcpyDeviceToHost));
+    for (int d = 0; d < h.depth; d++) {
+        Node nd;
+        HIPCHK(hipMemcpy(&nd, e->v.nodes + (size_t)t * e->v.cap + (path[d] & 0x0FFFFFFFu), sizeof(Node), hipMemcpyDeviceToHost));
+        actions[d] = nd.a;
+    }
+    return h.depth;
+}
+
+extern "C" int azg_read_counters(azg_engine *e, void *stream, azg_counters *out) {
+    if (!e || !out) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t gc[8];
+    std::vector<int64_t> sims((size_t)e->v.B), exps((size_t)e->v.B);
+    HIPCHK(hipMemcpyAsync(gc, e->v.gcount, sizeof(gc), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(sims.data(), e->v.slot_sims, sizeof(int64_t) * e->v.B, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(exps.data(), e->v.slot_exp, sizeof(int64_t) * e->v.B, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memset(out, 0, sizeof(*out));
+    for (int i = 0; i < e->v.B; i++) { out->sims += sims[i]; out->expansions += exps[i]; }
+    out->games_played = gc[GC_GAMES]; out->num_results = gc[GC_RESULTS]; out->num_examples = gc[GC_EXAMPLES];
+    out->error = gc[GC_ERROR]; out->max_nodes_used = gc[GC_MAXNODES];
+    return AZG_OK;
+}
+
+extern "C" int azg_examples_dev(azg_engine *e, float **obs, float **pi, float **z) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    if (obs) *obs = e->v.ex_obs; if (pi) *pi = e->v.ex_pi; if (z) *z = e->v.ex_z;
+    return AZG_OK;
+}
+
+extern "C" int azg_copy_examples(azg_engine *e, void *stream, int first, int count, float *obs, float *pi, float *z) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    if (first < 0 || count < 0 || first + count > e->v.ex_cap) return fail(AZG_E_INVALID_ARG, "example range out of bounds");
+    if (count == 0) return AZG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t A = e->gi.action_size, NV = e->gi.num_players + 1, O = (size_t)e->gi.obs_c * e->gi.obs_h * e->gi.obs_w;
+    if (obs) HIPCHK(hipMemcpyAsync(obs, e->v.ex_obs + (size_t)first * O, sizeof(float) * count * O, hipMemcpyDeviceToDevice, s));
+    if (pi) HIPCHK(hipMemcpyAsync(pi, e->v.ex_pi + (size_t)first * A, sizeof(float) * count * A, hipMemcpyDeviceToDevice, s));
+    if (z) HIPCHK(hipMemcpyAsync(z, e->v.ex_z + (size_t)first * NV, sizeof(float) * count * NV, hipMemcpyDeviceToDevice, s));
+    return AZG_OK;
+}
+
+extern "C" int azg_read_results(azg_engine *e, void *stream, int first, int count, uint8_t *ws, int32_t *turns, int32_t *slot) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    if (first < 0 || count < 0 || first + count > e->v.res_cap) return fail(AZG_E_INVALID_ARG, "result range out of bounds");
+    hipStream_t s = (hipStream_t)stream;
+    const int NV = e->gi.num_players + 1;
+    if (count == 0) return AZG_OK;
+    HIPCHK(hipMemcpyAsync(ws, e->v.res_ws + (size_t)first * NV, (size_t)count * NV, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(turns, e->v.res_turns + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(slot, e->v.res_slot + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+
+extern "C" int azg_clear_outputs(azg_engine *e, void *stream) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    HIPCHK(hipMemsetAsync(e->v.gcount, 0, sizeof(int32_t) * 3, (hipStream_t)stream));
+    return AZG_OK;
+}
+
+extern "C" int azg_last_actions_dev(azg_engine *e, int32_t **actions) {
+    if (!e || !actions) return fail(AZG_E_INVALID_ARG, "null argument");
+    *actions = e->v.last_action;
+    return AZG_OK;
+}
+
+extern "C" int azg_profile_enable(azg_engine *e, int on) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    prof_drain(e);
+    e->profile = on != 0;
+    if (on) { for (int f = 0; f < 3; f++) { e->ms[f] = 0; e->launches[f] = 0; } }
+    return AZG_OK;
+}
+extern "C" int azg_profile_read(azg_engine *e, double *ms3, int64_t *launches3) {
+    if (!e || !ms3 || !launches3) return fail(AZG_E_INVALID_ARG, "null argument");
+    prof_drain(e);
+    for (int f = 0; f < 3; f++) { ms3[f] = e->ms[f]; launches3[f] = e->launches[f]; }
+    return AZG_OK;
+}

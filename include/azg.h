@@ -1,0 +1,180 @@
+/*
+ * azg.h -- C ABI of libazg_hip.so, the MI355X-native batched self-play / MCTS engine.
+ *
+ * The reference (kevaday/alphazero-general) has no FFI: its hot path is two Cython extension classes,
+ * alphazero/MCTS.pyx and alphazero/SelfPlayAgent.pyx.  This header is what a binding for that path would bind;
+ * each entry point names the reference interface it replaces (file:line relative to the reference root).
+ * The Python classes in alphazero_general_amd/{MCTS,SelfPlayAgent}.py are thin ctypes callers of exactly these
+ * functions (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-owned.  "dev" pointers are device (HBM) pointers of the calling
+ *     process' HIP context, "host" pointers are ordinary host memory.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  All work is stream-ordered; nothing
+ *     synchronises unless the function name says `_sync`/`_read` or the doc says "blocking".
+ *   - one engine per GPU per process; an engine is not thread-safe.
+ *   - return 0 on success, a negative azg_status otherwise; azg_last_error() gives the message
+ *     (the Python layer maps AZG_E_INVALID_ACTION to ValueError like MCTS.pyx:195, the rest to RuntimeError).
+ *   - there is NO CPU fallback: every compute entry point launches HIP kernels and fails with AZG_E_HIP when no
+ *     device is available.
+ */
+#ifndef AZG_H
+#define AZG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZG_ABI_VERSION 1
+
+typedef enum azg_status {
+    AZG_OK = 0,
+    AZG_E_INVALID_ARG = -1,
+    AZG_E_HIP = -2,             /* HIP runtime error / no device                                   */
+    AZG_E_INVALID_ACTION = -3,  /* update_root on an action that is not a child (MCTS.pyx:195)      */
+    AZG_E_TREE_FULL = -4,       /* a tree's node arena overflowed (raise nodes_per_tree)            */
+    AZG_E_EXAMPLES_FULL = -5,   /* the training-example buffer overflowed (raise example_capacity)  */
+    AZG_E_UNSUPPORTED = -6
+} azg_status;
+
+/* games with device-side rules (Game plugin API, alphazero/Game.py:7-113) */
+typedef enum azg_game {
+    AZG_GAME_CONNECT4 = 0,      /* alphazero/envs/connect4/connect4.pyx + Connect4Logic.pyx          */
+    AZG_GAME_BRANDUBH = 1,      /* alphazero/envs/brandubh/fastafl.pyx + fastafl/cengine.pyx         */
+    AZG_GAME_TRIMOK = 2         /* build-defined 3-player env (N-player path, BASELINE config 5)     */
+} azg_game;
+
+/* Game state as it crosses the ABI (all games): the reference's board array, row-major, one int8 per cell
+ * (connect4: 1/-1/0 as Connect4Logic.pyx:34; brandubh: piece codes of fastafl/cengine.pyx:24-32),
+ * GameState._player / _turns (Game.py:10-11) and two game-specific words. */
+typedef struct azg_state {
+    int8_t  cells[64];
+    int32_t player;
+    int32_t turns;
+    int32_t aux[2];
+} azg_state;                    /* 80 bytes */
+
+typedef struct azg_game_info {
+    int32_t action_size;        /* GameState.action_size()       Game.py:26-30   */
+    int32_t obs_c, obs_h, obs_w;/* GameState.observation_size()  Game.py:32-42   */
+    int32_t num_players;        /* GameState.num_players()       Game.py:49-53   */
+    int32_t has_draw;           /* GameState.has_draw()          Game.py:60-63   */
+    int32_t max_turns;          /* GameState.max_turns()         Game.py:55-58   */
+    int32_t num_symmetries;     /* len(GameState.symmetries())   Game.py:99-113  */
+    int32_t cells;              /* board cells used in azg_state.cells            */
+    int32_t max_children;       /* upper bound on legal moves in one position     */
+} azg_game_info;
+
+/* Engine configuration.  Search keys are the ones MCTS.__init__ reads (MCTS.pyx:133-139); agent keys the ones
+ * SelfPlayAgent reads (SelfPlayAgent.pyx:58,82-86,149-150,156-158,172,181,187). */
+typedef struct azg_config {
+    int32_t  abi_version;       /* AZG_ABI_VERSION */
+    int32_t  game;              /* azg_game */
+    int32_t  device;            /* HIP device ordinal */
+    int32_t  num_slots;         /* B: concurrent games (batch_tensor.shape[0], SelfPlayAgent.pyx:23-26) */
+    int32_t  arena;             /* 1: one tree per player per game (SelfPlayAgent.pyx:60-73)      */
+    int32_t  nodes_per_tree;    /* node-arena capacity per tree; 0 = default for the game         */
+    int32_t  example_capacity;  /* max (obs, pi, z) samples held; 0 = no sample recording         */
+    int32_t  result_capacity;   /* max finished-game records held                                  */
+    float    cpuct, fpu_reduction, root_noise_frac, root_policy_temp, min_discount;   /* MCTS.pyx:134-138 */
+    int32_t  add_root_noise, add_root_temp;        /* SelfPlayAgent.pyx:149-150 (forced off in arena) */
+    int32_t  symmetric_samples;                    /* args.symmetricSamples  :187                      */
+    int32_t  mcts_reset_threshold;                 /* args.mctsResetThreshold :172-174, 0 = None       */
+    int32_t  games_per_iteration;                  /* args.gamesPerIteration :179-183                  */
+    float    start_temp, arena_temp;               /* args.startTemp :58, args.arenaTemp :158          */
+    int32_t  temp_table_len;                       /* temp used for the move at turn t, i.e.           */
+    const float *temp_table;                       /*   args.temp_scaling_fn iterated (:156-157); host */
+    uint64_t tape_seed;                            /* random tape                          */
+    uint64_t slot_base;                            /* global id of slot 0 (multi-GPU sharding)         */
+} azg_config;
+
+typedef struct azg_engine azg_engine;
+
+typedef struct azg_counters {
+    int64_t  sims;              /* find_leaf + process_results pairs                              */
+    int64_t  expansions;        /* find_leaf calls that took the n == 0 branch (MCTS.pyx:223-226)  */
+    int32_t  games_played;      /* SelfPlayAgent.games_played (capped at games_per_iteration)     */
+    int32_t  num_results;       /* result_queue length (every finished game)           */
+    int32_t  num_examples;      /* output_queue length                                             */
+    int32_t  error;             /* sticky azg_status raised on device (tree/example overflow ...)  */
+    int32_t  max_nodes_used;    /* high-water mark of any tree arena                               */
+    int32_t  reserved;
+} azg_counters;
+
+/* ---- library ------------------------------------------------------------------------------------------- */
+int          azg_abi_version(void);
+const char  *azg_last_error(void);
+int          azg_game_info_get(int game, azg_game_info *out);              /* Game.py static methods       */
+int          azg_device_count(void);
+
+/* ---- engine life cycle (SelfPlayAgent.__init__ :14-58 / MCTS.__init__ :133-145) -------------------------- */
+int  azg_engine_create(const azg_config *cfg, azg_engine **out);
+int  azg_engine_destroy(azg_engine *e);
+/* reset every slot to the initial position with fresh trees (SelfPlayAgent.pyx:54-59; MCTS.reset :154-160) */
+int  azg_engine_reset(azg_engine *e, void *stream);
+/* overwrite the game state of `count` slots starting at `first` (host array) and give them fresh trees */
+int  azg_set_states(azg_engine *e, void *stream, int first, int count, const azg_state *host_states, int reset_trees);
+int  azg_get_states(azg_engine *e, void *stream, int first, int count, azg_state *host_states);      /* blocking */
+int  azg_get_leaf_states(azg_engine *e, void *stream, int first, int count, azg_state *host_states); /* blocking */
+int  azg_set_tape_counters(azg_engine *e, void *stream, int first, int count, const uint64_t *host_ctr);
+int  azg_get_tape_counters(azg_engine *e, void *stream, int first, int count, uint64_t *host_ctr);   /* blocking */
+
+/* ---- one simulation step ---------------------------------------------------------------------------------- */
+/* SelfPlayAgent.generateBatch (:103-135) = MCTS.find_leaf (:208-228) on every slot + leaf observation
+ * (GameState.observation) written as row `row_of_slot[slot]` (NULL: row = slot) of the dense NN input
+ * obs_dev[rows, C, H, W]; obs_dtype 0 = float32, 1 = float16. */
+int  azg_select(azg_engine *e, void *stream, void *obs_dev, int obs_dtype, const int32_t *row_of_slot_dev);
+/* arena helper (:117-132): rows grouped by model index = player_to_index[mover]; writes row_of_slot_dev[B] and
+ * rows_per_model_dev[P] (device), to be called before azg_select */
+int  azg_arena_rows(azg_engine *e, void *stream, const int32_t *player_to_index_host, int32_t *row_of_slot_dev,
+                    int32_t *rows_per_model_dev);
+/* SelfPlayAgent.processBatch (:137-151) = MCTS.process_results (:230-289) on every slot with row
+ * row_of_slot[slot] of policy_dev[rows, A] / value_dev[rows, P+1] (float32 probabilities). */
+int  azg_backup(azg_engine *e, void *stream, const float *policy_dev, const float *value_dev,
+                const int32_t *row_of_slot_dev);
+/* SelfPlayAgent.playMoves (:153-202): temperature, sample the move from MCTS.probs, record history,
+ * MCTS.update_root + GameState.play_action, end-of-game bookkeeping (results, samples x symmetries, reset).
+ * record_history = not fast (:161). */
+int  azg_advance(azg_engine *e, void *stream, int record_history);
+
+/* ---- single-tree API (MCTS.pyx public methods; slot-wise) ------------------------------------------------ */
+int  azg_root_counts(azg_engine *e, void *stream, int32_t *counts_dev /*[B, A]*/);                 /* MCTS.counts :297-303 */
+int  azg_root_probs(azg_engine *e, void *stream, float temp, float *probs_dev /*[B, A]*/);        /* MCTS.probs  :308-329 */
+int  azg_root_value(azg_engine *e, void *stream, int average, float *value_dev /*[B]*/);          /* MCTS.value  :331-344 */
+/* MCTS.update_root(gs, a) (:185-195) on one slot's tree(s); the game state itself is NOT advanced. blocking. */
+int  azg_update_root(azg_engine *e, void *stream, int slot, int action);
+/* children of a slot's root in list order (Node._children): a, n, q, p, v.  blocking; returns k or <0. */
+int  azg_root_children(azg_engine *e, void *stream, int slot, int tree, int max_k, int32_t *a, int32_t *n, float *q, float *p, float *v);
+/* root header / search statistics of a slot's tree: n, q, v, player, e, depth, max_depth. blocking. */
+int  azg_tree_info(azg_engine *e, void *stream, int slot, int tree, int32_t *out8);
+/* path of the last find_leaf as actions (length = depth). blocking; returns depth or <0. */
+int  azg_last_path(azg_engine *e, void *stream, int slot, int tree, int max_len, int32_t *actions);
+
+/* ---- outputs ------------------------------------------------------------------------------------------------ */
+int  azg_read_counters(azg_engine *e, void *stream, azg_counters *host_out);                      /* blocking */
+/* device views of the accumulated examples, in the reference's output_queue order (Coach.py:364-386 layout):
+ * obs f32 [n, C, H, W], pi f32 [n, A], z f32 [n, P+1] */
+int  azg_examples_dev(azg_engine *e, float **obs_dev, float **pi_dev, float **z_dev);
+/* stream-ordered device-to-device copy of examples [first, first+count) into caller-owned device buffers */
+int  azg_copy_examples(azg_engine *e, void *stream, int first, int count, float *obs_dst, float *pi_dst, float *z_dst);
+/* finished games in result_queue order: winstate u8 [n, P+1], turns i32 [n], slot i32 [n]  (host, blocking) */
+int  azg_read_results(azg_engine *e, void *stream, int first, int count, uint8_t *winstate, int32_t *turns, int32_t *slot);
+int  azg_clear_outputs(azg_engine *e, void *stream);      /* new iteration: games_played = 0, queues emptied */
+/* per-slot action chosen by the last azg_advance (device [B]) */
+int  azg_last_actions_dev(azg_engine *e, int32_t **actions_dev);
+
+/* ---- timing hooks for bench.py (HIP events on `stream` around the engine's own kernels) -------------------- */
+int  azg_profile_enable(azg_engine *e, int on);
+/* accumulated GPU ms + launch counts per kernel family: select, backup, advance. blocking. */
+int  azg_profile_read(azg_engine *e, double *ms3, int64_t *launches3);
+
+/* ---- random tape (exposed so that host code can draw the agent-level numbers) ------------------------------- */
+uint64_t azg_tape_u64(uint64_t seed, uint64_t stream, uint64_t ctr);
+double   azg_tape_uniform(uint64_t seed, uint64_t stream, uint64_t ctr);
+void     azg_tape_shuffle_pos(uint64_t seed, uint64_t stream, uint64_t ctr, int k, int32_t *pos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZG_H */

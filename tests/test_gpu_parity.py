@@ -1,0 +1,273 @@
+"""GPU parity tests (pytest -m gpu): the HIP engine, called through the C ABI, against
+  (1) the committed golden vectors produced by the actual reference (tests/golden/*.npz), and
+  (2) the CPU oracle run live on the same seeded inputs at sizes the oracle finishes in seconds,
+plus size-independent properties at BASELINE.json's full size (2048 games x 100 sims).
+Bars: visit counts, actions, paths, pi(T=1), samples bit-exact; q/v bit-exact in the exact tier (no root
+temperature), atol 1e-5 otherwise; pi(T not in {1, .5, 0}) within rtol 3e-7 (powf tier)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+C4 = 0
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@pytest.fixture(scope='module')
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return torch
+
+
+def engine(**kw):
+    from alphazero_general_amd.engine import DeviceEngine
+    game = kw.pop('game', C4)
+    B = kw.pop('B')
+    return DeviceEngine(game, B, **kw)
+
+
+def ostate(g):
+    return (g.cells(), g.player, g.turns)
+
+
+def fake_batch(torch, seed, slots, step, A, NV, dev):
+    pol = np.zeros((len(slots), A), np.float32); val = np.zeros((len(slots), NV), np.float32)
+    for r, s in enumerate(slots):
+        pol[r], val[r] = ol.fake_eval(seed, int(s), step, A, NV)
+    return torch.from_numpy(pol).to(dev), torch.from_numpy(val).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------- tree goldens
+@pytest.mark.parametrize('cname', ['default', 'c4train', 'noise', 'noise_temp'])
+def test_c4_tree_vs_reference_goldens(torch_mod, cname):
+    torch = torch_mod
+    d = np.load(os.path.join(G, 'c4_tree.npz'))
+    cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
+    noise, temp, sims = bool(noise), bool(temp), int(sims)
+    seed = int(d[cname + '_seed'])
+    R = d['prefix'].shape[0]
+    A, NV = 7, 3
+    exact = not temp
+    eng = engine(B=R, cpuct=cpuct, fpu_reduction=fpu, add_root_noise=noise, add_root_temp=temp, seed=seed, sims_hint=sims)
+    states = []
+    for r in range(R):
+        g = ol.OGame(C4)
+        for a in d['prefix'][r]:
+            if a >= 0:
+                g.play(a)
+        states.append(ostate(g))
+    eng.set_states(states)
+    obs = eng.new_obs()
+    for s in range(sims):
+        eng.select(obs)
+        for r in range(0, R, 7):                      # spot-check leaf paths every sim on a subset of roots
+            path = eng.last_path(r)
+            assert len(path) == d[cname + '_depth'][r, s]
+            assert (path[:24] == d[cname + '_paths'][r, s][:len(path)]).all(), (r, s)
+        pol, val = fake_batch(torch, seed, range(R), s, A, NV, eng.device)
+        eng.backup(pol, val)
+        cnt = eng.root_counts().cpu().numpy()
+        assert (cnt == d[cname + '_rootn'][:, s]).all(), s
+    for r in range(R):
+        ch = eng.root_children(r)
+        k = len(ch['a'])
+        assert (ch['a'] == d[cname + '_a'][r][:k]).all() and (d[cname + '_a'][r][k:] == -1).all()
+        assert (ch['n'] == d[cname + '_n'][r][:k]).all()
+        for f in ('q', 'p', 'v'):
+            if exact:
+                assert (ch[f] == d[cname + '_' + f][r][:k]).all(), (f, r)
+            else:
+                assert np.allclose(ch[f], d[cname + '_' + f][r][:k], atol=1e-5), (f, r)
+        info = eng.tree_info(r)
+        assert info['n'] == d[cname + '_root_n'][r] and info['max_depth'] == d[cname + '_maxdepth'][r]
+    assert (eng.root_counts().cpu().numpy() == d[cname + '_counts']).all()
+    for ti, t in enumerate(d['prob_temps']):
+        pr = eng.root_probs(float(t)).cpu().numpy()
+        ref = d[cname + '_probs'][:, ti]
+        if t in (1.0, 0.5, 0.0):
+            assert (pr == ref).all(), t
+        else:
+            assert np.allclose(pr, ref, rtol=3e-7, atol=1e-12), t
+    assert (eng.root_value(False).cpu().numpy() == d[cname + '_vmax']).all()
+    assert (eng.root_value(True).cpu().numpy() == d[cname + '_vavg']).all()
+    assert (eng.tape_counters() == d[cname + '_ctr']).all()
+    eng.counters()
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ agent goldens
+AGENT_CFGS = {
+    'plain': dict(),
+    'noisy': dict(add_root_noise=True, add_root_temp=True, cpuct=4.0, fpu_reduction=0.4),
+    'fastmix': dict(symmetric_samples=False),
+    'reset': dict(mcts_reset_threshold=3),
+    'warmup': dict(),
+}
+AGENT_ROUND = {'fastmix': dict(prob_fast=0.5, fast_sims=6), 'warmup': dict(warmup=True, warmup_sims=5)}
+
+
+def run_engine_agent(torch, eng, seed, slot_base, sims, games, prob_fast=0.0, fast_sims=20, warmup=False, warmup_sims=5,
+                     max_rounds=500):
+    from alphazero_general_amd.utils import AGENT_STREAM
+    from alphazero_general_amd import _abi
+    L = _abi.lib()
+    B, A, NV = eng.B, eng.A, eng.NV
+    rec = dict(actions=[], counts=[], obs_crc=[], games_played=[], sims=[])
+    obs = eng.new_obs()
+    step, actr = 0, 0
+    wp = torch.full((B, A), 1 / A, dtype=torch.float32, device=eng.device)
+    wv = torch.full((B, NV), 1 / NV, dtype=torch.float32, device=eng.device)
+    gp = 0
+    for _ in range(max_rounds):
+        if gp >= games:
+            break
+        fast = L.azg_tape_uniform(seed, AGENT_STREAM + slot_base, actr) < prob_fast
+        actr += 1
+        ns = fast_sims if fast else (warmup_sims if warmup else sims)
+        rec['sims'].append(ns)
+        for s in range(ns):
+            eng.select(None if warmup else obs)
+            if warmup:
+                eng.backup(wp, wv)
+            else:
+                o = obs.cpu().numpy()
+                rec['obs_crc'].append([crc(o[i]) for i in range(B)])
+                pol, val = fake_batch(torch, seed, [slot_base + i for i in range(B)], step, A, NV, eng.device)
+                eng.backup(pol, val)
+            step += 1
+        rec['counts'].append(eng.root_counts().cpu().numpy())
+        eng.advance(record_history=not fast)
+        rec['actions'].append(eng.last_actions().cpu().numpy())
+        gp = eng.counters()['games_played']
+        rec['games_played'].append(gp)
+    return rec
+
+
+@pytest.mark.parametrize('cname', list(AGENT_CFGS))
+def test_c4_agent_vs_reference_goldens(torch_mod, cname):
+    torch = torch_mod
+    d = np.load(os.path.join(G, 'c4_agent.npz'))
+    B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
+    seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
+    eng = engine(B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=4096, sims_hint=sims,
+                 **AGENT_CFGS[cname])
+    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games, **AGENT_ROUND.get(cname, {}))
+    assert (np.array(rec['sims']) == d[cname + '_round_sims']).all()
+    assert (np.array(rec['counts']) == d[cname + '_counts']).all()
+    assert (np.array(rec['actions']) == d[cname + '_actions']).all()
+    assert (np.array(rec['games_played']) == d[cname + '_games_played']).all()
+    if cname != 'warmup':
+        assert (np.array(rec['obs_crc'], np.uint32) == d[cname + '_obs_crc']).all()
+    obs, pi, z = [t.cpu().numpy() for t in eng.examples()]
+    assert obs.shape == d[cname + '_s_obs'].shape
+    assert (obs == d[cname + '_s_obs']).all()
+    assert (pi == d[cname + '_s_pi']).all()
+    assert (z == d[cname + '_s_z']).all()
+    ws, turns, slot = eng.results()
+    assert (ws == d[cname + '_r_ws']).all() and (turns == d[cname + '_r_turns']).all()
+    eng.close()
+
+
+# ----------------------------------------------------------------------------------- live oracle, larger sizes
+@pytest.mark.parametrize('B,sims,games,kw', [
+    (256, 40, 300, dict(cpuct=4.0, fpu_reduction=0.4)),
+    (96, 30, 120, dict(add_root_noise=True, cpuct=1.25)),
+])
+def test_c4_selfplay_vs_oracle_live(torch_mod, B, sims, games, kw):
+    torch = torch_mod
+    seed = 4242
+    okw = dict(kw)
+    ag = ol.OAgent(C4, B, sims=sims, games_per_iteration=games, seed=seed, **okw)
+    eng = engine(B=B, seed=seed, games_per_iteration=games, example_capacity=200000, sims_hint=sims, **kw)
+    obs = eng.new_obs()
+    A, NV = 7, 3
+    step = 0
+    while ag.games_played < games:
+        ag.begin_round()
+        for s in range(sims):
+            oobs, rg, rm = ag.generate_batch()
+            eng.select(obs)
+            if step % 7 == 0:
+                assert (obs.cpu().numpy() == oobs).all(), step
+            pol = np.zeros((B, A), np.float32); val = np.zeros((B, NV), np.float32)
+            for i in range(B):
+                pol[i], val[i] = ol.fake_eval(seed, i, step, A, NV)
+            ag.process_batch(pol, val)
+            eng.backup(torch.from_numpy(pol).to(eng.device), torch.from_numpy(val).to(eng.device))
+            step += 1
+        ag.play_moves()
+        eng.advance(True)
+        assert (eng.last_actions().cpu().numpy() == ag.last_actions()).all()
+    c = eng.counters()
+    assert c['games_played'] == ag.games_played
+    assert c['sims'] == ag.sims_done and c['expansions'] == ag.expansions
+    oo, op, oz = ag.samples()
+    eo, ep, ez = [t.cpu().numpy() for t in eng.examples()]
+    assert eo.shape == oo.shape and (eo == oo).all() and (ep == op).all() and (ez == oz).all()
+    ws, turns, slot = eng.results()
+    ows, oturns, oslot = ag.results()
+    assert (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all()
+    eng.close()
+
+
+# ------------------------------------------------------------------- full-size properties (2048 games x 100 sims)
+def test_c4_full_size_properties(torch_mod):
+    torch = torch_mod
+    B, sims = 2048, 100
+    seed = 7
+    eng = engine(B=B, seed=seed, cpuct=4.0, fpu_reduction=0.4, games_per_iteration=1 << 30, example_capacity=400000, sims_hint=sims)
+    eng2 = engine(B=B // 2, seed=seed, slot_base=B // 2, cpuct=4.0, fpu_reduction=0.4, games_per_iteration=1 << 30,
+                  example_capacity=200000, sims_hint=sims)
+    g = torch.Generator(device='cpu'); g.manual_seed(0)
+    obs, obs2 = eng.new_obs(torch.float16), eng2.new_obs(torch.float16)
+    for move in range(3):
+        for s in range(sims):
+            pol = torch.rand((B, 7), generator=g) + 1e-3
+            pol = (pol / pol.sum(1, keepdim=True)).to(eng.device)
+            val = torch.rand((B, 3), generator=g) + 1e-3
+            val = (val / val.sum(1, keepdim=True)).to(eng.device)
+            eng.select(obs); eng.backup(pol, val)
+            eng2.select(obs2); eng2.backup(pol[B // 2:].contiguous(), val[B // 2:].contiguous())
+        cnt = eng.root_counts()
+        # every simulation adds exactly one visit below the root: sum(child n) == root.n - 1 for a fresh root (Q8)
+        if move == 0:
+            assert (cnt.sum(1) == sims - 1).all()
+        pr = eng.root_probs(1.0)
+        assert torch.allclose(pr.sum(1), torch.ones(B, device=eng.device), atol=1e-5)
+        assert ((pr > 0) == (cnt > 0)).all()
+        # sharding invariance: slots [B/2, B) of the big engine == an engine created with slot_base = B/2
+        assert (cnt[B // 2:] == eng2.root_counts()).all()
+        eng.advance(True); eng2.advance(True)
+        assert (eng.last_actions()[B // 2:] == eng2.last_actions()).all()
+        # the sampled action is always a visited child
+        act = eng.last_actions().long()
+        assert (cnt.gather(1, act[:, None]) > 0).all()
+    c = eng.counters()
+    assert c['sims'] == 3 * sims * B and c['expansions'] <= c['sims']
+    st = eng.get_states(0, 16)
+    assert all(t == 3 for (_, _, t) in st)
+    eng.close(); eng2.close()
+
+
+def test_errors_surface(torch_mod):
+    eng = engine(B=4, sims_hint=1, nodes_per_tree=16)
+    obs = eng.new_obs()
+    torch = torch_mod
+    pol = torch.full((4, 7), 1 / 7, device=eng.device); val = torch.full((4, 3), 1 / 3, device=eng.device)
+    with pytest.raises(ValueError):
+        eng.update_root(0, 9)                      # not a legal action -> ValueError like MCTS.pyx:195
+    from alphazero_general_amd._abi import AzgError
+    with pytest.raises(AzgError):
+        for _ in range(10):
+            eng.select(obs); eng.backup(pol, val)
+        eng.counters()                             # tree arena overflow is reported, not silently dropped
+    eng.close()
