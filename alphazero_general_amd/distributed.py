@@ -1,0 +1,84 @@
+"""Multi-GPU layer: one process per GPU, game slots sharded by rank, ZERO communication during search.  The only
+exchange step is once per iteration: all-gather the finished (state, pi, z) example shards (variable length per
+rank) and sum the win/draw tallies -- what Coach.saveIterationSamples / processGameResults consume
+(alphazero/Coach.py:364-398).  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+
+Message sizes are tiny (connect4: 712 B per sample), so the exchange is latency-bound: one all_gather of the
+counts (one int per rank) and one padded all_gather per tensor, instead of per-sample traffic.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_games(total_games, rank, world):
+    """Per-rank game quota: ceil(total / world) for every rank (quotas instead of a global atomic)."""
+    return (int(total_games) + world - 1) // world
+
+
+def slot_base(rank, slots_per_rank):
+    """Global id of a rank's slot 0: shards reproduce the trajectories a single engine of world*B slots would play."""
+    return rank * int(slots_per_rank)
+
+
+def all_gather_examples(obs, pi, z, group=None):
+    """Variable-length all-gather of example shards.  Returns (obs, pi, z) holding every rank's samples, rank order,
+    each rank's samples in its own output order."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return obs, pi, z
+    world = dist.get_world_size(group)
+    n = torch.tensor([obs.shape[0]], dtype=torch.int64, device=obs.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(max(counts), 1)
+    out = []
+    for t in (obs, pi, z):
+        pad = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        out.append(torch.cat([b[:c] for b, c in zip(bufs, counts)]))
+    return tuple(out)
+
+
+def all_reduce_tallies(values, group=None):
+    """Sum small integer tallies (wins per player, draws, game-length sum, games, expansions ...) over ranks."""
+    t = torch.as_tensor(values, dtype=torch.int64)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    t = t.to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu()
+
+
+def max_over_ranks(x, group=None):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(x)
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def barrier(group=None):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)

@@ -1,0 +1,212 @@
+"""The NN boundary of the hot path: a policy/value ResNet with the reference's architecture and checkpoint keys
+(alphazero/NNetArchitecture.py:69-120) and an NNetWrapper-shaped object exposing the two calls the search uses
+(alphazero/NNetWrapper.py:207-232): predict(board) -> (p, v) numpy and process(batch) -> (P, V) device tensors of
+probabilities.  The network stays PyTorch-ROCm (MIOpen / hipBLASLt -> MFMA); what is new is the inference path:
+eval-mode BatchNorm folded into the convolutions, channels-last fp16, softmax epilogue in fp32, and optional
+hipGraph capture at a fixed batch size.  Training is out of scope.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .utils import dotdict
+
+DEFAULT_NET_ARGS = dotdict(num_channels=32, depth=4, value_head_channels=16, policy_head_channels=16,
+                           value_dense_layers=[512, 64], policy_dense_layers=[512, 256])        # Coach.py:108-116
+CONNECT4_NET_ARGS = dotdict(num_channels=128, depth=8, value_head_channels=32, policy_head_channels=32,
+                            value_dense_layers=[1024, 256], policy_dense_layers=[1024])           # envs/connect4/train.py:45-50
+BRANDUBH_NET_ARGS = dotdict(num_channels=64, depth=4, value_head_channels=16, policy_head_channels=16,
+                            value_dense_layers=[1024, 128], policy_dense_layers=[1024])           # envs/hnefatafl/train_brandubh.py:50-55
+
+
+def _mlp(sizes):
+    """Linear chain with Identity between layers (the reference passes activation=nn.Identity, :88-93,97-102);
+    module indices 0,2,4.. keep the reference's Sequential numbering so state_dicts interchange."""
+    layers = []
+    for i in range(len(sizes) - 1):
+        layers += [nn.Linear(sizes[i], sizes[i + 1]), nn.Identity()]
+    return nn.Sequential(*layers)
+
+
+class ResidualBlock(nn.Module):
+    """Pre-activation block: bn1-relu-conv1-bn2-relu-conv2 + x (NNetArchitecture.py:36-66, stride 1)."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(ch)
+        self.conv1 = nn.Conv2d(ch, ch, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(ch)
+        self.conv2 = nn.Conv2d(ch, ch, 3, padding=1, bias=False)
+
+    def forward(self, x):
+        out = self.conv1(F.relu(self.bn1(x)))
+        out = self.conv2(F.relu(self.bn2(out)))
+        return out + x
+
+
+class ResNet(nn.Module):
+    def __init__(self, obs_size, action_size, value_size, args):
+        super().__init__()
+        self.channels, self.board_x, self.board_y = obs_size
+        self.action_size = action_size
+        ch = args.num_channels
+        self.conv1 = nn.Conv2d(self.channels, ch, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(ch)
+        self.resnet = nn.Sequential(*[ResidualBlock(ch) for _ in range(args.depth)])
+        self.v_conv = nn.Conv2d(ch, args.value_head_channels, 1, bias=False)
+        self.v_bn = nn.BatchNorm2d(args.value_head_channels)
+        self.v_fc = _mlp([self.board_x * self.board_y * args.value_head_channels] + list(args.value_dense_layers) + [value_size])
+        self.pi_conv = nn.Conv2d(ch, args.policy_head_channels, 1, bias=False)
+        self.pi_bn = nn.BatchNorm2d(args.policy_head_channels)
+        self.pi_fc = _mlp([self.board_x * self.board_y * args.policy_head_channels] + list(args.policy_dense_layers) + [action_size])
+
+    def trunk(self, s):
+        s = s.view(-1, self.channels, self.board_x, self.board_y)
+        return self.resnet(F.relu(self.bn1(self.conv1(s))))
+
+    def forward(self, s):
+        s = self.trunk(s)
+        v = self.v_fc(torch.flatten(self.v_bn(self.v_conv(s)), 1))
+        pi = self.pi_fc(torch.flatten(self.pi_bn(self.pi_conv(s)), 1))
+        return F.log_softmax(pi, dim=1), F.log_softmax(v, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------ inference path
+def _fold(conv_w, bn):
+    """conv followed by eval-mode BN -> (weight, bias)."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return conv_w * scale.view(-1, 1, 1, 1), bn.bias - bn.running_mean * scale
+
+
+class FoldedResNet(nn.Module):
+    """Eval-only restatement of ResNet.forward with every conv->BN pair folded; the pre-activation BN at the head of
+    a block cannot fold (the residual stream also bypasses it) and stays as a fused affine+relu."""
+
+    def __init__(self, net: ResNet):
+        super().__init__()
+        with torch.no_grad():
+            self.shape = (net.channels, net.board_x, net.board_y)
+            w, b = _fold(net.conv1.weight, net.bn1)
+            self.stem_w, self.stem_b = nn.Parameter(w.clone()), nn.Parameter(b.clone())
+            self.pre_scale, self.pre_shift = nn.ParameterList(), nn.ParameterList()
+            self.w1, self.b1, self.w2 = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
+            for blk in net.resnet:
+                sc = blk.bn1.weight / torch.sqrt(blk.bn1.running_var + blk.bn1.eps)
+                self.pre_scale.append(nn.Parameter(sc.view(1, -1, 1, 1).clone()))
+                self.pre_shift.append(nn.Parameter((blk.bn1.bias - blk.bn1.running_mean * sc).view(1, -1, 1, 1).clone()))
+                w, b = _fold(blk.conv1.weight, blk.bn2)
+                self.w1.append(nn.Parameter(w.clone())); self.b1.append(nn.Parameter(b.clone()))
+                self.w2.append(nn.Parameter(blk.conv2.weight.clone()))
+            w, b = _fold(net.v_conv.weight, net.v_bn)
+            wp, bp = _fold(net.pi_conv.weight, net.pi_bn)
+            self.head_w = nn.Parameter(torch.cat([w, wp]).clone()); self.head_b = nn.Parameter(torch.cat([b, bp]).clone())
+            self.vc = w.shape[0]
+            self.v_fc, self.pi_fc = self._chain(net.v_fc), self._chain(net.pi_fc)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @staticmethod
+    def _chain(seq):
+        """A chain of Linear layers with Identity in between is one affine map: collapse it."""
+        W, b = None, None
+        for m in seq:
+            if isinstance(m, nn.Linear):
+                if W is None:
+                    W, b = m.weight.clone(), m.bias.clone()
+                else:
+                    W, b = m.weight @ W, m.weight @ b + m.bias
+        lin = nn.Linear(W.shape[1], W.shape[0])
+        lin.weight.copy_(W); lin.bias.copy_(b)
+        return lin
+
+    def forward(self, s):
+        s = F.relu(F.conv2d(s, self.stem_w, self.stem_b, padding=1))
+        for i in range(len(self.w1)):
+            t = F.relu(s * self.pre_scale[i] + self.pre_shift[i])
+            t = F.relu(F.conv2d(t, self.w1[i], self.b1[i], padding=1))
+            s = F.conv2d(t, self.w2[i], None, padding=1) + s
+        h = F.conv2d(s, self.head_w, self.head_b)
+        v = self.v_fc(torch.flatten(h[:, :self.vc], 1))
+        pi = self.pi_fc(torch.flatten(h[:, self.vc:], 1))
+        return F.softmax(pi.float(), dim=1), F.softmax(v.float(), dim=1)     # == exp(log_softmax) (NNetWrapper.py:231)
+
+
+class NNetWrapper:
+    """The slice of alphazero/NNetWrapper.py the search path calls: predict (:207-223), process (:225-232),
+    __call__ (:35-36), plus state_dict-compatible save/load of the network (:240-274)."""
+
+    def __init__(self, game_cls, args=None, *, device=None, dtype=torch.float16, fast=True):
+        self.game_cls = game_cls
+        self.args = dotdict(DEFAULT_NET_ARGS.copy() if args is None else args)
+        for k, v in DEFAULT_NET_ARGS.items():
+            self.args.setdefault(k, v)
+        obs = tuple(game_cls.observation_size())
+        self.device = torch.device(device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu'))
+        self.nnet = ResNet(obs, game_cls.action_size(), game_cls.num_players() + game_cls.has_draw(), self.args).to(self.device)
+        self.nnet.eval()
+        self.dtype = dtype if self.device.type == 'cuda' else torch.float32
+        self.fast = fast
+        self._infer = None
+        self._graph = None
+
+    def __call__(self, board):
+        return self.predict(board)
+
+    def refresh(self):
+        """Rebuild the folded inference network after the weights changed."""
+        net = FoldedResNet(self.nnet).to(self.device).to(self.dtype)
+        if self.device.type == 'cuda':
+            net = net.to(memory_format=torch.channels_last)
+        self._infer, self._graph = net.eval(), None
+        return self
+
+    @torch.no_grad()
+    def process(self, batch):
+        """batch [B,C,H,W] (any float dtype, any device) -> (policy [B,A], value [B,P+1]) float32 probabilities on
+        the network's device."""
+        if not self.fast:
+            pi, v = self.nnet(batch.to(self.device, torch.float32))
+            return torch.exp(pi), torch.exp(v)
+        if self._infer is None:
+            self.refresh()
+        x = batch.to(self.device, self.dtype)
+        if self.device.type == 'cuda':
+            x = x.contiguous(memory_format=torch.channels_last)
+        return self._infer(x)
+
+    def predict(self, board):
+        b = torch.as_tensor(np.asarray(board, dtype=np.float32))[None]
+        p, v = self.process(b)
+        return p[0].cpu().numpy(), v[0].cpu().numpy()
+
+    # ---- hipGraph-captured fixed-batch evaluation: static input/output tensors the engine reads and writes
+    def capture(self, batch_size, in_dtype=None):
+        assert self.device.type == 'cuda'
+        if self._infer is None:
+            self.refresh()
+        in_dtype = in_dtype or self.dtype
+        C, H, W = self.nnet.channels, self.nnet.board_x, self.nnet.board_y
+        x = torch.zeros((batch_size, C, H, W), dtype=in_dtype, device=self.device)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(3):
+                self.process(x)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), torch.no_grad():
+            p, v = self.process(x)
+        self._graph = (g, x, p, v)
+        return x, p, v
+
+    def replay(self):
+        self._graph[0].replay()
+
+    def save_checkpoint(self, path):
+        torch.save({'state_dict': self.nnet.state_dict(), 'args': dict(self.args)}, path)
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.nnet.load_state_dict(ck['state_dict'])
+        self._infer = None

@@ -1,0 +1,159 @@
+"""bench.py -- self-play throughput of the MI355X engine on BASELINE.json's headline config.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): connect4, 2048 concurrent games per GPU x 100 MCTS sims per move, fp16 ResNet 128ch x 8
+(envs/connect4/train.py net + search hyper-parameters), random-init weights, games from the empty board, root noise +
+root temperature on, probFastSim = 0.  One "step" = one self-play round of the hot path over
+the whole batch: 100 x [select -> network -> backup] + advance, i.e. 204 800 simulations per GPU.  value = MCTS node
+expansions per second summed over all GPUs (games/s is reported next to it).  Everything is resident in HBM; the
+only host traffic in the timed region is one 40-byte counter read per round.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from alphazero_general_amd import distributed as D  # noqa: E402
+from alphazero_general_amd.envs.connect4 import Game  # noqa: E402
+from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper  # noqa: E402
+from alphazero_general_amd.selfplay import SelfPlayRunner  # noqa: E402
+from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
+
+B_PER_GPU, SIMS = 2048, 100
+# algorithmic figures (DESIGN.md "Roofline"): bytes one simulation moves through the tree kernels / FLOPs per leaf
+C4_SELECT_BYTES_PER_SIM = 5 * (32 + 7 * 32) + (32 + 7 * 32) + 2 * 80 + 336 + 5 * 4   # D=5 levels read, expand write, states, fp16 obs, path
+C4_BACKUP_BYTES_PER_SIM = 7 * 4 + 12 + 7 * 4 + 5 * (4 + 16) + 32
+C4_NET_FLOPS_PER_LEAF = 205e6
+HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
+
+
+def selfplay_args(games):
+    return dotdict(cpuct=4.0, fpu_reduction=0.4, root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0,
+                   numMCTSSims=SIMS, numFastSims=20, numWarmupSims=5, probFastSim=0.0, gamesPerIteration=games,
+                   add_root_noise=True, add_root_temp=True, symmetricSamples=True, mctsResetThreshold=None,
+                   startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
+
+
+def cpu_baseline(net, seconds=12.0):
+    """The CPU path timed beside the GPU number: the C oracle (bit-exact restatement of the reference Cython path,
+    oracle/) drives the same workload on ONE host core, leaves evaluated by the same GPU network through host
+    buffers (the reference's own arrangement, Coach.py:337-342).  Bounded sample."""
+    import oracle_lib as ol
+    Bc = 256
+    ag = ol.OAgent(0, Bc, sims=SIMS, games_per_iteration=1 << 30, seed=1, cpuct=4.0, fpu_reduction=0.4,
+                   add_root_noise=True, add_root_temp=True)
+    t_tree = t_all = 0.0
+    sims_done = 0
+    t_start = time.time()
+    while time.time() - t_start < seconds:
+        ag.begin_round()
+        for s in range(SIMS):
+            t0 = time.time()
+            obs, _, _ = ag.generate_batch()
+            t1 = time.time()
+            p, v = net.process(torch.from_numpy(obs))
+            p, v = p.cpu().numpy(), v.cpu().numpy()
+            t2 = time.time()
+            ag.process_batch(p, v)
+            t3 = time.time()
+            t_tree += (t1 - t0) + (t3 - t2); t_all += t3 - t0
+            sims_done += Bc
+        t0 = time.time(); ag.play_moves(); dt = time.time() - t0
+        t_tree += dt; t_all += dt
+    return {'value': round(ag.expansions / t_all, 1), 'unit': 'expansions/s', 'cores': 1, 'kind': 'port',
+            'sample': 'connect4 %d games x %d sims, %d simulations in %.1f s on one host core, leaves evaluated by the same GPU net '
+                      'through host buffers' % (Bc, SIMS, sims_done, t_all),
+            'tree_only_value': round(ag.expansions / t_tree, 1), 'host_cpus': os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=45)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--slots', type=int, default=B_PER_GPU)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank, local_rank, world = D.init_from_env()
+    assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (there is no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    torch.manual_seed(0)                                            # same random-init weights on every rank
+    B = a.slots
+    net = NNetWrapper(Game, CONNECT4_NET_ARGS, device=dev, dtype=torch.float16)
+    games = 1 << 30
+    per_game = 43 * 2
+    runner = SelfPlayRunner(Game, net, selfplay_args(games), num_slots=B, seed=0, slot_base=D.slot_base(rank, B),
+                            device=local_rank, use_graph=not a.no_graph,
+                            example_capacity=int(B * (a.steps + a.warmup + 8) / 7.0 + 2 * B) * per_game)
+    eng = runner.engine
+    for _ in range(a.warmup):
+        runner.play_round()
+    c0 = eng.counters()
+    ev_nn = []
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.time()
+    for k in range(a.steps):
+        if k == a.steps // 2:                                       # HIP-event timing of the kernels for ONE round
+            if runner.use_graph:                                    # (events around every launch perturb the pipeline)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); runner.nnet.replay(); e1.record(); ev_nn.append((e0, e1))
+            eng.profile(True)
+        runner.play_round()
+        if k == a.steps // 2:
+            prof = eng.profile_read()
+            eng.profile(False)
+    c1 = eng.counters()
+    # the exchange step of an iteration: all-gather the example shards (RCCL) + tallies
+    obs, pi, z = eng.examples(c0['num_examples'], c1['num_examples'] - c0['num_examples'])
+    gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
+    torch.cuda.synchronize(); D.barrier()
+    dt = D.max_over_ranks(time.time() - t0)
+    tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'],
+                                 c1['games_played'] - c0['games_played'], gobs.shape[0] if rank == 0 else 0])
+    if rank != 0:
+        return
+    expansions, sims, games_done, nsamples = [int(x) for x in tall]
+    sel_us = prof['select_ms'] * 1e3 / max(prof['select_n'], 1)
+    bak_us = prof['backup_ms'] * 1e3 / max(prof['backup_n'], 1)
+    adv_us = prof['advance_ms'] * 1e3 / max(prof['advance_n'], 1)
+    sel_gbs = C4_SELECT_BYTES_PER_SIM * B / (sel_us * 1e-6) / 1e9
+    out = {
+        'metric': 'mcts_node_expansions_per_sec', 'value': round(expansions / dt, 1), 'unit': 'expansions/s',
+        'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net', 'data': 'synthetic',
+        'config': {'workload': 'connect4 self-play, %d games/GPU x %d sims/move, fp16 ResNet 128ch x 8, random-init, noise+temp on'
+                               % (B, SIMS), 'games_per_gpu': B, 'sims_per_move': SIMS, 'hipgraph_net': bool(runner.use_graph)},
+        'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(sims / dt, 1),
+        'games_finished': games_done, 'samples_gathered': nsamples,
+        'roofline': {'kernel': 'k_select<C4>', 'bound': 'hbm', 'achieved': round(sel_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(sel_gbs / HBM_PEAK_GBS, 6), 'traffic': None, 'avg_launch_us': round(sel_us, 2),
+                     'algorithmic_bytes_per_launch': C4_SELECT_BYTES_PER_SIM * B},
+        'tree_kernels_us': {'select': round(sel_us, 2), 'backup': round(bak_us, 2), 'advance': round(adv_us, 2),
+                            'backup_GBps': round(C4_BACKUP_BYTES_PER_SIM * B / (bak_us * 1e-6) / 1e9, 2)},
+    }
+    if ev_nn:
+        nn_ms = ev_nn[0][0].elapsed_time(ev_nn[0][1])
+        tf = C4_NET_FLOPS_PER_LEAF * B / (nn_ms * 1e-3) / 1e12
+        out['nn_roofline'] = {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'ms_per_batch': round(nn_ms, 3)}
+    if a.gpus == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(net)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
