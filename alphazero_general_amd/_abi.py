@@ -59,13 +59,15 @@ SYMBOLS = {
     'azg_get_tape_counters': (_i, [_vp, _vp, _i, _i, C.POINTER(_u64)]),
     'azg_select': (_i, [_vp, _vp, _vp, _i, _vp]),
     'azg_arena_rows': (_i, [_vp, _vp, _i32p, _vp, _vp]),
-    'azg_backup': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'azg_backup': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     'azg_advance': (_i, [_vp, _vp, _i]),
     'azg_root_counts': (_i, [_vp, _vp, _vp]),
     'azg_root_probs': (_i, [_vp, _vp, _f, _vp]),
     'azg_root_value': (_i, [_vp, _vp, _i, _vp]),
     'azg_update_root': (_i, [_vp, _vp, _i, _i]),
     'azg_root_children': (_i, [_vp, _vp, _i, _i, _i, _i32p, _i32p, _f32p, _f32p, _f32p]),
+    'azg_node_children': (_i, [_vp, _vp, _i, _i, _i, _i, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p]),
+    'azg_reset_max_depth': (_i, [_vp, _vp]),
     'azg_tree_info': (_i, [_vp, _vp, _i, _i, _i32p]),
     'azg_last_path': (_i, [_vp, _vp, _i, _i, _i, _i32p]),
     'azg_read_counters': (_i, [_vp, _vp, C.POINTER(Counters)]),

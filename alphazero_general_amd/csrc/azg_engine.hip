@@ -253,11 +253,13 @@ extern "C" int azg_arena_rows(azg_engine *e, void *stream, const int32_t *p2i_ho
     return AZG_OK;
 }
 
-extern "C" int azg_backup(azg_engine *e, void *stream, const float *policy, const float *value, const int32_t *row_of_slot) {
+extern "C" int azg_backup(azg_engine *e, void *stream, const float *policy, const float *value, const int32_t *row_of_slot, int flags) {
     if (!e || !policy || !value) return fail(AZG_E_INVALID_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
+    View v = e->v;
+    if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
-    GAME_SWITCH(e, hipLaunchKernelGGL((k_backup<G>), dim3(e->v.B), dim3(64), 0, s, e->v, policy, value, row_of_slot));
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_backup<G>), dim3(e->v.B), dim3(64), 0, s, v, policy, value, row_of_slot));
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -329,6 +331,33 @@ extern "C" int azg_root_children(azg_engine *e, void *stream, int slot, int tree
     HIPCHK(hipMemcpy(ch.data(), base + root.first_child, sizeof(Node) * k, hipMemcpyDeviceToHost));
     for (int i = 0; i < k; i++) { a[i] = ch[i].a; n[i] = ch[i].n; q[i] = ch[i].q; p[i] = ch[i].p; vv[i] = ch[i].v; }
     return k;
+}
+
+extern "C" int azg_node_children(azg_engine *e, void *stream, int slot, int tree, int node, int max_k, int32_t *idx, int32_t *a, int32_t *n, float *q, float *p, float *vv) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    const int t = tree_of(e, slot, tree);
+    TreeHdr h; Node nd;
+    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
+    if (node < 0) node = h.root;
+    if (node >= h.alloc) return fail(AZG_E_INVALID_ARG, "node index out of range");
+    Node *base = e->v.nodes + (size_t)t * e->v.cap;
+    HIPCHK(hipMemcpy(&nd, base + node, sizeof(Node), hipMemcpyDeviceToHost));
+    int k = nd.nchild;
+    if (k > max_k) return fail(AZG_E_INVALID_ARG, "max_k too small");
+    if (k == 0) return 0;
+    std::vector<Node> ch((size_t)k);
+    HIPCHK(hipMemcpy(ch.data(), base + nd.first_child, sizeof(Node) * k, hipMemcpyDeviceToHost));
+    for (int i = 0; i < k; i++) { idx[i] = nd.first_child + i; a[i] = ch[i].a; n[i] = ch[i].n; q[i] = ch[i].q; p[i] = ch[i].p; vv[i] = ch[i].v; }
+    return k;
+}
+
+extern "C" int azg_reset_max_depth(azg_engine *e, void *stream) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    hipLaunchKernelGGL(k_reset_max_depth, dim3(((int)(e->v.B * e->v.T) + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->v);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
 }
 
 extern "C" int azg_tree_info(azg_engine *e, void *stream, int slot, int tree, int32_t *out8) {

@@ -513,6 +513,11 @@ __global__ __launch_bounds__(64) void k_reset(View ev, int first, int count, int
     for (int t = 0; t < ev.T; t++) init_tree(ev, slot * ev.T + t, lane);
 }
 
+__global__ __launch_bounds__(64) void k_reset_max_depth(View ev) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t < ev.B * ev.T) ev.hdr[t].max_depth = 0;
+}
+
 // arena rows (SelfPlayAgent.pyx:117-132): rows grouped by model = player_to_index[mover], slot order inside a group
 __global__ __launch_bounds__(64) void k_arena_rows(View ev, const int32_t *p2i, int32_t *row_of_slot, int32_t *rows_per_model) {
     const int lane = threadIdx.x;

@@ -128,10 +128,11 @@ class DeviceEngine:
         _abi.check(self.L.azg_arena_rows(self.h, _stream(), p2i, _ptr(self._row_of_slot), _ptr(self._rows_per_model)))
         return self._row_of_slot, self._rows_per_model
 
-    def backup(self, policy, value, row_of_slot=None):
+    def backup(self, policy, value, row_of_slot=None, add_root_noise=None, add_root_temp=None):
         assert policy.is_cuda and policy.dtype == torch.float32 and policy.is_contiguous() and policy.shape[1] == self.A
         assert value.is_cuda and value.dtype == torch.float32 and value.is_contiguous() and value.shape[1] == self.NV
-        _abi.check(self.L.azg_backup(self.h, _stream(), _ptr(policy), _ptr(value), _ptr(row_of_slot)))
+        flags = -1 if add_root_noise is None and add_root_temp is None else (int(bool(add_root_noise)) | 2 * int(bool(add_root_temp)))
+        _abi.check(self.L.azg_backup(self.h, _stream(), _ptr(policy), _ptr(value), _ptr(row_of_slot), flags))
 
     def advance(self, record_history=True):
         _abi.check(self.L.azg_advance(self.h, _stream(), int(bool(record_history))))
@@ -161,6 +162,16 @@ class DeviceEngine:
         k = _abi.check(self.L.azg_root_children(self.h, _stream(), slot, tree, K, a, n, q, p, v))
         return dict(a=np.array(a[:k], np.int32), n=np.array(n[:k], np.int32), q=np.array(q[:k], np.float32),
                     p=np.array(p[:k], np.float32), v=np.array(v[:k], np.float32))
+
+    def node_children(self, slot, node=-1, tree=0):
+        K = max(self.gi.max_children, 1)
+        idx = (C.c_int32 * K)(); a = (C.c_int32 * K)(); n = (C.c_int32 * K)()
+        q = (C.c_float * K)(); p = (C.c_float * K)(); v = (C.c_float * K)()
+        k = _abi.check(self.L.azg_node_children(self.h, _stream(), slot, tree, int(node), K, idx, a, n, q, p, v))
+        return [dict(idx=idx[i], a=a[i], n=n[i], q=q[i], p=p[i], v=v[i]) for i in range(k)]
+
+    def reset_max_depth(self):
+        _abi.check(self.L.azg_reset_max_depth(self.h, _stream()))
 
     def tree_info(self, slot, tree=0):
         o = (C.c_int32 * 8)()

@@ -132,7 +132,10 @@ int  azg_arena_rows(azg_engine *e, void *stream, const int32_t *player_to_index_
 /* SelfPlayAgent.processBatch (:137-151) = MCTS.process_results (:230-289) on every slot with row
  * row_of_slot[slot] of policy_dev[rows, A] / value_dev[rows, P+1] (float32 probabilities). */
 int  azg_backup(azg_engine *e, void *stream, const float *policy_dev, const float *value_dev,
-                const int32_t *row_of_slot_dev);
+                const int32_t *row_of_slot_dev, int flags);
+#define AZG_FLAGS_DEFAULT (-1)   /* use azg_config.add_root_noise / add_root_temp                          */
+#define AZG_FLAG_NOISE 1          /* process_results(..., add_root_noise, add_root_temp) per call (:230)    */
+#define AZG_FLAG_TEMP  2
 /* SelfPlayAgent.playMoves (:153-202): temperature, sample the move from MCTS.probs, record history,
  * MCTS.update_root + GameState.play_action, end-of-game bookkeeping (results, samples x symmetries, reset).
  * record_history = not fast (:161). */
@@ -146,6 +149,11 @@ int  azg_root_value(azg_engine *e, void *stream, int average, float *value_dev /
 int  azg_update_root(azg_engine *e, void *stream, int slot, int action);
 /* children of a slot's root in list order (Node._children): a, n, q, p, v.  blocking; returns k or <0. */
 int  azg_root_children(azg_engine *e, void *stream, int slot, int tree, int max_k, int32_t *a, int32_t *n, float *q, float *p, float *v);
+/* children of an arbitrary node (node < 0: the root) incl. their node indices, for tree walks
+ * (utils.plot_mcts_tree, alphazero/utils.py:57-83). blocking; returns k or <0. */
+int  azg_node_children(azg_engine *e, void *stream, int slot, int tree, int node, int max_k, int32_t *idx, int32_t *a, int32_t *n, float *q, float *p, float *v);
+/* MCTS.search resets max_depth at the start of every search (MCTS.pyx:168,179) */
+int  azg_reset_max_depth(azg_engine *e, void *stream);
 /* root header / search statistics of a slot's tree: n, q, v, player, e, depth, max_depth. blocking. */
 int  azg_tree_info(azg_engine *e, void *stream, int slot, int tree, int32_t *out8);
 /* path of the last find_leaf as actions (length = depth). blocking; returns depth or <0. */

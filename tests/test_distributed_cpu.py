@@ -1,0 +1,92 @@
+"""The N > 1 path on CPU: two gloo ranks shard game slots, exchange variable-length example shards with the
+all-gather used by bench.py / the native driver, and sum tallies.  (The engine itself needs a GPU; here the shards
+are produced by the CPU oracle so that the exchange is tested on real self-play data, including the sharding
+invariance property: rank r with slot_base = r*B reproduces the second half of a 2B-slot run.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _play(B, slot_base, seed, games):
+    import oracle_lib as ol
+    ag = ol.OAgent(0, B, sims=8, games_per_iteration=games, seed=seed, slot_base=slot_base)
+    step = 0
+    while ag.games_played < games:
+        ns = ag.begin_round()
+        for _ in range(ns):
+            obs, rg, rm = ag.generate_batch()
+            pol = np.zeros((B, 7), np.float32); val = np.zeros((B, 3), np.float32)
+            for i in range(B):
+                pol[i], val[i] = ol.fake_eval(seed, slot_base + i, step, 7, 3)
+            ag.process_batch(pol, val); step += 1
+        ag.play_moves()
+    return ag
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from alphazero_general_amd import distributed as D
+    r, lr, w = D.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    B = 6
+    games = D.shard_games(9, rank, world) + rank            # unequal quotas -> unequal shard lengths
+    ag = _play(B, D.slot_base(rank, B), 5, games)
+    obs, pi, z = [torch.from_numpy(x) for x in ag.samples()]
+    gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
+    tall = D.all_reduce_tallies([ag.games_played, obs.shape[0]])
+    tmax = D.max_over_ranks(float(rank + 1))
+    D.barrier()
+    q.put((rank, obs.shape[0], gobs.numpy(), gpi.numpy(), gz.numpy(), tall.numpy(), tmax, obs.numpy(), pi.numpy()))
+    dist.destroy_process_group()
+
+
+def test_gloo_allgather_examples_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n0, n1 = res[0][1], res[1][1]
+    assert n0 != n1 and n0 > 0 and n1 > 0
+    for r in res:
+        assert r[2].shape[0] == n0 + n1
+        assert (r[2][:n0] == res[0][7]).all() and (r[2][n0:] == res[1][7]).all()       # rank order, own order kept
+        assert (r[3][:n0] == res[0][8]).all() and (r[3][n0:] == res[1][8]).all()
+        assert r[4].shape == (n0 + n1, 3)
+        assert r[5][1] == n0 + n1 and r[6] == 2.0
+    assert (res[0][2] == res[1][2]).all()
+
+
+def test_sharding_invariance_oracle():
+    """slot_base makes shards reproduce the big run: slots [6,12) of a 12-slot agent == a 6-slot agent at slot_base 6."""
+    import oracle_lib as ol
+    big = ol.OAgent(0, 12, sims=6, games_per_iteration=1 << 30, seed=3)
+    small = ol.OAgent(0, 6, sims=6, games_per_iteration=1 << 30, seed=3, slot_base=6)
+    for rnd in range(5):
+        big.begin_round(); small.begin_round()
+        for s in range(6):
+            big.generate_batch(); small.generate_batch()
+            pol = np.zeros((12, 7), np.float32); val = np.zeros((12, 3), np.float32)
+            for i in range(12):
+                pol[i], val[i] = ol.fake_eval(3, i, rnd * 6 + s, 7, 3)
+            big.process_batch(pol, val); small.process_batch(pol[6:].copy(), val[6:].copy())
+        big.play_moves(); small.play_moves()
+        assert (big.last_actions()[6:] == small.last_actions()).all()

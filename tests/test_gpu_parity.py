@@ -271,3 +271,50 @@ def test_errors_surface(torch_mod):
             eng.select(obs); eng.backup(pol, val)
         eng.counters()                             # tree arena overflow is reported, not silently dropped
     eng.close()
+
+
+# ------------------------------------------------------------------ single-tree MCTS class (reference API surface)
+def test_mcts_class_api_vs_oracle(torch_mod):
+    from alphazero_general_amd.MCTS import MCTS
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.utils import dotdict
+    seed = 31337
+    args = dotdict(root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1, fpu_reduction=0.2, cpuct=1.25,
+                   _num_players=3, numMCTSSims=50, _azg_seed=seed)
+    m = MCTS(args)
+    g = Game()
+    for a in (3, 3, 2):
+        g.play_action(a)
+    og = ol.OGame(C4)
+    for a in (3, 3, 2):
+        og.play(a)
+    om = ol.OMCTS(C4, seed=seed, stream=0)
+    step = [0]
+
+    def nn(obs):
+        assert obs.shape == (4, 6, 7)
+        p, v = ol.fake_eval(seed, 0, step[0], 7, 3)
+        step[0] += 1
+        return p, v
+    m.search(g, nn, 50, False, False)
+    for s in range(50):
+        leaf, _ = om.find_leaf(og)
+        p, v = ol.fake_eval(seed, 0, s, 7, 3)
+        om.process_results(v, p)
+    assert (m.counts(g) == om.counts()).all()
+    assert (m.probs(g, 1.0) == om.probs(1.0)).all()
+    assert m.best_action(g) == int(np.argmax(om.counts()))
+    assert m.value() == om.value(False) and m.value(True) == om.value(True)
+    assert m.max_depth == om.max_depth
+    ch = {c.a: (c.n, c.q) for c in m._root._children}
+    och = om.root_children()
+    assert ch == {int(a): (int(n), float(q)) for a, n, q in zip(och['a'], och['n'], och['q'])}
+    a = m.best_action(g)
+    m.update_root(g, a); om.update_root(og, a)
+    g.play_action(a); og.play(a)
+    m.raw_search(g, 20, False, False); om.raw_search(og, 20)
+    assert (m.counts(g) == om.counts()).all()
+    with pytest.raises(ValueError):
+        full = Game()
+        m2 = MCTS(args)
+        m2.update_root(full, 7)
