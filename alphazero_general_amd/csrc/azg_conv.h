@@ -1,0 +1,160 @@
+// azg_conv.h -- fused 3x3 convolution for small boards on gfx950 MFMA (the network's hot op).
+//
+// Replaces, for the residual tower of alphazero/NNetArchitecture.py:36-120 in eval mode, the MIOpen implicit-GEMM
+// kernel + 4 separate elementwise launches per layer (bias, ReLU, pre-activation BN affine, residual add) that
+// PyTorch issues (profiles/r01_bench_kernel_stats_baseline.csv: 47 us conv + ~38 us elementwise per layer) with ONE
+// launch per convolution:
+//
+//     y = epilogue( conv3x3( prologue(x) ) )       prologue: optional per-channel affine + ReLU (pre-activation BN)
+//                                                  epilogue: + bias, optional + residual, optional ReLU, fp16 store
+//
+// Formulation: Y^T[cout, pixel] = sum over 9 taps of W_tap[cout, cin] . X^T[cin, pixel + shift(tap)]
+//   * activations are NHWC fp16, flattened to rows = board*H*W + y*W + x, 256 B (128 channels) per row;
+//   * one workgroup (4 waves) owns BOARDS whole boards = ROWS pixel rows, staged ONCE in LDS (43 KB for 4 connect4
+//     boards) and re-read by all 9 taps at a row offset of dy*W+dx; taps that fall off the board read a zero row;
+//   * wave w computes couts [32w, 32w+32) for all rows: MFMA v_mfma_f32_16x16x32_f16 with A = weights (16 couts x
+//     32 cin, loaded straight from L2 in a pre-packed fragment layout: each wave needs only its own cout slice, so
+//     LDS sharing would buy nothing) and B = activations (32 cin x 16 pixels, ds_read_b128 from the LDS tile);
+//     D[cout = 4*(lane/16)+r][pixel = lane%16] puts 4 consecutive channels of one pixel in a lane -> 8-byte stores;
+//   * LDS tile layout: row r, 16-byte chunk c lives at r*256 + ((c + 2r) & 15)*16.  For every read group of
+//     ds_read_b128 (8 lanes on rows R+{0..3,12..15} with chunk c, 8 lanes on rows R+{4..11} with chunk c+1) the 16
+//     slots are distinct for ANY row offset R: conflict-free for all 9 taps (an XOR swizzle is not: odd shifts pair up).
+// grid = boards / BOARDS workgroups (512 for 2048 connect4 boards: two resident per CU, one per SIMD pair).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace azg {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+    const void *x;          // KS==4: [rows, 128] fp16 ; stem (KS==1): [rows, 8] fp16 (NHWC, channels padded to 8)
+    const void *w;          // packed fragments [9][KS][8][64] x 16 B
+    const float *bias;      // [128]
+    const float *pre_scale; // [128] or null      prologue affine (pre-activation BatchNorm, eval mode)
+    const float *pre_shift; // [128]
+    const void *residual;   // [rows, 128] fp16 or null
+    void *y;                // [rows, 128] fp16
+    int boards;
+};
+
+template <int H, int W, int BOARDS, int KS, bool PRE, bool RES, bool RELU>
+__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvParams P) {
+    constexpr int HW = H * W, ROWS = BOARDS * HW, NSUB = (ROWS + 15) / 16, ZERO_BASE = ROWS * 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int row0 = blockIdx.x * ROWS;
+    const int rows_here = min(ROWS, P.boards * HW - row0);
+
+    // ---- stage the activation tile in LDS (with the optional pre-activation affine + ReLU) ----
+    if constexpr (KS == 4) {
+        const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0 * 16;
+        const int chunk = tid & 15;
+        float sc[8], sh[8];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { sc[j] = P.pre_scale[chunk * 8 + j]; sh[j] = P.pre_shift[chunk * 8 + j]; }
+        }
+        for (int c = tid; c < ROWS * 16; c += 256) {
+            const int row = c >> 4;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < rows_here) v = xg[c];
+            if constexpr (PRE) {
+                half8 h = *reinterpret_cast<half8 *>(&v);
+#pragma unroll
+                for (int j = 0; j < 8; j++) { float f = (float)h[j] * sc[j] + sh[j]; h[j] = (_Float16)(f > 0.f ? f : 0.f); }
+                v = *reinterpret_cast<uint4 *>(&h);
+            }
+            *reinterpret_cast<uint4 *>(smem + row * 256 + ((chunk + 2 * row) & 15) * 16) = v;
+        }
+    } else {
+        const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
+        for (int c = tid; c < ROWS * 4; c += 256) {            // chunks 0..3 of every row: channels 0..31, only 0..7 live
+            const int row = c >> 2, chunk = c & 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (chunk == 0 && row < rows_here) v = xg[row];
+            *reinterpret_cast<uint4 *>(smem + row * 256 + ((chunk + 2 * row) & 15) * 16) = v;
+        }
+    }
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + ZERO_BASE + tid * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // ---- per-lane pixel coordinates of each 16-row subtile ----
+    int py[NSUB], px[NSUB];
+#pragma unroll
+    for (int ps = 0; ps < NSUB; ps++) {
+        const int p = ps * 16 + i16;
+        const int pos = p % HW;
+        py[ps] = p < ROWS ? pos / W : -100;                     // rows past the tile never pass the bounds test
+        px[ps] = pos % W;
+    }
+
+    floatx4 acc[2][NSUB];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    const half8 *wfrag = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;   // + (tap*KS+ks)*8*64
+    half8 a_cur[2], a_nxt[2];
+    a_cur[0] = wfrag[0]; a_cur[1] = wfrag[64];
+
+#pragma unroll 1
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1, shift = dy * W + dx;
+        int base[NSUB], swz[NSUB];
+#pragma unroll
+        for (int ps = 0; ps < NSUB; ps++) {
+            const int yy = py[ps] + dy, xx = px[ps] + dx;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int src = ps * 16 + i16 + shift;
+            base[ps] = ok ? src * 256 : ZERO_BASE;
+            swz[ps] = 2 * src + g;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int kk = tap * KS + ks;
+            const int kn = kk + 1 < 9 * KS ? kk + 1 : kk;       // prefetch the next weight fragments (L2)
+            a_nxt[0] = wfrag[(size_t)kn * 512]; a_nxt[1] = wfrag[(size_t)kn * 512 + 64];
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) {
+                const half8 b = *reinterpret_cast<const half8 *>(smem + base[ps] + ((swz[ps] + ks * 4) & 15) * 16);
+                acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[0], b, acc[0][ps], 0, 0, 0);
+                acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[1], b, acc[1][ps], 0, 0, 0);
+            }
+            a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
+        }
+    }
+
+    // ---- epilogue: + bias (+ residual) (ReLU) -> fp16, 4 consecutive channels per lane ----
+    _Float16 *yg = reinterpret_cast<_Float16 *>(P.y);
+    const _Float16 *rg = reinterpret_cast<const _Float16 *>(P.residual);
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int c0 = (2 * wave + m) * 16 + g * 4;
+        const float b0 = P.bias[c0], b1 = P.bias[c0 + 1], b2 = P.bias[c0 + 2], b3 = P.bias[c0 + 3];
+#pragma unroll
+        for (int ps = 0; ps < NSUB; ps++) {
+            const int p = ps * 16 + i16;
+            if (p < rows_here) {
+                const size_t o = (size_t)(row0 + p) * 128 + c0;
+                float v0 = acc[m][ps][0] + b0, v1 = acc[m][ps][1] + b1, v2 = acc[m][ps][2] + b2, v3 = acc[m][ps][3] + b3;
+                if constexpr (RES) {
+                    const half4 r = *reinterpret_cast<const half4 *>(rg + o);
+                    v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+                }
+                if constexpr (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                half4 out = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                *reinterpret_cast<half4 *>(yg + o) = out;
+            }
+        }
+    }
+}
+
+// leaf observation planes [B, C, H, W] (any of the engine's obs dtypes) are written by k_select directly as the stem's
+// NHWC8 fp16 rows when obs_dtype == 2 (see G::write_obs_nhwc8).
+
+}  // namespace azg

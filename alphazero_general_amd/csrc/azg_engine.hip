@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "azg_kernels.h"
+#include "azg_conv.h"
 
 using namespace azg;
 
@@ -234,11 +235,12 @@ extern "C" int azg_get_tape_counters(azg_engine *e, void *stream, int first, int
 
 extern "C" int azg_select(azg_engine *e, void *stream, void *obs, int obs_dtype, const int32_t *row_of_slot) {
     if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
-    if (obs_dtype != 0 && obs_dtype != 1) return fail(AZG_E_INVALID_ARG, "obs_dtype must be 0 (f32) or 1 (f16)");
+    if (obs_dtype < 0 || obs_dtype > 2) return fail(AZG_E_INVALID_ARG, "obs_dtype must be 0 (f32), 1 (f16) or 2 (f16 NHWC8)");
     hipStream_t s = (hipStream_t)stream;
     EvPair p; prof_begin(e, s, 0, p);
     if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, float>), dim3(e->v.B), dim3(64), 0, s, e->v, (float *)obs, row_of_slot)); }
-    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, _Float16>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, _Float16>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
+    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, _Float16, true>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
     prof_end(e, s, 0, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -448,6 +450,38 @@ extern "C" int azg_last_actions_dev(azg_engine *e, int32_t **actions) {
     if (!e || !actions) return fail(AZG_E_INVALID_ARG, "null argument");
     *actions = e->v.last_action;
     return AZG_OK;
+}
+
+template <int H, int W, int BOARDS>
+static int launch_conv(hipStream_t s, const ConvParams &P, int stem, int relu) {
+    constexpr int ROWS = BOARDS * H * W;
+    const size_t lds = (size_t)ROWS * 256 + 256;
+    const dim3 grid((P.boards + BOARDS - 1) / BOARDS), block(256);
+    const bool pre = P.pre_scale != nullptr, res = P.residual != nullptr;
+#define AZG_CONV(KS, PRE, RES, RELU) hipLaunchKernelGGL((k_conv3x3<H, W, BOARDS, KS, PRE, RES, RELU>), grid, block, lds, s, P)
+    if (stem) { if (relu) AZG_CONV(1, false, false, true); else AZG_CONV(1, false, false, false); }
+    else if (pre && res && relu) AZG_CONV(4, true, true, true);
+    else if (pre && res) AZG_CONV(4, true, true, false);
+    else if (pre && relu) AZG_CONV(4, true, false, true);
+    else if (pre) AZG_CONV(4, true, false, false);
+    else if (res && relu) AZG_CONV(4, false, true, true);
+    else if (res) AZG_CONV(4, false, true, false);
+    else if (relu) AZG_CONV(4, false, false, true);
+    else AZG_CONV(4, false, false, false);
+#undef AZG_CONV
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
+                               const float *pre_shift, const void *residual, void *y, int boards, int stem, int relu) {
+    if (!x || !w || !bias || !y || boards <= 0) return fail(AZG_E_INVALID_ARG, "null argument");
+    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return fail(AZG_E_INVALID_ARG, "pre_scale and pre_shift go together");
+    ConvParams P{x, w, bias, pre_scale, pre_shift, residual, y, boards};
+    switch (game) {
+    case AZG_GAME_CONNECT4: return launch_conv<C4::H, C4::W, 4>((hipStream_t)stream, P, stem, relu);
+    default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
+    }
 }
 
 extern "C" int azg_profile_enable(azg_engine *e, int on) {

@@ -76,7 +76,7 @@ AZG_DEV int add_children(const View &ev, int slot, Node *nodes, TreeHdr *h, int 
 }
 
 // ================================================================================================ select
-template <class G, typename OT>
+template <class G, typename OT, bool NHWC8 = false>
 __global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *row_of_slot) {
     if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
     constexpr int NCH = (G::MAXK + 63) / 64;
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *
     G::store(st, &ev.leaf_states[slot], lane);
     if (obs) {
         const int row = row_of_slot ? row_of_slot[slot] : slot;
-        G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);     // SelfPlayAgent.pyx:116-123
+        if constexpr (NHWC8) G::write_obs_nhwc8(st, (_Float16 *)obs + (size_t)row * G::CELLS * 8, lane);
+        else G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);     // SelfPlayAgent.pyx:116-123
     }
 }
 

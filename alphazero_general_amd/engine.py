@@ -116,8 +116,13 @@ class DeviceEngine:
         """find_leaf on every slot; leaf observations into obs[rows, C, H, W] (float32 or float16)."""
         dt = 0
         if obs is not None:
-            assert obs.is_cuda and obs.is_contiguous() and obs.shape[1:] == self.obs_shape
-            dt = {torch.float32: 0, torch.float16: 1}[obs.dtype]
+            assert obs.is_cuda and obs.is_contiguous()
+            if obs.dim() == 3:                                   # [rows, H*W, 8] fp16: input format of the MFMA stem conv
+                assert obs.dtype == torch.float16 and obs.shape[1:] == (self.gi.obs_h * self.gi.obs_w, 8)
+                dt = 2
+            else:
+                assert obs.shape[1:] == self.obs_shape
+                dt = {torch.float32: 0, torch.float16: 1}[obs.dtype]
         _abi.check(self.L.azg_select(self.h, _stream(), _ptr(obs), dt, _ptr(row_of_slot)))
 
     def arena_rows(self, player_to_index):

@@ -132,11 +132,97 @@ class FoldedResNet(nn.Module):
         return F.softmax(pi.float(), dim=1), F.softmax(v.float(), dim=1)     # == exp(log_softmax) (NNetWrapper.py:231)
 
 
+# ------------------------------------------------------------------------------------- hand-written MFMA tower
+def pack_conv_weight(w, ks):
+    """[128, Cin, 3, 3] float -> fp16 MFMA A-fragment order [9 taps][ks][8 cout-subtiles][64 lanes][8] that
+    csrc/azg_conv.h reads: lane = g*16 + i holds W[cout = ms*16 + i, cin = ks*32 + g*8 + j, tap]."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cout == 128 and cin <= ks * 32
+    wp = torch.zeros((cout, ks * 32, 3, 3), dtype=torch.float32, device=w.device)
+    wp[:, :cin] = w.float()
+    t = wp.permute(2, 3, 0, 1).reshape(9, 8, 16, ks, 4, 8)            # [tap, ms, i, ks, g, j]
+    return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1).to(torch.float16)
+
+
+class HipResNet:
+    """The eval-mode network with its residual tower on the hand-written gfx950 MFMA convolution
+    (azg_conv3x3_f16: one launch per conv with the bias / ReLU / pre-activation affine / residual add fused) and the
+    two heads -- 1x1 conv + BN + flatten + Linear chain, all linear in the reference (NNetArchitecture.py:88-102,
+    112-118) -- collapsed into ONE [H*W*128, A + P+1] GEMM followed by the two softmaxes.
+    Activations are NHWC fp16 rows [B*H*W, 128]; the input is the engine's obs_dtype 2 format [B, H*W, 8]."""
+
+    def __init__(self, folded: FoldedResNet, game_id, device):
+        from . import _abi
+        self.L, self.game, self.device = _abi.lib(), int(game_id), torch.device(device)
+        self._check = _abi.check
+        C, H, W = folded.shape
+        self.C, self.HW = C, H * W
+        assert folded.stem_w.shape[0] == 128 and C <= 8, 'the MFMA tower is built for 128 channels'
+        f32 = dict(dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            self.stem_w = pack_conv_weight(folded.stem_w.float(), 1).to(self.device)
+            self.stem_b = folded.stem_b.float().to(**f32).contiguous()
+            self.blocks = []
+            for i in range(len(folded.w1)):
+                self.blocks.append(dict(
+                    ps=folded.pre_scale[i].float().reshape(-1).to(**f32).contiguous(),
+                    pt=folded.pre_shift[i].float().reshape(-1).to(**f32).contiguous(),
+                    w1=pack_conv_weight(folded.w1[i].float(), 4).to(self.device), b1=folded.b1[i].float().to(**f32).contiguous(),
+                    w2=pack_conv_weight(folded.w2[i].float(), 4).to(self.device)))
+            self.zero_b = torch.zeros(128, **f32)
+            # heads: logits[b, o] = sum_{pos,k} s[b,pos,k] * Wfull[pos*128+k, o] + bfull[o]
+            hw, hb = folded.head_w.float().reshape(-1, 128), folded.head_b.float()           # [vc+pc, 128], [vc+pc]
+            vc = folded.vc
+            Wv, bv = folded.v_fc.weight.float(), folded.v_fc.bias.float()                     # [NV, vc*HW] (index c*HW+pos)
+            Wp, bp = folded.pi_fc.weight.float(), folded.pi_fc.bias.float()
+            NV, A, HW = Wv.shape[0], Wp.shape[0], self.HW
+            fv = torch.einsum('ocp,ck->pko', Wv.reshape(NV, vc, HW), hw[:vc])                 # [HW, 128, NV]
+            fp = torch.einsum('ocp,ck->pko', Wp.reshape(A, -1, HW), hw[vc:])                  # [HW, 128, A]
+            self.A, self.NV = A, NV
+            self.head_w = torch.cat([fp, fv], dim=2).reshape(HW * 128, A + NV).to(self.device, torch.float16).contiguous()
+            bfv = bv + torch.einsum('ocp,c->o', Wv.reshape(NV, vc, HW), hb[:vc])
+            bfp = bp + torch.einsum('ocp,c->o', Wp.reshape(A, -1, HW), hb[vc:])
+            self.head_b = torch.cat([bfp, bfv]).to(**f32).contiguous()
+        self._bufs = {}
+
+    def _buffers(self, B):
+        if B not in self._bufs:
+            mk = lambda: torch.empty((B * self.HW, 128), dtype=torch.float16, device=self.device)
+            self._bufs[B] = (mk(), mk(), mk())
+        return self._bufs[B]
+
+    def _conv(self, x, w, b, y, boards, *, pre=None, res=None, stem=False, relu=True):
+        import ctypes as C
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.L.azg_conv3x3_f16(st, self.game, vp(x), vp(w), vp(b), vp(pre[0] if pre else None),
+                                           vp(pre[1] if pre else None), vp(res), vp(y), int(boards), int(stem), int(relu)))
+
+    def forward_nhwc8(self, x):
+        """x: [B, H*W, 8] fp16 -> (policy [B, A], value [B, P+1]) float32 probabilities."""
+        B = x.shape[0]
+        s, u, t = self._buffers(B)
+        self._conv(x, self.stem_w, self.stem_b, s, B, stem=True, relu=True)
+        for blk in self.blocks:
+            self._conv(s, blk['w1'], blk['b1'], u, B, pre=(blk['ps'], blk['pt']), relu=True)
+            self._conv(u, blk['w2'], self.zero_b, t, B, res=s, relu=False)
+            s, t = t, s
+        logits = torch.matmul(s.view(B, self.HW * 128), self.head_w).float() + self.head_b
+        return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
+
+    def to_nhwc8(self, batch):
+        """[B, C, H, W] (any float dtype) -> [B, H*W, 8] fp16."""
+        B, C = batch.shape[0], batch.shape[1]
+        x = torch.zeros((B, self.HW, 8), dtype=torch.float16, device=self.device)
+        x[:, :, :C] = batch.to(self.device).reshape(B, C, self.HW).permute(0, 2, 1)
+        return x
+
+
 class NNetWrapper:
     """The slice of alphazero/NNetWrapper.py the search path calls: predict (:207-223), process (:225-232),
     __call__ (:35-36), plus state_dict-compatible save/load of the network (:240-274)."""
 
-    def __init__(self, game_cls, args=None, *, device=None, dtype=torch.float16, fast=True):
+    def __init__(self, game_cls, args=None, *, device=None, dtype=torch.float16, fast=True, backend='auto'):
         self.game_cls = game_cls
         self.args = dotdict(DEFAULT_NET_ARGS.copy() if args is None else args)
         for k, v in DEFAULT_NET_ARGS.items():
@@ -147,7 +233,11 @@ class NNetWrapper:
         self.nnet.eval()
         self.dtype = dtype if self.device.type == 'cuda' else torch.float32
         self.fast = fast
+        # backend: 'torch' = folded PyTorch modules (MIOpen); 'hip' = hand-written MFMA tower (csrc/azg_conv.h);
+        # 'auto' = hip when the net is a 128-channel tower on a GPU and the game has a conv geometry, else torch
+        self.backend = backend
         self._infer = None
+        self._hip = None
         self._graph = None
 
     def __call__(self, board):
@@ -158,7 +248,11 @@ class NNetWrapper:
         net = FoldedResNet(self.nnet).to(self.device).to(self.dtype)
         if self.device.type == 'cuda':
             net = net.to(memory_format=torch.channels_last)
-        self._infer, self._graph = net.eval(), None
+        self._infer, self._graph, self._hip = net.eval(), None, None
+        use_hip = self.backend == 'hip' or (self.backend == 'auto' and self.device.type == 'cuda'
+                                            and self.args.num_channels == 128 and getattr(self.game_cls, 'AZG_GAME_ID', None) == 0)
+        if use_hip:
+            self._hip = HipResNet(FoldedResNet(self.nnet).to(self.device), self.game_cls.AZG_GAME_ID, self.device)
         return self
 
     @torch.no_grad()
@@ -170,6 +264,8 @@ class NNetWrapper:
             return torch.exp(pi), torch.exp(v)
         if self._infer is None:
             self.refresh()
+        if self._hip is not None:
+            return self._hip.forward_nhwc8(self._hip.to_nhwc8(batch))
         x = batch.to(self.device, self.dtype)
         if self.device.type == 'cuda':
             x = x.contiguous(memory_format=torch.channels_last)
@@ -182,23 +278,34 @@ class NNetWrapper:
 
     # ---- hipGraph-captured fixed-batch evaluation: static input/output tensors the engine reads and writes
     def capture(self, batch_size, in_dtype=None):
+        """Capture one fixed-batch evaluation into a hipGraph.  Returns (static input, policy, value); with the MFMA
+        backend the input is the engine's obs_dtype 2 tensor [B, H*W, 8] fp16, otherwise [B, C, H, W]."""
         assert self.device.type == 'cuda'
         if self._infer is None:
             self.refresh()
         in_dtype = in_dtype or self.dtype
         C, H, W = self.nnet.channels, self.nnet.board_x, self.nnet.board_y
-        x = torch.zeros((batch_size, C, H, W), dtype=in_dtype, device=self.device)
+        if self._hip is not None:
+            x = torch.zeros((batch_size, H * W, 8), dtype=torch.float16, device=self.device)
+            run = lambda: self._hip.forward_nhwc8(x)
+        else:
+            x = torch.zeros((batch_size, C, H, W), dtype=in_dtype, device=self.device)
+            run = lambda: self.process(x)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():
             for _ in range(3):
-                self.process(x)
+                run()
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g), torch.no_grad():
-            p, v = self.process(x)
+            p, v = run()
         self._graph = (g, x, p, v)
         return x, p, v
+
+    @property
+    def input_is_nhwc8(self):
+        return self._hip is not None
 
     def replay(self):
         self._graph[0].replay()

@@ -1,0 +1,80 @@
+"""Numerics of the network path on the GPU: the folded PyTorch inference net and the hand-written MFMA tower
+(azg_conv3x3_f16) against the plain fp32 PyTorch reference of the same architecture (NNetArchitecture.py:69-120).
+Tolerance: probabilities within 3e-3 absolute (fp16 activations/weights, fp32 accumulation) -- the parity bar for the
+floating-point network; the tree itself is checked bit-exactly with the SAME (p, v) fed to oracle and engine."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomize(net, torch, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.8 + 0.4)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) * 0.6 + 0.7)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+
+
+def _boards(torch, B, seed=0):
+    rng = np.random.RandomState(seed)
+    from alphazero_general_amd.envs.connect4 import Game
+    obs = []
+    for b in range(B):
+        g = Game()
+        for _ in range(rng.randint(0, 30)):
+            v = np.flatnonzero(g.valid_moves())
+            if len(v) == 0 or g.win_state().any():
+                break
+            g.play_action(int(rng.choice(v)))
+        obs.append(g.observation())
+    return torch.from_numpy(np.array(obs, np.float32))
+
+
+@pytest.mark.parametrize('backend', ['torch', 'hip'])
+def test_inference_paths_vs_fp32_reference(backend):
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
+    torch.manual_seed(3)
+    net = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', backend=backend)
+    _randomize(net.nnet.cpu(), torch); net.nnet.to('cuda:0')
+    x = _boards(torch, 37 if backend == 'hip' else 16)            # 37: not a multiple of the 4-board workgroup tile
+    with torch.no_grad():
+        lp, lv = net.nnet(x.to('cuda:0'))
+        rp, rv = torch.exp(lp).cpu(), torch.exp(lv).cpu()
+    p, v = net.process(x)
+    assert (net._hip is not None) == (backend == 'hip')
+    assert p.shape == rp.shape and v.shape == rv.shape and p.dtype == torch.float32
+    assert float((p.cpu() - rp).abs().max()) < 3e-3, float((p.cpu() - rp).abs().max())
+    assert float((v.cpu() - rv).abs().max()) < 3e-3, float((v.cpu() - rv).abs().max())
+    assert torch.allclose(p.sum(1).cpu(), torch.ones(p.shape[0]), atol=1e-4)
+
+
+def test_mfma_conv_single_layer_vs_torch():
+    """One fused conv (prologue affine + ReLU, bias, residual, ReLU) against torch in fp32, asymmetric weights."""
+    import ctypes as C
+    import torch
+    from alphazero_general_amd import _abi
+    from alphazero_general_amd.nnet import pack_conv_weight
+    torch.manual_seed(0)
+    dev = 'cuda:0'
+    B = 9
+    x = (torch.randn(B, 128, 6, 7) * 0.5).half().to(dev)
+    w = (torch.randn(128, 128, 3, 3) * 0.05).half().to(dev)
+    bias = torch.randn(128, device=dev); ps = torch.rand(128, device=dev) + 0.5; pt = torch.randn(128, device=dev) * 0.1
+    res = (torch.randn(B, 128, 6, 7) * 0.5).half().to(dev)
+    ref = torch.relu(torch.nn.functional.conv2d(torch.relu(x.float() * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)).half().float(),
+                                                w.float(), bias, padding=1) + res.float())
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, 128).contiguous()
+    xr, rr = rows(x), rows(res)
+    y = torch.empty_like(xr)
+    wp = pack_conv_weight(w.float(), 4).to(dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _abi.check(_abi.lib().azg_conv3x3_f16(st, 0, vp(xr), vp(wp), vp(bias), vp(ps), vp(pt), vp(rr), vp(y), B, 0, 1))
+    got = y.float().reshape(B, 6, 7, 128).permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-2 * max(1.0, ref.abs().max().item()) / 4, err
