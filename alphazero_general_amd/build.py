@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'azg_engine.hip')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in ('azg_engine.hip', 'azg_kernels.h', 'azg_games.h', 'azg_device.h')] + \
+DEPS = [os.path.join(HERE, 'csrc', f) for f in sorted(os.listdir(os.path.join(HERE, 'csrc')))] + \
        [os.path.join(os.path.dirname(HERE), 'include', 'azg.h')]
 OUT = os.path.join(HERE, 'lib', 'libazg_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']

@@ -154,6 +154,172 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvParams P) {
     }
 }
 
+
+// ================================================================================================ fused tower
+// The whole residual tower in ONE persistent launch: a workgroup keeps the residual stream s of its BOARDS boards in
+// LDS (buf0) for all 1 + 2*nblocks convolutions and ping-pongs the conv input through buf1
+// (t = relu(bn(s)) -> u = relu(conv1(t)+b) -> s' = conv2(u) + s), so activations never touch HBM between the input
+// planes and the final stream: the only per-layer traffic is the weight fragments, shared by all CUs out of L2.
+// 4 waves per workgroup, ONE workgroup per CU (2 x 42 KB tiles), one wave per SIMD with 22 independent accumulators
+// and double-buffered B fragments; grid = min(#tiles, #CUs), each workgroup loops over its tiles.
+struct TowerParams {
+    const void *x;            // [boards*H*W, 8] fp16 (NHWC, channels padded to 8) -- the engine's obs_dtype 2
+    const void *w;            // packed fragments: stem [9][1][8][64] then per block conv1, conv2 [9][4][8][64], 16 B each
+    const float *bias;        // [1 + 2*nblocks][128]
+    const float *pre_scale;   // [nblocks][128]
+    const float *pre_shift;   // [nblocks][128]
+    void *y;                  // [boards*H*W, 128] fp16: final residual stream
+    int boards, nblocks;
+};
+
+template <int H, int W, int ROWS, int NSUB, int KS>
+__device__ __forceinline__ void conv_main(const char *in, const char *zero, const half8 *wfrag, floatx4 (&acc)[2][NSUB],
+                                          const int (&py)[NSUB], const int (&px)[NSUB], int g, int i16) {
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    half8 bb[2][NSUB];
+    half8 a[3][2];
+    a[0][0] = wfrag[0]; a[0][1] = wfrag[64];
+    a[1][0] = wfrag[512]; a[1][1] = wfrag[512 + 64];
+    // B fragments of k-step 0 (tap 0: dy = dx = -1)
+#pragma unroll
+    for (int ps = 0; ps < NSUB; ps++) {
+        const int yy = py[ps] - 1, xx = px[ps] - 1;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int src = ps * 16 + i16 - W - 1;
+        const char *bp = ok ? in + src * 256 : zero;
+        bb[0][ps] = *reinterpret_cast<const half8 *>(bp + ((2 * src + g) & 15) * 16);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 9 * KS; kk++) {
+        const int cur = kk & 1, an = (kk + 2) % 3, ac = kk % 3;
+        // issue the loads of the NEXT steps first (weights two k-steps ahead from L2, B fragments one k-step ahead from
+        // LDS), then run this step's 22 MFMAs under them.  sched_barrier pins that order: left alone, hipcc sinks every
+        // ds_read next to its consumer and waits lgkmcnt(0) before each MFMA pair (one wave per SIMD = nothing hides it).
+        if (kk + 2 < 9 * KS) { a[an][0] = wfrag[(size_t)(kk + 2) * 512]; a[an][1] = wfrag[(size_t)(kk + 2) * 512 + 64]; }
+        if (kk + 1 < 9 * KS) {
+            const int tap = (kk + 1) / KS, ks = (kk + 1) % KS;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) {
+                const int yy = py[ps] + dy, xx = px[ps] + dx;
+                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const int src = ps * 16 + i16 + dy * W + dx;
+                const char *bp = ok ? in + src * 256 : zero;
+                bb[cur ^ 1][ps] = *reinterpret_cast<const half8 *>(bp + ((2 * src + g + ks * 4) & 15) * 16);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < NSUB; ps++) {
+            acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur][ps], acc[0][ps], 0, 0, 0);
+            acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur][ps], acc[1][ps], 0, 0, 0);
+        }
+        // pin the interleave: [2 MFMA | address VALU | 1 ds_read] x NSUB, weight loads up front
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+        for (int ps = 0; ps < NSUB; ps++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int H, int W, int BOARDS>
+__global__ __launch_bounds__(256, 1) void k_tower(TowerParams P) {
+    constexpr int HW = H * W, ROWS = BOARDS * HW, NSUB = (ROWS + 15) / 16, TILE = ROWS * 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *buf0 = smem, *buf1 = smem + TILE, *zero = smem + 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
+    if (tid < 16) *reinterpret_cast<uint4 *>(zero + tid * 16) = make_uint4(0, 0, 0, 0);
+    int py[NSUB], px[NSUB];
+#pragma unroll
+    for (int ps = 0; ps < NSUB; ps++) {
+        const int p = ps * 16 + i16, pos = p % HW;
+        py[ps] = p < ROWS ? pos / W : -100;
+        px[ps] = pos % W;
+    }
+    const half8 *wbase = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
+    floatx4 acc[2][NSUB];
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        const int rows_here = min(ROWS, P.boards * HW - row0);
+        // ---- input planes -> buf1 (chunks 0..3 = channels 0..31, only 0..7 live) ----
+        {
+            const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
+            for (int c = tid; c < ROWS * 4; c += 256) {
+                const int row = c >> 2, chunk = c & 3;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (chunk == 0 && row < rows_here) v = xg[row];
+                *reinterpret_cast<uint4 *>(buf1 + row * 256 + ((chunk + 2 * row) & 15) * 16) = v;
+            }
+        }
+        __syncthreads();
+        const half8 *wl = wbase;
+        for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
+            if (layer == 0) { conv_main<H, W, ROWS, NSUB, 1>(buf1, zero, wl, acc, py, px, g, i16); wl += (size_t)9 * 512; }
+            else { conv_main<H, W, ROWS, NSUB, 4>(buf1, zero, wl, acc, py, px, g, i16); wl += (size_t)36 * 512; }
+            __syncthreads();                                    // every wave is done reading buf1
+            // layer 0 (stem) and even layers (conv2): produce s -> buf0 and t = relu(affine(s)) -> buf1
+            // odd layers (conv1): produce u = relu(acc + b) -> buf1
+            const bool is_s = (layer & 1) == 0;
+            const int nb = layer >> 1;                          // block whose pre-activation consumes this s
+            const bool has_next = nb < P.nblocks;
+            const float *bias = P.bias + (size_t)layer * 128;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int c0 = (2 * wave + m) * 16 + g * 4;
+                const float b0 = bias[c0], b1 = bias[c0 + 1], b2 = bias[c0 + 2], b3 = bias[c0 + 3];
+                float s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                if (is_s && has_next) {
+                    const float *ps_ = P.pre_scale + (size_t)nb * 128 + c0, *pt_ = P.pre_shift + (size_t)nb * 128 + c0;
+                    s0 = ps_[0]; s1 = ps_[1]; s2 = ps_[2]; s3 = ps_[3]; t0 = pt_[0]; t1 = pt_[1]; t2 = pt_[2]; t3 = pt_[3];
+                }
+#pragma unroll
+                for (int ps = 0; ps < NSUB; ps++) {
+                    const int p = ps * 16 + i16;
+                    if (p < ROWS) {
+                        const int off = p * 256 + ((((c0 >> 3) + 2 * p) & 15) * 16) + (g & 1) * 8;
+                        float v0 = acc[m][ps][0] + b0, v1 = acc[m][ps][1] + b1, v2 = acc[m][ps][2] + b2, v3 = acc[m][ps][3] + b3;
+                        if (!is_s) {
+                            half4 u = {(_Float16)fmaxf(v0, 0.f), (_Float16)fmaxf(v1, 0.f), (_Float16)fmaxf(v2, 0.f), (_Float16)fmaxf(v3, 0.f)};
+                            *reinterpret_cast<half4 *>(buf1 + off) = u;
+                        } else {
+                            if (layer == 0) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            else {
+                                const half4 r = *reinterpret_cast<const half4 *>(buf0 + off);
+                                v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+                            }
+                            half4 sv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                            *reinterpret_cast<half4 *>(buf0 + off) = sv;
+                            if (has_next) {
+                                half4 tv = {(_Float16)fmaxf((float)sv[0] * s0 + t0, 0.f), (_Float16)fmaxf((float)sv[1] * s1 + t1, 0.f),
+                                            (_Float16)fmaxf((float)sv[2] * s2 + t2, 0.f), (_Float16)fmaxf((float)sv[3] * s3 + t3, 0.f)};
+                                *reinterpret_cast<half4 *>(buf1 + off) = tv;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- final residual stream -> HBM (un-swizzled rows) ----
+        {
+            uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * 16;
+            for (int c = tid; c < rows_here * 16; c += 256) {
+                const int row = c >> 4, chunk = c & 15;
+                yg[c] = *reinterpret_cast<const uint4 *>(buf0 + row * 256 + ((chunk + 2 * row) & 15) * 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // leaf observation planes [B, C, H, W] (any of the engine's obs dtypes) are written by k_select directly as the stem's
 // NHWC8 fp16 rows when obs_dtype == 2 (see G::write_obs_nhwc8).
 

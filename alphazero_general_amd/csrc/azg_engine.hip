@@ -484,6 +484,36 @@ extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void
     }
 }
 
+template <int H, int W, int BOARDS>
+static int launch_tower(hipStream_t s, const TowerParams &P) {
+    constexpr int ROWS = BOARDS * H * W;
+    const size_t lds = (size_t)2 * ROWS * 256 + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
+    const int grid = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), lds, s, P);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
+                                    const float *pre_shift, void *y, int boards, int nblocks) {
+    if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
+    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks};
+    switch (game) {
+    case AZG_GAME_CONNECT4: return launch_tower<C4::H, C4::W, 4>((hipStream_t)stream, P);
+    default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
+    }
+}
+
 extern "C" int azg_profile_enable(azg_engine *e, int on) {
     if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
     prof_drain(e);

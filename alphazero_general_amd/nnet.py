@@ -170,6 +170,13 @@ class HipResNet:
                     w1=pack_conv_weight(folded.w1[i].float(), 4).to(self.device), b1=folded.b1[i].float().to(**f32).contiguous(),
                     w2=pack_conv_weight(folded.w2[i].float(), 4).to(self.device)))
             self.zero_b = torch.zeros(128, **f32)
+            # the same parameters laid out for the fused persistent tower (azg_resnet_tower_f16)
+            self.tower_w = torch.cat([self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])]).contiguous()
+            self.tower_b = torch.stack([self.stem_b] + [t for b in self.blocks for t in (b['b1'], self.zero_b)]).contiguous()
+            nb = len(self.blocks)
+            self.tower_ps = torch.stack([b['ps'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, 128), **f32)
+            self.tower_pt = torch.stack([b['pt'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, 128), **f32)
+            self.fused = True
             # heads: logits[b, o] = sum_{pos,k} s[b,pos,k] * Wfull[pos*128+k, o] + bfull[o]
             hw, hb = folded.head_w.float().reshape(-1, 128), folded.head_b.float()           # [vc+pc, 128], [vc+pc]
             vc = folded.vc
@@ -202,11 +209,18 @@ class HipResNet:
         """x: [B, H*W, 8] fp16 -> (policy [B, A], value [B, P+1]) float32 probabilities."""
         B = x.shape[0]
         s, u, t = self._buffers(B)
-        self._conv(x, self.stem_w, self.stem_b, s, B, stem=True, relu=True)
-        for blk in self.blocks:
-            self._conv(s, blk['w1'], blk['b1'], u, B, pre=(blk['ps'], blk['pt']), relu=True)
-            self._conv(u, blk['w2'], self.zero_b, t, B, res=s, relu=False)
-            s, t = t, s
+        if self.fused:                                           # one persistent launch, activations resident in LDS
+            import ctypes as C
+            vp = lambda q: C.c_void_p(q.data_ptr())
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self.L.azg_resnet_tower_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
+                                                    vp(self.tower_pt), vp(s), int(B), len(self.blocks)))
+        else:                                                    # one launch per convolution
+            self._conv(x, self.stem_w, self.stem_b, s, B, stem=True, relu=True)
+            for blk in self.blocks:
+                self._conv(s, blk['w1'], blk['b1'], u, B, pre=(blk['ps'], blk['pt']), relu=True)
+                self._conv(u, blk['w2'], self.zero_b, t, B, res=s, relu=False)
+                s, t = t, s
         logits = torch.matmul(s.view(B, self.HW * 128), self.head_w).float() + self.head_b
         return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
 

@@ -183,6 +183,13 @@ int  azg_conv3x3_f16(void *stream, int game, const void *x_dev, const void *w_pa
                      const float *pre_scale_dev, const float *pre_shift_dev, const void *residual_dev, void *y_dev,
                      int boards, int stem, int relu);
 
+/* The whole residual tower (stem + 2*nblocks convolutions) in ONE persistent launch with activations resident in
+ * LDS (csrc/azg_conv.h k_tower).  x: [boards*H*W, 8] fp16; w_packed: stem fragments then conv1, conv2 of every block;
+ * bias: f32 [1 + 2*nblocks][128] (stem, then b1, b2 per block); pre_scale/pre_shift: f32 [nblocks][128];
+ * y: [boards*H*W, 128] fp16 = the final residual stream (input of the collapsed heads GEMM). */
+int  azg_resnet_tower_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
+                          const float *pre_scale_dev, const float *pre_shift_dev, void *y_dev, int boards, int nblocks);
+
 /* ---- timing hooks for bench.py (HIP events on `stream` around the engine's own kernels) -------------------- */
 int  azg_profile_enable(azg_engine *e, int on);
 /* accumulated GPU ms + launch counts per kernel family: select, backup, advance. blocking. */

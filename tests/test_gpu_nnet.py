@@ -33,18 +33,22 @@ def _boards(torch, B, seed=0):
     return torch.from_numpy(np.array(obs, np.float32))
 
 
-@pytest.mark.parametrize('backend', ['torch', 'hip'])
+@pytest.mark.parametrize('backend', ['torch', 'hip', 'hip_layers'])
 def test_inference_paths_vs_fp32_reference(backend):
+    layers = backend == 'hip_layers'
+    backend = 'hip' if layers else backend
     import torch
     from alphazero_general_amd.envs.connect4 import Game
     from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
     torch.manual_seed(3)
     net = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', backend=backend)
     _randomize(net.nnet.cpu(), torch); net.nnet.to('cuda:0')
-    x = _boards(torch, 37 if backend == 'hip' else 16)            # 37: not a multiple of the 4-board workgroup tile
+    x = _boards(torch, 1061 if backend == 'hip' else 16)            # 37: not a multiple of the 4-board workgroup tile
     with torch.no_grad():
         lp, lv = net.nnet(x.to('cuda:0'))
         rp, rv = torch.exp(lp).cpu(), torch.exp(lv).cpu()
+    if layers:
+        net.refresh(); net._hip.fused = False
     p, v = net.process(x)
     assert (net._hip is not None) == (backend == 'hip')
     assert p.shape == rp.shape and v.shape == rv.shape and p.dtype == torch.float32
