@@ -172,56 +172,81 @@ struct TowerParams {
     int boards, nblocks;
 };
 
-template <int H, int W, int ROWS, int NSUB, int KS>
-__device__ __forceinline__ void conv_main(const char *in, const char *zero, const half8 *wfrag, floatx4 (&acc)[2][NSUB],
-                                          const int (&py)[NSUB], const int (&px)[NSUB], int g, int i16) {
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    half8 bb[2][NSUB];
-    half8 a[3][2];
-    a[0][0] = wfrag[0]; a[0][1] = wfrag[64];
-    a[1][0] = wfrag[512]; a[1][1] = wfrag[512 + 64];
-    // B fragments of k-step 0 (tap 0: dy = dx = -1)
-#pragma unroll
-    for (int ps = 0; ps < NSUB; ps++) {
-        const int yy = py[ps] - 1, xx = px[ps] - 1;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const int src = ps * 16 + i16 - W - 1;
-        const char *bp = ok ? in + src * 256 : zero;
-        bb[0][ps] = *reinterpret_cast<const half8 *>(bp + ((2 * src + g) & 15) * 16);
+// LDS image of the tower: every board is stored with one pad line above and two pad columns to the right
+// ((H+1) lines of W+2 positions, LEAD pad rows in front), so that ALL nine taps of every real pixel are plain
+// in-bounds reads that return zeros off the board -- no per-tap masking and no address arithmetic: the address of
+// pixel p's fragment for (tap, k-step) is   lane_base[p] + const(tap, ks)   and the constant folds into the ds_read
+// offset field (the main loop is nothing but [2 MFMA, 1 ds_read offset:imm] groups).
+// Rows are 288 B apart (256 B of channels + 32 B pad): chunk c of padded row q starts at 16-byte bank slot
+// (c + 2q) mod 16 -- the conflict-free mapping derived above, obtained from the pad instead of a swizzle.  What it
+// needs is that the 8 lanes {0-3,12-15} and the 8 lanes {4-11} of a fragment each cover all residues q mod 8; padded
+// rows are not consecutive, so the pixel -> (subtile, lane) assignment is a host-built table (tower_pixmap) that
+// deals every 8-lane set one pixel of each residue class.  The board stride (== 2 mod 8) makes the classes equal.
+template <int H, int W, int BOARDS>
+struct TowerGeom {
+    static constexpr int HW = H * W, ROWS = BOARDS * HW, NSUB = (ROWS + 15) / 16;
+    static constexpr int PW = W + 2, LEAD = PW + 1;
+    static constexpr int BS0 = (H + 1) * PW, BSTRIDE = BS0 + ((2 - BS0 % 8) + 8) % 8;     // == 2 (mod 8)
+    static constexpr int TROWS = LEAD + (BOARDS - 1) * BSTRIDE + BS0 + PW + 1;
+    static constexpr int RSTRIDE = 288, TILE = TROWS * RSTRIDE;
+    static constexpr int BIAS = (PW + 1) * RSTRIDE;                          // makes every tap offset non-negative
+    __host__ __device__ static __forceinline__ int qrow(int p) {             // padded row of pixel p (tile-local)
+        const int b = p / HW, pos = p - b * HW, y = pos / W, x = pos - y * W;
+        return LEAD + b * BSTRIDE + (y + 1) * PW + x;
     }
+};
+
+// host: pixel index for (subtile, lane&15), -1 = spare lane.  8-lane set k = k-th pixel of every residue class.
+template <class GEO>
+static void tower_pixmap(int16_t *map /*[NSUB*16]*/) {
+    static const int setA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, setB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    int cls[8][GEO::ROWS], cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < GEO::ROWS; p++) { int r = GEO::qrow(p) & 7; cls[r][cnt[r]++] = p; }
+    for (int i = 0; i < GEO::NSUB * 16; i++) map[i] = -1;
+    // deal the classes round-robin: 8-lane set k takes, for every residue r, the k-th pixel of class r if it exists;
+    // leftovers (classes of unequal size) go to the free lanes of the last sets
+    int nsets = GEO::NSUB * 2, used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < nsets; k++) {
+        const int *lanes = (k & 1) ? setB : setA; int ps = k >> 1, li = 0;
+        for (int r = 0; r < 8; r++) if (used[r] < cnt[r] && used[r] <= k) map[ps * 16 + lanes[li++]] = (int16_t)cls[r][used[r]++];
+    }
+    for (int r = 0; r < 8; r++)
+        while (used[r] < cnt[r])
+            for (int i = 0; i < GEO::NSUB * 16 && used[r] < cnt[r]; i++) if (map[i] < 0) map[i] = (int16_t)cls[r][used[r]++];
+}
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+template <class GEO, int KS, int NSUB, int RB>
+__device__ __forceinline__ void conv_main(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[4][2],
+                                          floatx4 (&acc)[2][NSUB]) {
+    constexpr int NSTEP = 9 * KS;
+    half8 bb[2][NSUB];
 #pragma unroll
-    for (int kk = 0; kk < 9 * KS; kk++) {
-        const int cur = kk & 1, an = (kk + 2) % 3, ac = kk % 3;
-        // issue the loads of the NEXT steps first (weights two k-steps ahead from L2, B fragments one k-step ahead from
-        // LDS), then run this step's 22 MFMAs under them.  sched_barrier pins that order: left alone, hipcc sinks every
-        // ds_read next to its consumer and waits lgkmcnt(0) before each MFMA pair (one wave per SIMD = nothing hides it).
-        if (kk + 2 < 9 * KS) { a[an][0] = wfrag[(size_t)(kk + 2) * 512]; a[an][1] = wfrag[(size_t)(kk + 2) * 512 + 64]; }
-        if (kk + 1 < 9 * KS) {
+    for (int ps = 0; ps < NSUB; ps++)                                        // k-step 0: tap (-1,-1), ks 0
+        bb[0][ps] = *reinterpret_cast<const half8 *>(in + lb[ps] + (GEO::BIAS + (-GEO::PW - 1) * GEO::RSTRIDE));
+#pragma unroll
+    for (int kk = 0; kk < NSTEP; kk++) {
+        const int cur = kk & 1, an = (RB + kk + 3) & 3, ac = (RB + kk) & 3;
+        // weights three k-steps ahead (running straight on into the next layer's fragments), B fragments one ahead
+        a[an][0] = wfrag[(size_t)(kk + 3) * 512]; a[an][1] = wfrag[(size_t)(kk + 3) * 512 + 64];
+        if (kk + 1 < NSTEP) {
             const int tap = (kk + 1) / KS, ks = (kk + 1) % KS;
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int off = GEO::BIAS + ((tap / 3 - 1) * GEO::PW + (tap % 3 - 1)) * GEO::RSTRIDE + ks * 64;
 #pragma unroll
-            for (int ps = 0; ps < NSUB; ps++) {
-                const int yy = py[ps] + dy, xx = px[ps] + dx;
-                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                const int src = ps * 16 + i16 + dy * W + dx;
-                const char *bp = ok ? in + src * 256 : zero;
-                bb[cur ^ 1][ps] = *reinterpret_cast<const half8 *>(bp + ((2 * src + g + ks * 4) & 15) * 16);
-            }
+            for (int ps = 0; ps < NSUB; ps++) bb[cur ^ 1][ps] = *reinterpret_cast<const half8 *>(in + lb[ps] + off);
         }
 #pragma unroll
         for (int ps = 0; ps < NSUB; ps++) {
             acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur][ps], acc[0][ps], 0, 0, 0);
             acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur][ps], acc[1][ps], 0, 0, 0);
         }
-        // pin the interleave: [2 MFMA | address VALU | 1 ds_read] x NSUB, weight loads up front
+        // pin the interleave [2 MFMA | 1 ds_read] x NSUB with the two weight loads up front: left alone hipcc sinks each
+        // ds_read next to its consumer and waits lgkmcnt(0) before every MFMA pair (one wave per SIMD: nothing hides it)
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 #pragma unroll
         for (int ps = 0; ps < NSUB; ps++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -229,78 +254,88 @@ __device__ __forceinline__ void conv_main(const char *in, const char *zero, cons
 }
 
 template <int H, int W, int BOARDS>
-__global__ __launch_bounds__(256, 1) void k_tower(TowerParams P) {
-    constexpr int HW = H * W, ROWS = BOARDS * HW, NSUB = (ROWS + 15) / 16, TILE = ROWS * 256;
+__global__ __launch_bounds__(256, 1) void k_tower(TowerParams P, const int16_t *pixmap) {
+    using GEO = TowerGeom<H, W, BOARDS>;
+    constexpr int HW = GEO::HW, ROWS = GEO::ROWS, NSUB = GEO::NSUB, TILE = GEO::TILE, RS = GEO::RSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *buf0 = smem, *buf1 = smem + TILE, *zero = smem + 2 * TILE;
+    char *buf0 = smem, *buf1 = smem + TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
-    if (tid < 16) *reinterpret_cast<uint4 *>(zero + tid * 16) = make_uint4(0, 0, 0, 0);
-    int py[NSUB], px[NSUB];
+    for (int c = tid; c < 2 * TILE / 16; c += 256) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
+    unsigned lb[NSUB], eb[NSUB];                        // fragment-read base / epilogue base of this lane's pixel per subtile
+    bool live[NSUB];
 #pragma unroll
     for (int ps = 0; ps < NSUB; ps++) {
-        const int p = ps * 16 + i16, pos = p % HW;
-        py[ps] = p < ROWS ? pos / W : -100;
-        px[ps] = pos % W;
+        const int p = pixmap[ps * 16 + i16];
+        live[ps] = p >= 0;
+        const int q = p >= 0 ? GEO::qrow(p) : GEO::LEAD;                     // spare lanes read (and discard) pad rows
+        lb[ps] = (unsigned)(TILE + q * RS + g * 16 - GEO::BIAS);             // absolute LDS offset inside buf1 (the conv input)
+        eb[ps] = (unsigned)(q * RS + g * 8);
     }
-    const half8 *wbase = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
+    const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
+    half8 a[4][2];
     floatx4 acc[2][NSUB];
+    __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
         const int rows_here = min(ROWS, P.boards * HW - row0);
-        // ---- input planes -> buf1 (chunks 0..3 = channels 0..31, only 0..7 live) ----
+        // ---- input planes -> buf1: channels 0..7 live, 8..31 zero (the stem reads 32 channels) ----
         {
             const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
             for (int c = tid; c < ROWS * 4; c += 256) {
-                const int row = c >> 2, chunk = c & 3;
+                const int p = c >> 2, chunk = c & 3;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (chunk == 0 && row < rows_here) v = xg[row];
-                *reinterpret_cast<uint4 *>(buf1 + row * 256 + ((chunk + 2 * row) & 15) * 16) = v;
+                if (chunk == 0 && p < rows_here) v = xg[p];
+                *reinterpret_cast<uint4 *>(buf1 + GEO::qrow(p) * RS + chunk * 16) = v;
             }
         }
+        const half8 *wt = wl;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { a[i][0] = wt[(size_t)i * 512]; a[i][1] = wt[(size_t)i * 512 + 64]; }
         __syncthreads();
-        const half8 *wl = wbase;
         for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
-            if (layer == 0) { conv_main<H, W, ROWS, NSUB, 1>(buf1, zero, wl, acc, py, px, g, i16); wl += (size_t)9 * 512; }
-            else { conv_main<H, W, ROWS, NSUB, 4>(buf1, zero, wl, acc, py, px, g, i16); wl += (size_t)36 * 512; }
-            __syncthreads();                                    // every wave is done reading buf1
-            // layer 0 (stem) and even layers (conv2): produce s -> buf0 and t = relu(affine(s)) -> buf1
-            // odd layers (conv1): produce u = relu(acc + b) -> buf1
-            const bool is_s = (layer & 1) == 0;
-            const int nb = layer >> 1;                          // block whose pre-activation consumes this s
-            const bool has_next = nb < P.nblocks;
             const float *bias = P.bias + (size_t)layer * 128;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {                       // accumulators start at the bias
+                const int c0 = (2 * wave + m) * 16 + g * 4;
+                const floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
+#pragma unroll
+                for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
+            }
+            if (layer == 0) { conv_main<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
+            else { conv_main<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
+            __syncthreads();                                    // every wave is done reading buf1
+            // layer 0 (stem) and even layers (conv2): s -> buf0 and t = relu(affine(s)) -> buf1;  odd layers: u -> buf1
+            const bool is_s = (layer & 1) == 0;
+            const int nb = layer >> 1;
+            const bool has_next = nb < P.nblocks;
+            const half2v zero2 = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const int c0 = (2 * wave + m) * 16 + g * 4;
-                const float b0 = bias[c0], b1 = bias[c0 + 1], b2 = bias[c0 + 2], b3 = bias[c0 + 3];
-                float s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                half2v sc0 = zero2, sc1 = zero2, sh0 = zero2, sh1 = zero2;
                 if (is_s && has_next) {
                     const float *ps_ = P.pre_scale + (size_t)nb * 128 + c0, *pt_ = P.pre_shift + (size_t)nb * 128 + c0;
-                    s0 = ps_[0]; s1 = ps_[1]; s2 = ps_[2]; s3 = ps_[3]; t0 = pt_[0]; t1 = pt_[1]; t2 = pt_[2]; t3 = pt_[3];
+                    sc0 = (half2v){(_Float16)ps_[0], (_Float16)ps_[1]}; sc1 = (half2v){(_Float16)ps_[2], (_Float16)ps_[3]};
+                    sh0 = (half2v){(_Float16)pt_[0], (_Float16)pt_[1]}; sh1 = (half2v){(_Float16)pt_[2], (_Float16)pt_[3]};
                 }
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) {
-                    const int p = ps * 16 + i16;
-                    if (p < ROWS) {
-                        const int off = p * 256 + ((((c0 >> 3) + 2 * p) & 15) * 16) + (g & 1) * 8;
-                        float v0 = acc[m][ps][0] + b0, v1 = acc[m][ps][1] + b1, v2 = acc[m][ps][2] + b2, v3 = acc[m][ps][3] + b3;
+                    if (live[ps]) {
+                        const unsigned off = eb[ps] + (2 * wave + m) * 32;
+                        half2v lo = {(_Float16)acc[m][ps][0], (_Float16)acc[m][ps][1]};
+                        half2v hi = {(_Float16)acc[m][ps][2], (_Float16)acc[m][ps][3]};
                         if (!is_s) {
-                            half4 u = {(_Float16)fmaxf(v0, 0.f), (_Float16)fmaxf(v1, 0.f), (_Float16)fmaxf(v2, 0.f), (_Float16)fmaxf(v3, 0.f)};
-                            *reinterpret_cast<half4 *>(buf1 + off) = u;
+                            lo = __builtin_elementwise_max(lo, zero2); hi = __builtin_elementwise_max(hi, zero2);
+                            *reinterpret_cast<half2v *>(buf1 + off) = lo; *reinterpret_cast<half2v *>(buf1 + off + 4) = hi;
                         } else {
-                            if (layer == 0) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                            else {
-                                const half4 r = *reinterpret_cast<const half4 *>(buf0 + off);
-                                v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
-                            }
-                            half4 sv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                            *reinterpret_cast<half4 *>(buf0 + off) = sv;
+                            if (layer == 0) { lo = __builtin_elementwise_max(lo, zero2); hi = __builtin_elementwise_max(hi, zero2); }
+                            else { lo += *reinterpret_cast<const half2v *>(buf0 + off); hi += *reinterpret_cast<const half2v *>(buf0 + off + 4); }
+                            *reinterpret_cast<half2v *>(buf0 + off) = lo; *reinterpret_cast<half2v *>(buf0 + off + 4) = hi;
                             if (has_next) {
-                                half4 tv = {(_Float16)fmaxf((float)sv[0] * s0 + t0, 0.f), (_Float16)fmaxf((float)sv[1] * s1 + t1, 0.f),
-                                            (_Float16)fmaxf((float)sv[2] * s2 + t2, 0.f), (_Float16)fmaxf((float)sv[3] * s3 + t3, 0.f)};
-                                *reinterpret_cast<half4 *>(buf1 + off) = tv;
+                                half2v t0 = __builtin_elementwise_max(lo * sc0 + sh0, zero2), t1 = __builtin_elementwise_max(hi * sc1 + sh1, zero2);
+                                *reinterpret_cast<half2v *>(buf1 + off) = t0; *reinterpret_cast<half2v *>(buf1 + off + 4) = t1;
                             }
                         }
                     }
@@ -308,12 +343,12 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams P) {
             }
             __syncthreads();
         }
-        // ---- final residual stream -> HBM (un-swizzled rows) ----
+        // ---- final residual stream -> HBM (dense rows) ----
         {
             uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * 16;
             for (int c = tid; c < rows_here * 16; c += 256) {
-                const int row = c >> 4, chunk = c & 15;
-                yg[c] = *reinterpret_cast<const uint4 *>(buf0 + row * 256 + ((chunk + 2 * row) & 15) * 16);
+                const int p = c >> 4, chunk = c & 15;
+                yg[c] = *reinterpret_cast<const uint4 *>(buf0 + GEO::qrow(p) * RS + chunk * 16);
             }
         }
         __syncthreads();

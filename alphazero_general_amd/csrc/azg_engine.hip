@@ -486,19 +486,23 @@ extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void
 
 template <int H, int W, int BOARDS>
 static int launch_tower(hipStream_t s, const TowerParams &P) {
-    constexpr int ROWS = BOARDS * H * W;
-    const size_t lds = (size_t)2 * ROWS * 256 + 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    using GEO = TowerGeom<H, W, BOARDS>;
+    const size_t lds = (size_t)2 * GEO::TILE;
+    static int16_t *d_map[16] = {nullptr};                                  // per device: pixel -> (subtile, lane) table
     int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return fail(AZG_E_INVALID_ARG, "device ordinal out of range");
+    if (!d_map[dev]) {
+        int16_t map[GEO::NSUB * 16];
+        tower_pixmap<GEO>(map);
+        HIPCHK(hipMalloc((void **)&d_map[dev], sizeof(map)));
+        HIPCHK(hipMemcpy(d_map[dev], map, sizeof(map), hipMemcpyHostToDevice));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
     const int grid = ntiles < cus ? ntiles : cus;
-    hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), lds, s, P);
+    hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), lds, s, P, (const int16_t *)d_map[dev]);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }

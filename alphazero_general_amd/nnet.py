@@ -171,7 +171,8 @@ class HipResNet:
                     w2=pack_conv_weight(folded.w2[i].float(), 4).to(self.device)))
             self.zero_b = torch.zeros(128, **f32)
             # the same parameters laid out for the fused persistent tower (azg_resnet_tower_f16)
-            self.tower_w = torch.cat([self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])]).contiguous()
+            self.tower_w = torch.cat([self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])] +
+                                     [torch.zeros(3 * 512 * 8, dtype=torch.float16, device=self.device)]).contiguous()   # ring slack
             self.tower_b = torch.stack([self.stem_b] + [t for b in self.blocks for t in (b['b1'], self.zero_b)]).contiguous()
             nb = len(self.blocks)
             self.tower_ps = torch.stack([b['ps'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, 128), **f32)
