@@ -193,11 +193,11 @@ class HipResNet:
             self.head_b = torch.cat([bfp, bfv]).to(**f32).contiguous()
         self._bufs = {}
 
-    def _buffers(self, B):
-        if B not in self._bufs:
+    def _buffers(self, B, key=0):
+        if (B, key) not in self._bufs:
             mk = lambda: torch.empty((B * self.HW, 128), dtype=torch.float16, device=self.device)
-            self._bufs[B] = (mk(), mk(), mk())
-        return self._bufs[B]
+            self._bufs[(B, key)] = (mk(), mk(), mk())
+        return self._bufs[(B, key)]
 
     def _conv(self, x, w, b, y, boards, *, pre=None, res=None, stem=False, relu=True):
         import ctypes as C
@@ -206,10 +206,11 @@ class HipResNet:
         self._check(self.L.azg_conv3x3_f16(st, self.game, vp(x), vp(w), vp(b), vp(pre[0] if pre else None),
                                            vp(pre[1] if pre else None), vp(res), vp(y), int(boards), int(stem), int(relu)))
 
-    def forward_nhwc8(self, x):
-        """x: [B, H*W, 8] fp16 -> (policy [B, A], value [B, P+1]) float32 probabilities."""
+    def forward_nhwc8(self, x, key=0):
+        """x: [B, H*W, 8] fp16 -> (policy [B, A], value [B, P+1]) float32 probabilities.  `key` selects a private set
+        of activation buffers (one per captured graph, so that graphs on different streams never share scratch)."""
         B = x.shape[0]
-        s, u, t = self._buffers(B)
+        s, u, t = self._buffers(B, key)
         if self.fused:                                           # one persistent launch, activations resident in LDS
             import ctypes as C
             vp = lambda q: C.c_void_p(q.data_ptr())
@@ -231,6 +232,16 @@ class HipResNet:
         x = torch.zeros((B, self.HW, 8), dtype=torch.float16, device=self.device)
         x[:, :, :C] = batch.to(self.device).reshape(B, C, self.HW).permute(0, 2, 1)
         return x
+
+
+class CapturedNet:
+    """One hipGraph-captured fixed-batch evaluation: static input x, static outputs policy / value."""
+
+    def __init__(self, graph, x, policy, value):
+        self.graph, self.x, self.policy, self.value = graph, x, policy, value
+
+    def replay(self):
+        self.graph.replay()
 
 
 class NNetWrapper:
@@ -294,15 +305,23 @@ class NNetWrapper:
     # ---- hipGraph-captured fixed-batch evaluation: static input/output tensors the engine reads and writes
     def capture(self, batch_size, in_dtype=None):
         """Capture one fixed-batch evaluation into a hipGraph.  Returns (static input, policy, value); with the MFMA
-        backend the input is the engine's obs_dtype 2 tensor [B, H*W, 8] fp16, otherwise [B, C, H, W]."""
+        backend the input is the engine's obs_dtype 2 tensor [B, H*W, 8] fp16, otherwise [B, C, H, W].  Every call makes
+        an independent graph with its own buffers (CapturedNet), so several can run on different streams."""
+        cap = self.capture_net(batch_size, in_dtype)
+        self._graph = (cap.graph, cap.x, cap.policy, cap.value)
+        return cap.x, cap.policy, cap.value
+
+    def capture_net(self, batch_size, in_dtype=None):
         assert self.device.type == 'cuda'
         if self._infer is None:
             self.refresh()
         in_dtype = in_dtype or self.dtype
         C, H, W = self.nnet.channels, self.nnet.board_x, self.nnet.board_y
+        self._ncap = getattr(self, '_ncap', 0) + 1
+        key = self._ncap
         if self._hip is not None:
             x = torch.zeros((batch_size, H * W, 8), dtype=torch.float16, device=self.device)
-            run = lambda: self._hip.forward_nhwc8(x)
+            run = lambda: self._hip.forward_nhwc8(x, key)
         else:
             x = torch.zeros((batch_size, C, H, W), dtype=in_dtype, device=self.device)
             run = lambda: self.process(x)
@@ -315,8 +334,7 @@ class NNetWrapper:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g), torch.no_grad():
             p, v = run()
-        self._graph = (g, x, p, v)
-        return x, p, v
+        return CapturedNet(g, x, p, v)
 
     @property
     def input_is_nhwc8(self):

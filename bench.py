@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--slots', type=int, default=B_PER_GPU)
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--pipelines', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     a = ap.parse_args()
 
@@ -97,28 +98,33 @@ def main():
     games = 1 << 30
     per_game = 43 * 2
     runner = SelfPlayRunner(Game, net, selfplay_args(games), num_slots=B, seed=0, slot_base=D.slot_base(rank, B),
-                            device=local_rank, use_graph=not a.no_graph,
+                            device=local_rank, use_graph=not a.no_graph, pipelines=a.pipelines,
                             example_capacity=int(B * (a.steps + a.warmup + 8) / 7.0 + 2 * B) * per_game)
     eng = runner.engine
+    lanes = runner.lanes
     for _ in range(a.warmup):
         runner.play_round()
-    c0 = eng.counters()
+    c0 = runner.counters()
+    ex0 = [ln.engine.counters()['num_examples'] for ln in lanes]
     ev_nn = []
     D.barrier(); torch.cuda.synchronize()
     t0 = time.time()
     for k in range(a.steps):
         if k == a.steps // 2:                                       # HIP-event timing of the kernels for ONE round
+            torch.cuda.synchronize()
             if runner.use_graph:                                    # (events around every launch perturb the pipeline)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); runner.nnet.replay(); e1.record(); ev_nn.append((e0, e1))
+                with torch.cuda.stream(lanes[0].stream):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); lanes[0].net.replay(); e1.record(); ev_nn.append((e0, e1))
+                torch.cuda.synchronize()
             eng.profile(True)
         runner.play_round()
         if k == a.steps // 2:
             prof = eng.profile_read()
             eng.profile(False)
-    c1 = eng.counters()
+    c1 = runner.counters()
     # the exchange step of an iteration: all-gather the example shards (RCCL) + tallies
-    obs, pi, z = eng.examples(c0['num_examples'], c1['num_examples'] - c0['num_examples'])
+    obs, pi, z = runner.samples(ex0)
     gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
     torch.cuda.synchronize(); D.barrier()
     dt = D.max_over_ranks(time.time() - t0)
@@ -130,24 +136,26 @@ def main():
     sel_us = prof['select_ms'] * 1e3 / max(prof['select_n'], 1)
     bak_us = prof['backup_ms'] * 1e3 / max(prof['backup_n'], 1)
     adv_us = prof['advance_ms'] * 1e3 / max(prof['advance_n'], 1)
-    sel_gbs = C4_SELECT_BYTES_PER_SIM * B / (sel_us * 1e-6) / 1e9
+    Bl = B // a.pipelines                                           # slots per launch
+    sel_gbs = C4_SELECT_BYTES_PER_SIM * Bl / (sel_us * 1e-6) / 1e9
     out = {
         'metric': 'mcts_node_expansions_per_sec', 'value': round(expansions / dt, 1), 'unit': 'expansions/s',
         'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net', 'data': 'synthetic',
         'config': {'workload': 'connect4 self-play, %d games/GPU x %d sims/move, fp16 ResNet 128ch x 8, random-init, noise+temp on'
-                               % (B, SIMS), 'games_per_gpu': B, 'sims_per_move': SIMS, 'hipgraph_net': bool(runner.use_graph)},
+                               % (B, SIMS), 'games_per_gpu': B, 'sims_per_move': SIMS, 'hipgraph_net': bool(runner.use_graph),
+                   'stream_pipelines': a.pipelines},
         'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(sims / dt, 1),
         'games_finished': games_done, 'samples_gathered': nsamples,
         'roofline': {'kernel': 'k_select<C4>', 'bound': 'hbm', 'achieved': round(sel_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(sel_gbs / HBM_PEAK_GBS, 6), 'traffic': None, 'avg_launch_us': round(sel_us, 2),
-                     'algorithmic_bytes_per_launch': C4_SELECT_BYTES_PER_SIM * B},
+                     'algorithmic_bytes_per_launch': C4_SELECT_BYTES_PER_SIM * Bl},
         'tree_kernels_us': {'select': round(sel_us, 2), 'backup': round(bak_us, 2), 'advance': round(adv_us, 2),
-                            'backup_GBps': round(C4_BACKUP_BYTES_PER_SIM * B / (bak_us * 1e-6) / 1e9, 2)},
+                            'backup_GBps': round(C4_BACKUP_BYTES_PER_SIM * Bl / (bak_us * 1e-6) / 1e9, 2)},
     }
     if ev_nn:
         nn_ms = ev_nn[0][0].elapsed_time(ev_nn[0][1])
-        tf = C4_NET_FLOPS_PER_LEAF * B / (nn_ms * 1e-3) / 1e12
+        tf = C4_NET_FLOPS_PER_LEAF * (B // a.pipelines) / (nn_ms * 1e-3) / 1e12
         out['nn_roofline'] = {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'ms_per_batch': round(nn_ms, 3)}
     if a.gpus == 1 and not a.no_cpu_baseline:
