@@ -1,0 +1,221 @@
+"""`SelfPlayAgent` with the reference's constructor and process protocol (alphazero/SelfPlayAgent.pyx:13-202), so that
+the reference's Coach.py (Coach.py:291-361) and Arena.pyx (Arena.pyx:236-328) can spawn it unchanged ("compat mode"):
+
+    SelfPlayAgent(id, game_cls, ready_queue, batch_ready, batch_tensor, policy_tensor, value_tensor, output_queue,
+                  result_queue, complete_count, games_played, stop_event, pause_event, args, _is_arena, _is_warmup)
+
+It is an mp.Process; the caller owns every queue / event / shared tensor.  Per simulation the agent writes the leaf
+observations into `batch_tensor` (self-play) or puts the per-model list on `output_queue` (arena, :125-132), puts its
+id on `ready_queue`, waits for `batch_ready`, and reads `policy_tensor` / `value_tensor`; finished games go to
+`result_queue` as (final_state, winstate, id) and, while `games_played < gamesPerIteration` (tested under the
+caller's lock, :179-183), their samples to `output_queue` as (observation, pi, winstate float32).
+
+Where the search runs: Coach forks its agents AFTER initialising the GPU in the parent, and a forked child cannot
+use HIP.  The agent process therefore keeps the reference's role (queues, events, shared tensors) and drives a
+separate worker process (a fresh interpreter, alphazero_general_amd/_engine_worker.py) that owns the device engine; the two exchange the batch through POSIX shared memory
+and a pipe.  Compat mode pays that host hop per simulation by construction (the network lives in the parent); the
+throughput path is alphazero_general_amd.selfplay.SelfPlayRunner.  Errors in the worker are re-raised in the agent,
+which prints the traceback and exits like the reference (:100-101) -- but never leaves the parent waiting: it still
+counts itself complete.
+"""
+import itertools
+import os
+import time
+import traceback
+from multiprocessing import shared_memory
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from .Game import azg_game_id
+from .utils import default_temp_scaling, temp_table
+
+
+from ._engine_worker import engine_worker  # noqa: F401  (the device-side half; runs in its own process)
+
+
+class SelfPlayAgent(mp.Process):
+    def __init__(self, id, game_cls, ready_queue, batch_ready, batch_tensor, policy_tensor, value_tensor, output_queue,
+                 result_queue, complete_count, games_played, stop_event, pause_event, args, _is_arena=False, _is_warmup=False):
+        super().__init__()
+        self.id = id
+        self.game_cls = game_cls
+        self.ready_queue = ready_queue
+        self.batch_ready = batch_ready
+        self.batch_tensor = batch_tensor
+        self.batch_size = policy_tensor.shape[0] if _is_arena else self.batch_tensor.shape[0]     # :23-26
+        self.policy_tensor = policy_tensor
+        self.value_tensor = value_tensor
+        self.output_queue = output_queue
+        self.result_queue = result_queue
+        self.games_played = games_played
+        self.complete_count = complete_count
+        self.stop_event = stop_event
+        self.pause_event = pause_event
+        self.args = args
+        self._is_arena = _is_arena
+        self._is_warmup = _is_warmup
+        if _is_arena:
+            self.player_to_index = list(range(game_cls.num_players()))        # :44-47 (read by Arena.play_games)
+            np.random.shuffle(self.player_to_index)
+            self.batch_indices = None
+        self.fast = False
+        self._conn = None
+
+    # ---- worker plumbing ----
+    def _call(self, cmd, arg=None):
+        self._conn.send((cmd, arg))
+        status, out = self._conn.recv()
+        if status == 'error':
+            raise RuntimeError('device engine worker failed:\n' + out)
+        return out
+
+    def _check_pause(self):
+        while self.pause_event.is_set():
+            time.sleep(.1)
+
+    def _start_worker(self):
+        a = self.args
+        gid = azg_game_id(self.game_cls)
+        B, A, NV = self.batch_size, self.game_cls.action_size(), self.game_cls.num_players() + 1
+        O = int(np.prod(self.game_cls.observation_size()))
+        self._shm = {k: shared_memory.SharedMemory(create=True, size=4 * B * n) for k, n in (('obs', O), ('pol', A), ('val', NV))}
+        self._obs_h = np.ndarray((B, O), np.float32, buffer=self._shm['obs'].buf)
+        self._pol_h = np.ndarray((B, A), np.float32, buffer=self._shm['pol'].buf)
+        self._val_h = np.ndarray((B, NV), np.float32, buffer=self._shm['val'].buf)
+        sims = max(int(a.get('numMCTSSims', 100) or 0), int(a.get('numFastSims', 0) or 0), int(a.get('numWarmupSims', 0) or 0))
+        tt = temp_table(a.get('temp_scaling_fn', default_temp_scaling), a.get('startTemp', 1.0), self.game_cls.max_turns())
+        seed = int(a.get('_azg_seed', int.from_bytes(os.urandom(7), 'little'))) + 7919 * int(self.id)    # :81 np.random.seed()
+        cfg = dict(game=gid, B=B, A=A, NV=NV, O=O, arena=bool(self._is_arena), temp_table=tt,
+                   player_to_index=list(getattr(self, 'player_to_index', [])),
+                   shm={k: v.name for k, v in self._shm.items()},
+                   engine=dict(cpuct=a.cpuct, fpu_reduction=a.fpu_reduction, root_noise_frac=a.root_noise_frac,
+                               root_policy_temp=a.root_policy_temp, min_discount=a.get('min_discount', 1.0),
+                               add_root_noise=bool(a.get('add_root_noise', True)), add_root_temp=bool(a.get('add_root_temp', True)),
+                               symmetric_samples=bool(a.get('symmetricSamples', True)),
+                               mcts_reset_threshold=a.get('mctsResetThreshold', 0) or 0, games_per_iteration=1 << 30,
+                               start_temp=a.get('startTemp', 1.0), arena_temp=a.get('arenaTemp', 0.25), seed=seed,
+                               example_capacity=0 if self._is_arena else 8 * B * (self.game_cls.max_turns() or 64) + 1024,
+                               sims_hint=sims))
+        # a fresh interpreter (not a fork: HIP cannot be used in a forked child of a process that initialised it; not an
+        # mp child: Coach makes the agents daemonic and daemonic processes may not have mp children)
+        import subprocess
+        import sys
+        from multiprocessing.connection import Listener
+        key = os.urandom(16)
+        listener = Listener(family='AF_UNIX', authkey=key)
+        env = dict(os.environ, AZG_WORKER_KEY=key.hex(),
+                   PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+        self._worker = subprocess.Popen([sys.executable, '-m', 'alphazero_general_amd._engine_worker', listener.address], env=env)
+        self._conn = listener.accept()
+        listener.close()
+        self._conn.send(cfg)
+        status, out = self._conn.recv()
+        if status == 'error':
+            raise RuntimeError('device engine worker failed to start:\n' + out)
+
+    def _stop_worker(self):
+        try:
+            if self._conn is not None:
+                self._call('close')
+            self._worker.wait(10)
+        except Exception:
+            pass
+        for s in getattr(self, '_shm', {}).values():
+            try:
+                s.close(); s.unlink()
+            except Exception:
+                pass
+
+    # ---- the reference's loop (:79-101) ----
+    def run(self):
+        try:
+            np.random.seed()
+            self._start_worker()
+            a = self.args
+            while not self.stop_event.is_set() and self.games_played.value < a.gamesPerIteration:
+                self._check_pause()
+                self.fast = np.random.random_sample() < a.probFastSim
+                sims = a.numFastSims if self.fast else a.numMCTSSims if not self._is_warmup else a.numWarmupSims
+                for _ in range(sims):
+                    if self.stop_event.is_set(): break
+                    self.generateBatch()
+                    if self.stop_event.is_set(): break
+                    self.processBatch()
+                if self.stop_event.is_set(): break
+                self.playMoves()
+        except Exception:
+            print(traceback.format_exc())
+        finally:
+            # unlike the reference (an agent exception leaves the parent polling forever) the agent
+            # always reports completion
+            with self.complete_count.get_lock():
+                self.complete_count.value += 1
+            if not self._is_arena:
+                try:
+                    self.output_queue.close()
+                    self.output_queue.join_thread()
+                except Exception:
+                    pass
+            self._stop_worker()
+
+    def generateBatch(self):                                           # :103-135
+        self._check_pause()
+        if self._is_warmup:
+            self._call('select_noobs')
+            return
+        rows = self._call('select')
+        shape = tuple(self.game_cls.observation_size())
+        if self._is_arena:
+            row_of_slot, rpm = rows
+            obs = torch.from_numpy(self._obs_h.reshape((self.batch_size,) + shape).copy())
+            batch, off = [], 0
+            for mi in range(self.game_cls.num_players()):               # list indexed by model, [] when a model has no rows
+                n = int(rpm[mi])
+                batch.append(obs[off:off + n] if n else [])
+                off += n
+            self.output_queue.put(batch)
+            order = np.argsort(row_of_slot, kind='stable')               # row -> game, what the reference keeps (:132)
+            self.batch_indices = list(order)
+        else:
+            self.batch_tensor.copy_(torch.from_numpy(self._obs_h.reshape((self.batch_size,) + shape)))
+        self.ready_queue.put(self.id)
+
+    def processBatch(self):                                            # :137-151
+        if self._is_warmup:                                            # :48-52,111-114 uniform policy / value
+            self._pol_h[:] = 1.0 / self._pol_h.shape[1]
+            self._val_h[:] = 1.0 / self._val_h.shape[1]
+        else:
+            self.batch_ready.wait()
+            self.batch_ready.clear()
+            self._pol_h[:] = self.policy_tensor.data.numpy()
+            self._val_h[:] = self.value_tensor.data.numpy()
+        self._call('backup')
+
+    def playMoves(self):                                               # :153-202
+        self._check_pause()
+        fin, states = self._call('advance_begin', (not self.fast) and (not self._is_arena))
+        idx = np.flatnonzero(fin)
+        counted = np.zeros(self.batch_size, np.int32)
+        from .MCTS import decode_state
+        template = self.game_cls()
+        NV = self.game_cls.num_players() + 1
+        winstates = {}
+        for k, i in enumerate(idx):
+            ws = np.array([(int(fin[i]) >> j) & 1 for j in range(NV)], dtype=np.uint8)
+            winstates[int(i)] = ws
+            cells, player, turns = states[k]
+            self.result_queue.put((decode_state(template, cells, player, turns), ws, self.id))      # :178
+            lock = self.games_played.get_lock()
+            lock.acquire()
+            if self.games_played.value < self.args.gamesPerIteration:                                # :181-183
+                self.games_played.value += 1
+                counted[i] = 1
+            lock.release()
+        out = self._call('advance_commit', counted.tolist())
+        if out is not None and not self._is_arena:
+            o, p, z = out
+            for j in range(o.shape[0]):                                                             # :184-196
+                self._check_pause()
+                self.output_queue.put((o[j], p[j], z[j]))

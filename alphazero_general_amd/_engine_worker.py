@@ -1,0 +1,84 @@
+"""Device-side half of the compat SelfPlayAgent: a fresh interpreter that owns the DeviceEngine and serves the agent
+process over a multiprocessing.connection (see SelfPlayAgent.py).  Started as
+    python -m alphazero_general_amd._engine_worker <listener address>        (authkey in AZG_WORKER_KEY)
+"""
+import os
+import sys
+import traceback
+from multiprocessing import shared_memory
+
+import numpy as np
+
+
+def engine_worker(conn, cfg):
+    """Runs in a fresh (spawned) process: owns the DeviceEngine, serves commands from the agent process."""
+    try:
+        import torch as _t
+        from alphazero_general_amd.engine import DeviceEngine
+        B = cfg['B']
+        shm = {k: shared_memory.SharedMemory(name=n) for k, n in cfg['shm'].items()}
+        obs_h = np.ndarray((B, cfg['O']), np.float32, buffer=shm['obs'].buf)
+        pol_h = np.ndarray((B, cfg['A']), np.float32, buffer=shm['pol'].buf)
+        val_h = np.ndarray((B, cfg['NV']), np.float32, buffer=shm['val'].buf)
+        eng = DeviceEngine(cfg['game'], B, arena=cfg['arena'], temp_table_override=cfg['temp_table'], **cfg['engine'])
+        dev = eng.device
+        obs = eng.new_obs(_t.float32)
+        pol = _t.zeros((B, cfg['A']), dtype=_t.float32, device=dev)
+        val = _t.zeros((B, cfg['NV']), dtype=_t.float32, device=dev)
+        n_ex = 0
+        row_of_slot = None
+        conn.send(('ready', None))
+        while True:
+            cmd, arg = conn.recv()
+            if cmd == 'select':
+                rows = None
+                if cfg['arena']:
+                    row_of_slot, rpm = eng.arena_rows(cfg['player_to_index'])
+                eng.select(obs, row_of_slot)
+                obs_h[:] = obs.reshape(B, -1).cpu().numpy()
+                if cfg['arena']:
+                    rows = (row_of_slot.cpu().numpy().copy(), rpm.cpu().numpy().copy())
+                conn.send(('ok', rows))
+            elif cmd == 'select_noobs':
+                eng.select(None)
+                conn.send(('ok', None))
+            elif cmd == 'backup':
+                pol.copy_(_t.from_numpy(pol_h)); val.copy_(_t.from_numpy(val_h))
+                eng.backup(pol, val, row_of_slot if cfg['arena'] else None)
+                conn.send(('ok', None))
+            elif cmd == 'advance_begin':
+                fin = eng.advance_begin(record_history=arg)
+                idx = np.flatnonzero(fin)
+                states = [eng.get_states(int(i), 1)[0] for i in idx]
+                conn.send(('ok', (fin, states)))
+            elif cmd == 'advance_commit':
+                eng.advance_commit(arg)
+                c = eng.counters()
+                new = c['num_examples'] - n_ex
+                out = None
+                if new > 0:
+                    o, p, z = eng.examples(n_ex, new)
+                    out = (o.cpu().numpy(), p.cpu().numpy(), z.cpu().numpy())
+                n_ex = c['num_examples']
+                conn.send(('ok', out))
+            elif cmd == 'close':
+                conn.send(('ok', None))
+                break
+    except Exception:
+        try:
+            conn.send(('error', traceback.format_exc()))
+        except Exception:
+            pass
+
+
+
+
+def main():
+    from multiprocessing.connection import Client
+    conn = Client(sys.argv[1], family='AF_UNIX', authkey=bytes.fromhex(os.environ['AZG_WORKER_KEY']))
+    cfg = conn.recv()
+    engine_worker(conn, cfg)
+
+
+if __name__ == '__main__':
+    main()

@@ -273,10 +273,32 @@ extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
     EvPair p; prof_begin(e, s, 2, p);
     GAME_SWITCH(e, {
         hipLaunchKernelGGL((k_play<G>), dim3(e->v.B), dim3(64), 0, s, e->v, record_history);
-        hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v);
+        hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)nullptr);
         hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
     });
     prof_end(e, s, 2, p);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_advance_begin(azg_engine *e, void *stream, int record_history, int32_t *fin_host) {
+    if (!e || !fin_host) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_play<G>), dim3(e->v.B), dim3(64), 0, s, e->v, record_history));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(fin_host, e->v.fin_flag, sizeof(int32_t) * e->v.B, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+
+extern "C" int azg_advance_commit(azg_engine *e, void *stream, const int32_t *counted_host) {
+    if (!e || !counted_host) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(e->v.fin_counted, counted_host, sizeof(int32_t) * e->v.B, hipMemcpyHostToDevice, s));
+    GAME_SWITCH(e, {
+        hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)e->v.fin_counted);
+        hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
+    });
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }

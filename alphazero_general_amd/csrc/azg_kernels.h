@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
 
 // Phase 2 (one wave, slot order): result_queue order, the games_played cap (:179-183) and sample offsets.
 template <class G>
-__global__ __launch_bounds__(64) void k_finalize(View ev) {
+__global__ __launch_bounds__(64) void k_finalize(View ev, const int32_t *counted_in) {
     if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
     const int lane = threadIdx.x;
     const int nsym = ev.symmetric ? G::NSYM : 1;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void k_finalize(View ev) {
         const int s = s0 + lane;
         const int fin = s < ev.B ? (ev.fin_flag[s] != 0) : 0;
         const int rank = wave_excl_scan(fin, lane);
-        const int counted = fin && (gp + rank < ev.games_cap);
+        const int counted = counted_in ? (fin && counted_in[s] != 0) : (fin && (gp + rank < ev.games_cap));
         const int ns = (counted && !ev.arena) ? ev.hist_len[s] * nsym : 0;
         const int soff = wave_excl_scan(ns, lane);
         if (fin) { ev.fin_ridx[s] = nr + rank; ev.fin_counted[s] = counted; ev.fin_soff[s] = ne + soff; }

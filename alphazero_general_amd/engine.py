@@ -26,7 +26,7 @@ class DeviceEngine:
                  root_policy_temp=1.1, min_discount=1.0, add_root_noise=False, add_root_temp=False,
                  symmetric_samples=True, mcts_reset_threshold=0, games_per_iteration=1 << 30, start_temp=1.0,
                  arena_temp=0.25, temp_fn=default_temp_scaling, seed=0, slot_base=0, device=None,
-                 nodes_per_tree=0, example_capacity=0, result_capacity=0, sims_hint=100):
+                 nodes_per_tree=0, example_capacity=0, result_capacity=0, sims_hint=100, temp_table_override=None):
         self.L = _abi.lib()
         if not torch.cuda.is_available():
             raise RuntimeError('alphazero_general_amd needs a HIP device (no CPU fallback)')
@@ -37,7 +37,8 @@ class DeviceEngine:
         self.A, self.NV, self.P = gi.action_size, gi.num_players + 1, gi.num_players
         self.obs_shape = (gi.obs_c, gi.obs_h, gi.obs_w)
         self.O = gi.obs_c * gi.obs_h * gi.obs_w
-        self._tt = temp_table(temp_fn, start_temp, gi.max_turns)
+        self._tt = (np.ascontiguousarray(temp_table_override, np.float32) if temp_table_override is not None
+                    else temp_table(temp_fn, start_temp, gi.max_turns))
         if nodes_per_tree <= 0:
             # every simulation expands at most one node (<= max_children stubs); trees are kept for a whole game
             nodes_per_tree = gi.max_turns * max(int(sims_hint), 1) * gi.max_children + 64
@@ -141,6 +142,17 @@ class DeviceEngine:
 
     def advance(self, record_history=True):
         _abi.check(self.L.azg_advance(self.h, _stream(), int(bool(record_history))))
+
+    def advance_begin(self, record_history=True):
+        """playMoves up to the win test; returns fin[B] (winstate bits, 0 = still running).  Finished slots keep their
+        final state until advance_commit."""
+        fin = (C.c_int32 * self.B)()
+        _abi.check(self.L.azg_advance_begin(self.h, _stream(), int(bool(record_history)), fin))
+        return np.array(fin[:], np.int32)
+
+    def advance_commit(self, counted):
+        arr = (C.c_int32 * self.B)(*[int(bool(c)) for c in counted])
+        _abi.check(self.L.azg_advance_commit(self.h, _stream(), arr))
 
     # ---- root statistics --------------------------------------------------------------------------------
     def root_counts(self):

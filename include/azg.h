@@ -141,6 +141,14 @@ int  azg_backup(azg_engine *e, void *stream, const float *policy_dev, const floa
  * MCTS.update_root + GameState.play_action, end-of-game bookkeeping (results, samples x symmetries, reset).
  * record_history = not fast (:161). */
 int  azg_advance(azg_engine *e, void *stream, int record_history);
+/* The same in two steps, for callers that share one games_played counter between several agents
+ * (Coach with workers > 1: the `games_played < gamesPerIteration` test is made under the caller's lock, :179-183):
+ *   azg_advance_begin  plays the moves and reports which slots finished: fin_host[B] = winstate bits (0 = running);
+ *                      the finished slots still hold their final state (azg_get_states) until the commit.  blocking.
+ *   azg_advance_commit counted_host[B] != 0 marks the finished games that count: results for every finished game,
+ *                      samples + reset for the counted ones. */
+int  azg_advance_begin(azg_engine *e, void *stream, int record_history, int32_t *fin_host);
+int  azg_advance_commit(azg_engine *e, void *stream, const int32_t *counted_host);
 
 /* ---- single-tree API (MCTS.pyx public methods; slot-wise) ------------------------------------------------ */
 int  azg_root_counts(azg_engine *e, void *stream, int32_t *counts_dev /*[B, A]*/);                 /* MCTS.counts :297-303 */
