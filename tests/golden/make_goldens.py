@@ -138,7 +138,7 @@ def gen_tree(game_cls, game_id, name, n_roots, seed=7, configs=TREE_CONFIGS, max
             depth = np.zeros((n_roots, sims), np.int16)
             rootn = np.zeros((n_roots, sims, A), np.int16)
             rootq = np.zeros((n_roots, sims, A), np.float32)
-            kmax = 64 if A > 64 else A
+            kmax = 128 if A > 64 else A
             fin = {k: [] for k in ('a', 'n', 'q', 'p', 'v', 'counts', 'probs', 'vmax', 'vavg', 'root_n', 'maxdepth', 'ctr')}
             for r in range(n_roots):
                 g = game_cls()
@@ -272,8 +272,70 @@ def gen_agent(game_cls, game_id, name, configs=AGENT_CONFIGS, seed=99):
     np.savez_compressed(os.path.join(OUT, name + '_agent.npz'), **out)
 
 
+def br_game_cls():
+    """The reference's brandubh Game is a cdef class without has_draw()/max_turns(): the harness adds the
+    two static methods the callers need; nothing else is touched."""
+    from alphazero.envs.brandubh.fastafl import Game
+
+    class BGame(Game):
+        @staticmethod
+        def has_draw():
+            return True
+
+        @staticmethod
+        def max_turns():
+            return 100
+    return BGame
+
+
+def br_state(g):
+    return np.asarray(g._board._state, dtype=np.int8).reshape(-1), g.player, g.turns, int(g._board._king_captured)
+
+
+def gen_br_rules(n_games=60, seed=4321):
+    G = br_game_cls()
+    rng = np.random.RandomState(seed)
+    moves, lens, valid_bits, cells, ws, kc, obs_crc, obs_sample, sym_crc, max_k = [], [], [], [], [], [], [], [], [], 0
+    for gi in range(n_games):
+        g = G(); seq = []
+        while True:
+            v = np.asarray(g.valid_moves()); w = np.asarray(g.win_state())
+            c, pl, tu, k = br_state(g)
+            max_k = max(max_k, int(v.sum()))
+            valid_bits.append(np.packbits(v)); cells.append(c); ws.append(w.astype(np.uint8)); kc.append(k)
+            o = g.observation(); obs_crc.append(rh.crc(o))
+            if len(obs_sample) < 32:
+                obs_sample.append(o.copy())
+            m = np.full(101, -1, np.int16); m[:len(seq)] = seq
+            moves.append(m); lens.append(len(seq))
+            if len(seq) % 7 == 3:                      # symmetries on a subset of positions (slow in the reference)
+                pi = rng.rand(588).astype(np.float32) * v
+                sy = g.symmetries(pi)
+                sym_crc.append([len(moves) - 1] + [rh.crc(np.asarray(st._board._state, np.float32).astype(np.int8)) ^ rh.crc(p) for st, p in sy] + [rh.crc(pi)])
+            if w.any():
+                break
+            a = int(rng.choice(np.flatnonzero(v)))
+            g.play_action(a); seq.append(a)
+    np.savez_compressed(os.path.join(OUT, 'br_rules.npz'), moves=np.array(moves), lens=np.array(lens, np.int16),
+                        valid_bits=np.array(valid_bits), cells=np.array(cells), ws=np.array(ws), kc=np.array(kc, np.int8),
+                        obs_crc=np.array(obs_crc, np.uint32), obs_sample=np.array(obs_sample, np.float32),
+                        sym_crc=np.array(sym_crc, np.int64), sym_seed=np.int64(seed), max_k=np.int32(max_k))
+    print('br_rules: %d positions, max legal moves %d, %d symmetry checks' % (len(lens), max_k, len(sym_crc)))
+
+
+def gen_arena(game_cls, game_id, name, B=8, sims=12, games=10, seed=555):
+    """Arena-mode SelfPlayAgent traces (SelfPlayAgent.pyx:44-47,60-73,117-132,142-151,158,167-168).  The reference mis-routes
+    evaluations when games desynchronise; the trace records what the reference actually does."""
+    out = {}
+    o, args = run_ref_agent(game_cls, game_id, 'arena', B, sims, games, dict(), seed, slot_base=0, is_arena=True)
+    for k, v in o.items():
+        out['arena_' + k] = v
+    print('  %s/arena: rounds=%d results=%d games=%d p2i=%s' % (name, len(o['actions']), len(o['r_turns']), o['games_played'][-1], o['player_to_index']))
+    np.savez_compressed(os.path.join(OUT, name + '_arena.npz'), **out)
+
+
 def main():
-    which = sys.argv[1:] or ['c4_rules', 'c4_tree', 'c4_agent']
+    which = sys.argv[1:] or ['c4_rules', 'c4_tree', 'c4_agent', 'c4_arena']
     rh.import_reference()
     from alphazero.envs.connect4.connect4 import Game as C4
     if 'c4_rules' in which:
@@ -282,6 +344,16 @@ def main():
         gen_tree(C4, ol.GAME_CONNECT4, 'c4', n_roots=64)
     if 'c4_agent' in which:
         gen_agent(C4, ol.GAME_CONNECT4, 'c4')
+    if 'c4_arena' in which:
+        gen_arena(C4, ol.GAME_CONNECT4, 'c4')
+    if 'br_rules' in which:
+        gen_br_rules()
+    if 'br_tree' in which:
+        gen_tree(br_game_cls(), ol.GAME_BRANDUBH, 'br', n_roots=24, seed=11, max_prefix=40,
+                 configs=[('default', 1.25, 0.2, False, False, 80), ('noise_temp', 1.25, 0.2, True, True, 50)])
+    if 'br_agent' in which:
+        gen_agent(br_game_cls(), ol.GAME_BRANDUBH, 'br', seed=321,
+                  configs=[('plain', 6, 12, 4, dict()), ('noisy', 4, 10, 3, dict(add_root_noise=True, add_root_temp=True))])
 
 
 if __name__ == '__main__':

@@ -318,3 +318,59 @@ def test_mcts_class_api_vs_oracle(torch_mod):
         full = Game()
         m2 = MCTS(args)
         m2.update_root(full, 7)
+
+
+# ----------------------------------------------------------------------------------- arena mode (BASELINE config 4)
+def test_c4_arena_vs_oracle_live(torch_mod):
+    """Arena engine (one tree per player per game, rows grouped by model, correct row<->game routing) against the
+    oracle with ref_misroute off.  Until the first game ends all games are synchronised, where the reference's own
+    routing is correct too: that prefix is additionally pinned to the reference golden."""
+    torch = torch_mod
+    from alphazero_general_amd.utils import AGENT_STREAM
+    d = np.load(os.path.join(G, 'c4_arena.npz'))
+    B, sims, games, seed = int(d['arena_B']), int(d['arena_sims']), int(d['arena_games']), int(d['arena_seed'])
+    A, NV = 7, 3
+    ag = ol.OAgent(C4, B, sims=sims, games_per_iteration=games, seed=seed, is_arena=True, ref_misroute=False)
+    p2i = ag.player_to_index()
+    assert p2i == list(d['arena_player_to_index'])
+    eng = engine(B=B, arena=True, seed=seed, games_per_iteration=games, sims_hint=sims, arena_temp=0.25)
+    obs = eng.new_obs()
+    step, rnd = 0, 0
+    synced = True
+    while ag.games_played < games:
+        ag.begin_round()
+        for s in range(sims):
+            oobs, rg, rm = ag.generate_batch()
+            row_of_slot, rpm = eng.arena_rows(p2i)
+            eng.select(obs, row_of_slot)
+            assert (np.argsort(row_of_slot.cpu().numpy(), kind='stable') == rg).all()
+            assert (rpm.cpu().numpy() == np.bincount(rm, minlength=2)).all()
+            assert (obs.cpu().numpy() == oobs).all()
+            if synced:
+                assert [crc(oobs[i]) for i in range(B)] == list(d['arena_obs_crc'][step])
+            pol = np.zeros((B, A), np.float32); val = np.zeros((B, NV), np.float32)
+            for row in range(B):
+                pol[row], val[row] = ol.fake_eval(seed, rg[row], step, A, NV)
+            ag.process_batch(pol, val)
+            eng.backup(torch.from_numpy(pol).to(eng.device), torch.from_numpy(val).to(eng.device), row_of_slot)
+            step += 1
+        cnt = eng.root_counts().cpu().numpy()
+        for i in range(B):
+            ch = ag.root_children(i, ag.state(i).player)
+            c = np.zeros(A, np.int32); c[ch['a']] = ch['n']
+            assert (c == cnt[i]).all()
+        if synced:
+            assert (cnt == d['arena_counts'][rnd]).all()
+        ag.play_moves(); eng.advance(False)
+        assert (eng.last_actions().cpu().numpy() == ag.last_actions()).all()
+        if synced:
+            assert (ag.last_actions() == d['arena_actions'][rnd]).all()
+        if ag.games_played > 0:
+            synced = False
+        rnd += 1
+    c = eng.counters()
+    assert c['games_played'] == ag.games_played and c['num_examples'] == 0
+    ws, turns, slot = eng.results()
+    ows, oturns, oslot = ag.results()
+    assert (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all()
+    eng.close()
