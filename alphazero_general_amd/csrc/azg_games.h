@@ -114,4 +114,206 @@ struct C4 {
     static AZG_DEV int sym_action(int a, int k) { return k == 0 ? a : 6 - a; }
 };
 
+
+// ================================================================================================ brandubh
+// 7x7 tafl: alphazero/envs/brandubh/fastafl.pyx (Game) + fastafl/cengine.pyx (Board) + boardgame/board.pyx, board
+// options of variants.brandubh_args (king_two_sided_capture, move_over_throne, king cannot re-enter the throne).
+// The reference walks Python lists of Square objects; here lane i < 49 owns cell i = y*7+x (the Board._state value,
+// cengine.pyx:24-32) and everything is expressed on 49-bit wave ballots: sliding moves by per-lane ray walks over
+// the passable mask, custodian captures by uniform readlanes around the moved piece, the recursive group-surround
+// check (cengine.pyx:204-247) as a bitboard flood fill ("no member of the connected enemy group touches an empty
+// square"), win tests by neighbour masks.
+struct BR {
+    static constexpr int ID = AZG_GAME_BRANDUBH;
+    static constexpr int A = 588, H = 7, W = 7, CELLS = 49, P = 2, HAS_DRAW = 1, MAX_TURNS = 100, NSYM = 8;
+    static constexpr int OBS_C = 5, OBS = OBS_C * CELLS, MAXK = 128;
+    static constexpr uint64_t ALL = (1ULL << 49) - 1;
+    static constexpr uint64_t COL0 = 0x0040810204081ULL, COL6 = COL0 << 6;
+    struct S { int cell; int player, turns, kc; };
+
+    static AZG_DEV uint64_t nbr(uint64_t m) {       // squares orthogonally adjacent to the set m (board edges: nothing)
+        return ((m << 7) | (m >> 7) | ((m & ~COL6) << 1) | ((m & ~COL0) >> 1)) & ALL;
+    }
+    static AZG_DEV uint64_t mask_eq(const S &s, int lane, int v) { return __ballot(lane < CELLS && s.cell == v); }
+    static AZG_DEV bool is_king(int v) { return v == 3 || v == 7 || v == 8; }
+    static AZG_DEV bool is_att(int v) { return v == 1 || is_king(v); }                       // ATTACKERS cengine.pyx:42
+    static AZG_DEV int rd(const S &s, int idx) { return __builtin_amdgcn_readlane(s.cell, __builtin_amdgcn_readfirstlane(idx)); }
+
+    static AZG_DEV S load(const azg_state *st, int lane) {
+        S s;
+        s.cell = lane < CELLS ? (int)st->cells[lane] : 0;
+        s.player = __builtin_amdgcn_readfirstlane(st->player);
+        s.turns = __builtin_amdgcn_readfirstlane(st->turns);
+        s.kc = __builtin_amdgcn_readfirstlane(st->aux[0]);
+        return s;
+    }
+    static AZG_DEV void init(S &s) {                // fastafl/variants.py:13-19
+        const int lane = threadIdx.x & 63;
+        const int y = lane / 7, x = lane - y * 7;
+        int v = 0;
+        if (lane < CELLS) {
+            const bool corner = (x == 0 || x == 6) && (y == 0 || y == 6);
+            if (corner) v = 5;
+            else if (x == 3 && y == 3) v = 7;
+            else if ((x == 3 && (y == 2 || y == 4)) || (y == 3 && (x == 2 || x == 4))) v = 1;
+            else if ((x == 3 && (y <= 1 || y >= 5)) || (y == 3 && (x <= 1 || x >= 5))) v = 2;
+        }
+        s.cell = v; s.player = 0; s.turns = 0; s.kc = 0;
+    }
+    static AZG_DEV void store(const S &s, azg_state *st, int lane) {
+        st->cells[lane] = lane < CELLS ? (int8_t)s.cell : (int8_t)0;
+        if (lane == 0) { st->player = s.player; st->turns = s.turns; st->aux[0] = s.kc; st->aux[1] = 0; }
+    }
+    static AZG_DEV void decode(int a, int &src, int &dst) {          // fastafl.pyx:48-63 get_move
+        const int mt = a % 12; src = a / 12;
+        const int sx = src % 7, sy = src / 7;
+        int nx, ny;
+        if (mt < 6) { nx = sx; ny = mt + (mt >= sy ? 1 : 0); }
+        else { nx = mt - 6; nx += (nx >= sx ? 1 : 0); ny = sy; }
+        dst = ny * 7 + nx;
+    }
+    static AZG_DEV int encode(int x, int y, int nx, int ny) {        // fastafl.pyx:66-79 get_action
+        const int mt = x == nx ? (ny < y ? ny : ny - 1) : (nx < x ? 6 + nx : 6 + nx - 1);
+        return 12 * (x + y * 7) + mt;
+    }
+    // Board.move (cengine.pyx:249-272, no validity / win checks) + _check_capture (:172-197) + _check_surround (:228-247)
+    static AZG_DEV void play(S &s, int a) {
+        const int lane = threadIdx.x & 63;
+        a = __builtin_amdgcn_readfirstlane(a);
+        int src, dst; decode(a, src, dst);
+        const int srcv = rd(s, src), dstv = rd(s, dst);
+        const int piece = (srcv == 7 || srcv == 8) ? 3 : srcv;                               // remove_piece :311-326
+        const int newsrc = srcv == 7 ? 4 : srcv == 8 ? 5 : 0;
+        const int newdst = (dstv == 4 || dstv == 5) ? piece + dstv : piece;                  // add_piece :293-309
+        if (lane == src) s.cell = newsrc;
+        if (lane == dst) s.cell = newdst;
+        const int dx4[4] = {0, 1, 0, -1}, dy4[4] = {1, 0, -1, 0};                            // DIRECTIONS :46
+        const int mx = dst % 7, my = dst / 7;
+        // ---- custodian capture around the moved piece ----
+        const bool friendly_att = is_att(newdst);
+        const int enemy = newdst != 3 ? 3 - newdst : 2;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int ex = mx + dx4[d], ey = my + dy4[d];
+            if (ex < 0 || ex > 6 || ey < 0 || ey > 6) continue;
+            const int ev = rd(s, ey * 7 + ex);
+            const bool do_capture = ev == 3;                                                 // two-sided king capture (Q20)
+            if (ev == enemy || do_capture) {
+                const int fx = ex + dx4[d], fy = ey + dy4[d];
+                if (fx < 0 || fx > 6 || fy < 0 || fy > 6) continue;
+                const int fv = rd(s, fy * 7 + fx);
+                const bool friendly = friendly_att ? is_att(fv) : fv == newdst;
+                if (friendly || fv == 4 || fv == 5) {
+                    if (do_capture) s.kc = 1;
+                    else if (lane == ey * 7 + ex) s.cell = 0;
+                }
+            }
+        }
+        // ---- group surround: start squares in DIRECTIONS order, removals visible to the later ones ----
+        const bool enemy_is_att = rd(s, dst) == 2;
+        uint64_t checked = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int ex = mx + dx4[d], ey = my + dy4[d];
+            if (ex < 0 || ex > 6 || ey < 0 || ey > 6) continue;
+            const int e = ey * 7 + ex;
+            const uint64_t enemyM = enemy_is_att ? __ballot(lane < CELLS && is_att(s.cell)) : mask_eq(s, lane, 2);
+            if (!((enemyM >> e) & 1) || ((checked >> e) & 1)) continue;
+            uint64_t g = 1ULL << e;
+            for (;;) { const uint64_t g2 = g | (nbr(g) & enemyM); if (g2 == g) break; g = g2; }
+            checked |= g;
+            const uint64_t empty = mask_eq(s, lane, 0);
+            if ((nbr(g) & empty) == 0) {                                                     // every member fully blocked
+                const uint64_t kings = __ballot(lane < CELLS && is_king(s.cell));
+                if (g & kings) s.kc = 1;                                                     // a king is never lifted (:243-244)
+                if (lane < CELLS && ((g >> lane) & 1) && !is_king(s.cell)) s.cell = 0;
+            }
+        }
+        s.turns += 1; s.player ^= 1;
+    }
+    // Game.win_state (fastafl.pyx:186-199) + Board.get_winner (cengine.pyx:163-169) + _has_legals_check (:134-141)
+    static AZG_DEV int win_bits(const S &s) {
+        const int lane = threadIdx.x & 63;
+        if (s.turns >= 100) return 4;
+        const uint64_t esc = mask_eq(s, lane, 8);
+        const uint64_t adjE = nbr(mask_eq(s, lane, 0)), adjX = nbr(mask_eq(s, lane, 5));
+        const uint64_t kings = __ballot(lane < CELLS && is_king(s.cell));
+        const bool def_has = (mask_eq(s, lane, 2) & adjE) != 0;
+        const bool att_has = ((mask_eq(s, lane, 1) & adjE) | (kings & (adjE | adjX))) != 0;
+        if (esc != 0 || !def_has) return 2;           // attackers (player 1) win: result[2 - 1]
+        if (s.kc || !att_has) return 1;               // defenders (player 0) win: result[2 - 2]
+        return 0;
+    }
+    // Game.valid_moves (fastafl.pyx:171-178) + Board.legal_moves (cengine.pyx:109-132): ascending action list in LDS
+    static AZG_DEV int valid_list(const S &s, int lane, int *act_lds, int (&my_a)[2]) {
+        const int team = 2 - (s.turns & 1);                                                  // Board.to_play :330-331
+        const bool mine = lane < CELLS && (team == 1 ? is_att(s.cell) : s.cell == 2);
+        const bool king = is_king(s.cell);
+        const uint64_t E = mask_eq(s, lane, 0), T = mask_eq(s, lane, 4), X = mask_eq(s, lane, 5);
+        const uint64_t pass = E | T | (king ? X : 0ULL);                                      // the ray continues over these
+        const int x = lane % 7, y = lane / 7;
+        unsigned mv = 0;                                                                     // bit = move_type (0..11)
+        if (mine) {
+            for (int ny = y + 1; ny <= 6; ny++) { const int t = ny * 7 + x; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << (ny - 1); }
+            for (int ny = y - 1; ny >= 0; ny--) { const int t = ny * 7 + x; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << ny; }
+            for (int nx = x + 1; nx <= 6; nx++) { const int t = y * 7 + nx; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << (6 + nx - 1); }
+            for (int nx = x - 1; nx >= 0; nx--) { const int t = y * 7 + nx; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << (6 + nx); }
+        }
+        const int cnt = __popc(mv);
+        const int off = wave_excl_scan(cnt, lane);
+        const int k = wave_sum_i(cnt);
+        __syncthreads();
+        int j = 0;
+        for (unsigned m = mv; m; m &= m - 1) { if (off + j < MAXK) act_lds[off + j] = 12 * lane + (__ffs(m) - 1); j++; }
+        __syncthreads();
+        my_a[0] = lane < k ? act_lds[lane] : -1;
+        my_a[1] = 64 + lane < k ? act_lds[64 + lane] : -1;
+        return k < MAXK ? k : MAXK;
+    }
+    // Game.observation (fastafl.pyx:84-121,205-211): planes [black(2), white(1), king, to-move colour, 0] (Q18)
+    template <typename OT> static AZG_DEV void write_obs(const S &s, OT *out, int lane) {
+        const float colour = (float)(s.turns & 1), turn_no = (float)(s.turns / 100);
+        for (int e0 = 0; e0 < OBS; e0 += 64) {
+            const int e = e0 + lane;
+            const int plane = e / CELLS, i = e - plane * CELLS;
+            const int c = __shfl(s.cell, i < CELLS ? i : 0);
+            if (e < OBS) {
+                const float v = plane == 0 ? (c == 2 ? 1.f : 0.f) : plane == 1 ? (c == 1 ? 1.f : 0.f)
+                              : plane == 2 ? (is_king(c) ? 1.f : 0.f) : plane == 3 ? colour : turn_no;
+                out[e] = (OT)v;
+            }
+        }
+    }
+    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
+        if (lane < CELLS) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const int c = s.cell;
+            h8 v = {(_Float16)(c == 2 ? 1.f : 0.f), (_Float16)(c == 1 ? 1.f : 0.f), (_Float16)(is_king(c) ? 1.f : 0.f),
+                    (_Float16)(float)(s.turns & 1), (_Float16)(float)(s.turns / 100), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            *reinterpret_cast<h8 *>(out + lane * 8) = v;
+        }
+    }
+    // Game.symmetries (fastafl.pyx:213-256): k = (i-1)*2 + flip; state = fliplr^flip(rot90^i(state)); the policy index is
+    // permuted by the reference's own coordinate loop (sym_action)
+    static AZG_DEV S symmetry(const S &s, int k) {
+        const int lane = threadIdx.x & 63;
+        const int i = k / 2 + 1, flip = k & 1;
+        int r = lane / 7, c = lane - (lane / 7) * 7;
+        if (flip) c = 6 - c;                              // final[r][c] = rotated[r][6-c]
+        for (int t = 0; t < i; t++) { const int nr = c, nc = 6 - r; r = nr; c = nc; }       // rot90: new[r][c] = old[c][6-r]
+        S o = s;
+        const int v = __shfl(s.cell, lane < CELLS ? r * 7 + c : 0);
+        o.cell = lane < CELLS ? v : 0;
+        return o;
+    }
+    static AZG_DEV int sym_action(int a, int k) {
+        const int i = k / 2 + 1, flip = k & 1;
+        int src, dst; decode(a, src, dst);
+        int x = src % 7, y = src / 7, nx = dst % 7, ny = dst / 7;
+        for (int t = 0; t < i; t++) { const int tx = x, tnx = nx; x = 6 - y; nx = 6 - ny; y = tx; ny = tnx; }   // :241-246
+        if (flip) { x = 6 - x; nx = 6 - nx; }
+        return encode(x, y, nx, ny);
+    }
+};
+
 }  // namespace azg

@@ -81,24 +81,32 @@ class DeviceEngine:
     def set_states(self, states, first=0, reset_trees=True):
         """states: list of (cells int8 array, player, turns)"""
         arr = _abi.states_array(len(states))
-        for s, (cells, player, turns) in zip(arr, states):
+        for s, st in zip(arr, states):
+            cells, player, turns = st[0], st[1], st[2]
             c = np.asarray(cells, np.int8).reshape(-1)
             for i, v in enumerate(c):
                 s.cells[i] = int(v)
             s.player, s.turns = int(player), int(turns)
+            s.aux[0] = int(st[3]) if len(st) > 3 else 0
         _abi.check(self.L.azg_set_states(self.h, _stream(), first, len(states), arr, int(reset_trees)))
 
-    def _get(self, fn, first, count):
+    def _get(self, fn, first, count, full=False):
         count = self.B - first if count is None else count
         arr = _abi.states_array(count)
         _abi.check(fn(self.h, _stream(), first, count, arr))
+        if full:
+            return [(_abi.state_to_np(s, self.gi.cells), s.player, s.turns, s.aux[0]) for s in arr]
         return [(_abi.state_to_np(s, self.gi.cells), s.player, s.turns) for s in arr]
 
     def get_states(self, first=0, count=None):
         return self._get(self.L.azg_get_states, first, count)
 
-    def get_leaf_states(self, first=0, count=None):
-        return self._get(self.L.azg_get_leaf_states, first, count)
+    def get_leaf_states(self, first=0, count=None, full=False):
+        """full=True adds the game-specific word aux[0] (brandubh: Board._king_captured) as a 4th element."""
+        return self._get(self.L.azg_get_leaf_states, first, count, full)
+
+    def get_states_full(self, first=0, count=None):
+        return self._get(self.L.azg_get_states, first, count, True)
 
     def tape_counters(self):
         out = (C.c_uint64 * self.B)()

@@ -374,3 +374,130 @@ def test_c4_arena_vs_oracle_live(torch_mod):
     ows, oturns, oslot = ag.results()
     assert (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all()
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ brandubh (config 3)
+BR = 1
+
+
+def _br_positions(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        g = ol.OGame(BR)
+        L = rng.randint(0, 70)
+        for _ in range(L):
+            if g.win_state().any():
+                break
+            v = np.flatnonzero(g.valid_moves())
+            g.play(int(rng.choice(v)))
+        out.append(g)
+    return out
+
+
+def test_br_rules_fuzz(torch_mod):
+    """Device rule kernels against the oracle on random playout positions: expanding a root exposes valid_moves, win_state
+    and observation; the second simulation descends one ply and exposes play_action (captures, surround, king flags)."""
+    torch = torch_mod
+    N = 1536
+    pos = _br_positions(N, 5)
+    eng = engine(game=BR, B=N, seed=3, sims_hint=4)
+    eng.set_states([(g.cells(), g.player, g.turns, g.s.aux[0]) for g in pos])
+    obs = eng.new_obs()
+    eng.select(obs)
+    o = obs.cpu().numpy()
+    uni_p = torch.full((N, 588), 1 / 588, device=eng.device); uni_v = torch.full((N, 3), 1 / 3, device=eng.device)
+    for i, g in enumerate(pos):
+        ch = eng.root_children(i)
+        assert (np.sort(ch['a']) == np.flatnonzero(g.valid_moves())).all(), i
+        ws = g.win_state()
+        assert eng.tree_info(i)['e'] == int(ws[0]) + 2 * int(ws[1]) + 4 * int(ws[2]), i
+        assert (o[i] == g.observation()).all(), i
+    eng.backup(uni_p, uni_v)
+    eng.select(obs)
+    o = obs.cpu().numpy()
+    leaves = eng.get_leaf_states(full=True)
+    for i, g in enumerate(pos):
+        path = eng.last_path(i)
+        h = g.clone()
+        if g.win_state().any():
+            assert len(path) == 0
+        else:
+            assert len(path) == 1
+            h.play(int(path[0]))
+        cells, player, turns, kc = leaves[i]
+        assert (cells == h.cells()).all() and player == h.player and turns == h.turns and kc == h.s.aux[0], i
+        assert (o[i] == h.observation()).all(), i
+    eng.counters()
+    eng.close()
+
+
+@pytest.mark.parametrize('cname', ['default', 'noise_temp'])
+def test_br_tree_vs_reference_goldens(torch_mod, cname):
+    torch = torch_mod
+    d = np.load(os.path.join(G, 'br_tree.npz'))
+    cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
+    noise, temp, sims = bool(noise), bool(temp), int(sims)
+    seed = int(d[cname + '_seed'])
+    R, A, NV = d['prefix'].shape[0], 588, 3
+    exact = not temp
+    eng = engine(game=BR, B=R, cpuct=cpuct, fpu_reduction=fpu, add_root_noise=noise, add_root_temp=temp, seed=seed, sims_hint=sims)
+    states = []
+    for r in range(R):
+        g = ol.OGame(BR)
+        for a in d['prefix'][r]:
+            if a >= 0:
+                g.play(a)
+        states.append((g.cells(), g.player, g.turns, g.s.aux[0]))
+    eng.set_states(states)
+    obs = eng.new_obs()
+    for s in range(sims):
+        eng.select(obs)
+        for r in range(0, R, 5):
+            path = eng.last_path(r)
+            assert len(path) == d[cname + '_depth'][r, s]
+            assert (path[:24] == d[cname + '_paths'][r, s][:len(path)]).all(), (r, s)
+        pol, val = fake_batch(torch, seed, range(R), s, A, NV, eng.device)
+        eng.backup(pol, val)
+        cnt = eng.root_counts().cpu().numpy()
+        assert (cnt == d[cname + '_rootn'][:, s]).all(), s
+    for r in range(R):
+        ch = eng.root_children(r)
+        k = len(ch['a'])
+        assert (ch['a'] == d[cname + '_a'][r][:k]).all() and (ch['n'] == d[cname + '_n'][r][:k]).all()
+        for f in ('q', 'p', 'v'):
+            if exact:
+                assert (ch[f] == d[cname + '_' + f][r][:k]).all(), (f, r)
+            else:
+                assert np.allclose(ch[f], d[cname + '_' + f][r][:k], atol=1e-5), (f, r)
+    for ti, t in enumerate(d['prob_temps']):
+        pr = eng.root_probs(float(t)).cpu().numpy()
+        ref = d[cname + '_probs'][:, ti]
+        if t in (1.0, 0.5, 0.0):
+            assert (pr == ref).all(), t                 # exercises the numpy pairwise-sum plan for A = 588
+        else:
+            assert np.allclose(pr, ref, rtol=3e-7, atol=1e-12), t
+    assert (eng.root_value(False).cpu().numpy() == d[cname + '_vmax']).all()
+    assert (eng.root_value(True).cpu().numpy() == d[cname + '_vavg']).all()
+    assert (eng.tape_counters() == d[cname + '_ctr']).all()
+    eng.close()
+
+
+@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
+def test_br_agent_vs_reference_goldens(torch_mod, cname, kw):
+    torch = torch_mod
+    d = np.load(os.path.join(G, 'br_agent.npz'))
+    B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
+    seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
+    eng = engine(game=BR, B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=20000, sims_hint=sims, **kw)
+    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games)
+    assert (np.array(rec['counts']) == d[cname + '_counts']).all()
+    assert (np.array(rec['actions']) == d[cname + '_actions']).all()
+    assert (np.array(rec['games_played']) == d[cname + '_games_played']).all()
+    assert (np.array(rec['obs_crc'], np.uint32) == d[cname + '_obs_crc']).all()
+    obs, pi, z = [t.cpu().numpy() for t in eng.examples()]
+    assert obs.shape == d[cname + '_s_obs'].shape
+    assert (obs == d[cname + '_s_obs']).all() and (pi == d[cname + '_s_pi']).all() and (z == d[cname + '_s_z']).all()
+    ws, turns, slot = eng.results()
+    assert (ws == d[cname + '_r_ws']).all() and (turns == d[cname + '_r_turns']).all()
+    eng.close()
