@@ -34,8 +34,9 @@ static const azg_game_info k_info[] = {
     // action_size, c,h,w, players, has_draw, max_turns, nsym, cells, max_children
     {C4::A, C4::OBS_C, C4::H, C4::W, C4::P, C4::HAS_DRAW, C4::MAX_TURNS, C4::NSYM, C4::CELLS, C4::MAXK},
     {BR::A, BR::OBS_C, BR::H, BR::W, BR::P, BR::HAS_DRAW, BR::MAX_TURNS, BR::NSYM, BR::CELLS, BR::MAXK},
+    {TM::A, TM::OBS_C, TM::H, TM::W, TM::P, TM::HAS_DRAW, TM::MAX_TURNS, TM::NSYM, TM::CELLS, TM::MAXK},
 };
-static const int k_num_games = 2;
+static const int k_num_games = 3;
 
 extern "C" int azg_abi_version(void) { return AZG_ABI_VERSION; }
 extern "C" const char *azg_last_error(void) { return g_err.c_str(); }
@@ -83,6 +84,7 @@ template <typename T> static int dalloc(azg_engine *e, T **p, size_t count) {
     switch ((e)->cfg.game) { \
     case AZG_GAME_CONNECT4: { using G = C4; CALL; } break; \
     case AZG_GAME_BRANDUBH: { using G = BR; CALL; } break; \
+    case AZG_GAME_TRIMOK: { using G = TM; CALL; } break; \
     default: return fail(AZG_E_UNSUPPORTED, "game has no device rules"); }
 
 static void prof_begin(azg_engine *e, hipStream_t s, int fam, EvPair &p) {

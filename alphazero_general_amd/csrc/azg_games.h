@@ -316,4 +316,81 @@ struct BR {
     }
 };
 
+
+// ================================================================================================ trimok (3 players)
+// Build-defined N-player env (BASELINE config 5; rules in alphazero_general_amd/envs/trimok.py): 5x5 board, three players
+// place stones in turn, three in a row wins, full board draws.  One 25-bit bitboard per player in SGPRs.
+struct TM {
+    static constexpr int ID = AZG_GAME_TRIMOK;
+    static constexpr int A = 25, H = 5, W = 5, CELLS = 25, P = 3, HAS_DRAW = 1, MAX_TURNS = 25, NSYM = 1;
+    static constexpr int OBS_C = 5, OBS = OBS_C * CELLS, MAXK = 25;
+    struct S { uint32_t b[3]; int player, turns; };
+    static AZG_DEV S load(const azg_state *st, int lane) {
+        const int8_t v = lane < CELLS ? st->cells[lane] : (int8_t)0;
+        S s;
+        s.b[0] = (uint32_t)__ballot(v == 1); s.b[1] = (uint32_t)__ballot(v == 2); s.b[2] = (uint32_t)__ballot(v == 3);
+        s.player = __builtin_amdgcn_readfirstlane(st->player);
+        s.turns = __builtin_amdgcn_readfirstlane(st->turns);
+        return s;
+    }
+    static AZG_DEV void init(S &s) { s.b[0] = s.b[1] = s.b[2] = 0; s.player = 0; s.turns = 0; }
+    static AZG_DEV int cell(const S &s, int i) { return (int)((s.b[0] >> i) & 1) + 2 * (int)((s.b[1] >> i) & 1) + 3 * (int)((s.b[2] >> i) & 1); }
+    static AZG_DEV void store(const S &s, azg_state *st, int lane) {
+        st->cells[lane] = lane < CELLS ? (int8_t)cell(s, lane) : (int8_t)0;
+        if (lane == 0) { st->player = s.player; st->turns = s.turns; st->aux[0] = 0; st->aux[1] = 0; }
+    }
+    static AZG_DEV void play(S &s, int a) {
+        const uint32_t bit = 1u << a;
+        if (s.player == 0) s.b[0] |= bit; else if (s.player == 1) s.b[1] |= bit; else s.b[2] |= bit;
+        s.player = s.player == 2 ? 0 : s.player + 1; s.turns += 1;          // Game.py:73-79 (player + 1) % num_players
+    }
+    static AZG_DEV bool has3(uint32_t m) {
+        constexpr uint32_t XLE2 = 0x00739CE7u;                               // cells with x <= 2 (line start, going right)
+        constexpr uint32_t XGE2 = 0x01CE739Cu;                               // cells with x >= 2 (anti-diagonal start)
+        if (m & (m >> 1) & (m >> 2) & XLE2) return true;                     // horizontal
+        if (m & (m >> 5) & (m >> 10)) return true;                           // vertical
+        if (m & (m >> 6) & (m >> 12) & XLE2) return true;                    // diagonal  (+1, +1)
+        if (m & (m >> 4) & (m >> 8) & XGE2) return true;                     // diagonal  (-1, +1)
+        return false;
+    }
+    static AZG_DEV int win_bits(const S &s) {
+        if (has3(s.b[0])) return 1;
+        if (has3(s.b[1])) return 2;
+        if (has3(s.b[2])) return 4;
+        if ((s.b[0] | s.b[1] | s.b[2]) == 0x1FFFFFFu) return 8;
+        return 0;
+    }
+    static AZG_DEV int valid_list(const S &s, int lane, int *act_lds, int (&my_a)[1]) {
+        const uint32_t vm = ~(s.b[0] | s.b[1] | s.b[2]) & 0x1FFFFFFu;
+        const int k = __popc(vm);
+        // lane i takes the i-th set bit: select by rank
+        int a = -1;
+        if (lane < k) { uint32_t m = vm; for (int i = 0; i < lane; i++) m &= m - 1; a = __ffs(m) - 1; }
+        my_a[0] = a; (void)act_lds;
+        return k;
+    }
+    template <typename OT> static AZG_DEV void write_obs(const S &s, OT *out, int lane) {
+        const float turn = (float)((double)s.turns / 25.0);
+#pragma unroll
+        for (int e0 = 0; e0 < OBS; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < OBS) {
+                const int plane = e / CELLS, i = e - plane * CELLS;
+                const float v = plane < 3 ? (float)((s.b[plane == 0 ? 0 : plane == 1 ? 1 : 2] >> i) & 1) : plane == 3 ? (float)s.player : turn;
+                out[e] = (OT)v;
+            }
+        }
+    }
+    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
+        if (lane < CELLS) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 v = {(_Float16)(float)((s.b[0] >> lane) & 1), (_Float16)(float)((s.b[1] >> lane) & 1), (_Float16)(float)((s.b[2] >> lane) & 1),
+                    (_Float16)(float)s.player, (_Float16)(float)((double)s.turns / 25.0), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            *reinterpret_cast<h8 *>(out + lane * 8) = v;
+        }
+    }
+    static AZG_DEV S symmetry(const S &s, int k) { (void)k; return s; }
+    static AZG_DEV int sym_action(int a, int k) { (void)k; return a; }
+};
+
 }  // namespace azg

@@ -351,6 +351,15 @@ def main():
     if 'br_tree' in which:
         gen_tree(br_game_cls(), ol.GAME_BRANDUBH, 'br', n_roots=24, seed=11, max_prefix=40,
                  configs=[('default', 1.25, 0.2, False, False, 80), ('noise_temp', 1.25, 0.2, True, True, 50)])
+    if 'tm_tree' in which or 'tm_agent' in which:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+        from alphazero_general_amd.envs.trimok import Game as TM       # the rules statement; searched by the REFERENCE MCTS
+    if 'tm_tree' in which:
+        gen_tree(TM, ol.GAME_TRIMOK, 'tm', n_roots=32, seed=23, max_prefix=12,
+                 configs=[('default', 1.25, 0.2, False, False, 60), ('noise_temp', 2.0, 0.3, True, True, 40)])
+    if 'tm_agent' in which:
+        gen_agent(TM, ol.GAME_TRIMOK, 'tm', seed=777,
+                  configs=[('plain', 8, 15, 12, dict()), ('noisy', 6, 10, 8, dict(add_root_noise=True, add_root_temp=True))])
     if 'br_agent' in which:
         gen_agent(br_game_cls(), ol.GAME_BRANDUBH, 'br', seed=321,
                   configs=[('plain', 6, 12, 4, dict()), ('noisy', 4, 10, 3, dict(add_root_noise=True, add_root_temp=True))])

@@ -501,3 +501,65 @@ def test_br_agent_vs_reference_goldens(torch_mod, cname, kw):
     ws, turns, slot = eng.results()
     assert (ws == d[cname + '_r_ws']).all() and (turns == d[cname + '_r_turns']).all()
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ trimok, 3 players (config 5)
+TM = 2
+
+
+@pytest.mark.parametrize('cname', ['default', 'noise_temp'])
+def test_tm_tree_vs_reference_goldens(torch_mod, cname):
+    torch = torch_mod
+    d = np.load(os.path.join(G, 'tm_tree.npz'))
+    cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
+    noise, temp, sims = bool(noise), bool(temp), int(sims)
+    seed = int(d[cname + '_seed'])
+    R, A, NV = d['prefix'].shape[0], 25, 4
+    exact = not temp
+    eng = engine(game=TM, B=R, cpuct=cpuct, fpu_reduction=fpu, add_root_noise=noise, add_root_temp=temp, seed=seed, sims_hint=sims)
+    states = []
+    for r in range(R):
+        g = ol.OGame(TM)
+        for a in d['prefix'][r]:
+            if a >= 0:
+                g.play(a)
+        states.append(ostate(g))
+    eng.set_states(states)
+    obs = eng.new_obs()
+    for s in range(sims):
+        eng.select(obs)
+        pol, val = fake_batch(torch, seed, range(R), s, A, NV, eng.device)
+        eng.backup(pol, val)
+        assert (eng.root_counts().cpu().numpy() == d[cname + '_rootn'][:, s]).all(), s
+    for r in range(R):
+        ch = eng.root_children(r)
+        k = len(ch['a'])
+        assert (ch['a'] == d[cname + '_a'][r][:k]).all() and (ch['n'] == d[cname + '_n'][r][:k]).all()
+        for f in ('q', 'p', 'v'):
+            if exact:
+                assert (ch[f] == d[cname + '_' + f][r][:k]).all(), (f, r)
+            else:
+                assert np.allclose(ch[f], d[cname + '_' + f][r][:k], atol=1e-5), (f, r)
+    assert (eng.root_probs(1.0).cpu().numpy() == d[cname + '_probs'][:, 0]).all()
+    assert (eng.root_value(False).cpu().numpy() == d[cname + '_vmax']).all()
+    assert (eng.tape_counters() == d[cname + '_ctr']).all()
+    eng.close()
+
+
+@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
+def test_tm_agent_vs_reference_goldens(torch_mod, cname, kw):
+    torch = torch_mod
+    d = np.load(os.path.join(G, 'tm_agent.npz'))
+    B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
+    seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
+    eng = engine(game=TM, B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=8000, sims_hint=sims, **kw)
+    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games)
+    assert (np.array(rec['counts']) == d[cname + '_counts']).all()
+    assert (np.array(rec['actions']) == d[cname + '_actions']).all()
+    assert (np.array(rec['games_played']) == d[cname + '_games_played']).all()
+    assert (np.array(rec['obs_crc'], np.uint32) == d[cname + '_obs_crc']).all()
+    obs, pi, z = [t.cpu().numpy() for t in eng.examples()]
+    assert (obs == d[cname + '_s_obs']).all() and (pi == d[cname + '_s_pi']).all() and (z == d[cname + '_s_z']).all()
+    ws, turns, slot = eng.results()
+    assert (ws == d[cname + '_r_ws']).all() and (turns == d[cname + '_r_turns']).all()
+    eng.close()
