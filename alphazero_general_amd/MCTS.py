@@ -29,11 +29,14 @@ def encode_state(gs):
     raise NotImplementedError('cannot encode %r for the device engine' % type(gs))
 
 
-def decode_state(template, cells, player, turns):
+def decode_state(template, cells, player, turns, aux0=0):
     """Build a GameState of template's class from an azg_state."""
     cls = type(template)
     if hasattr(cls, 'from_azg_state'):
-        return cls.from_azg_state(cells, player, turns)
+        try:
+            return cls.from_azg_state(cells, player, turns, aux0)
+        except TypeError:
+            return cls.from_azg_state(cells, player, turns)
     g = template.clone()
     g._board.pieces = np.asarray(cells, np.intc).reshape(np.asarray(template._board.pieces).shape).copy()
     g._player, g._turns = int(player), int(turns)
@@ -127,10 +130,10 @@ class MCTS:
         e = self._ensure(gs)
         self._sync_root_state(gs)
         e.select(None)
-        cells, player, turns = e.get_leaf_states(0, 1)[0]
+        st = e.get_leaf_states(0, 1, full=True)[0]
         info = e.tree_info(0)
         self.depth, self.max_depth = info['depth'], info['max_depth']
-        return decode_state(gs, cells, player, turns)
+        return decode_state(gs, *st)
 
     def process_results(self, gs, value, pi, add_root_noise, add_root_temp):   # MCTS.pyx:230-289
         e = self._engine

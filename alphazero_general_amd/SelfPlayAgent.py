@@ -205,8 +205,7 @@ class SelfPlayAgent(mp.Process):
         for k, i in enumerate(idx):
             ws = np.array([(int(fin[i]) >> j) & 1 for j in range(NV)], dtype=np.uint8)
             winstates[int(i)] = ws
-            cells, player, turns = states[k]
-            self.result_queue.put((decode_state(template, cells, player, turns), ws, self.id))      # :178
+            self.result_queue.put((decode_state(template, *states[k]), ws, self.id))                 # :178
             lock = self.games_played.get_lock()
             lock.acquire()
             if self.games_played.value < self.args.gamesPerIteration:                                # :181-183

@@ -49,7 +49,7 @@ def engine_worker(conn, cfg):
             elif cmd == 'advance_begin':
                 fin = eng.advance_begin(record_history=arg)
                 idx = np.flatnonzero(fin)
-                states = [eng.get_states(int(i), 1)[0] for i in idx]
+                states = [eng.get_states_full(int(i), 1)[0] for i in idx]
                 conn.send(('ok', (fin, states)))
             elif cmd == 'advance_commit':
                 eng.advance_commit(arg)
