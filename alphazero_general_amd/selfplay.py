@@ -168,3 +168,80 @@ class SelfPlayRunner:
         Bl = self.B // self.pipelines
         return (np.concatenate([r[0] for r in rs]), np.concatenate([r[1] for r in rs]),
                 np.concatenate([r[2] + i * Bl for i, r in enumerate(rs)]))
+
+
+class ArenaRunner:
+    """Native batched Arena (BASELINE config 4): the replacement of the batched branch of Arena.play_games
+    (alphazero/Arena.pyx:208-328) + the arena mode of SelfPlayAgent (SelfPlayAgent.pyx:44-47,60-73,117-132,142-151,158,
+    167-168).  One engine with one tree per player per game; every simulation the leaf rows are grouped by model
+    (player_to_index[mover]), each model evaluates its own contiguous slice, and the results are routed back with the
+    correct row <-> game map (the reference's mis-routing, SURVEY.md Q15, is not reproduced).  Returns the
+    (wins, draws, winrates) contract of Arena.play_games (:376) via get_game_results semantics (utils.py:34-54)."""
+
+    def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None):
+        self.game_cls, self.nnets, self.args = game_cls, list(nnets), args
+        self.game = azg_game_id(game_cls)
+        self.B = int(num_slots)
+        P = game_cls.num_players()
+        assert len(self.nnets) == P
+        self.seed, self.slot_base = int(seed), int(slot_base)
+        # seat permutation, one per agent, drawn from the agent-level tape stream (SelfPlayAgent.pyx:44-47)
+        import ctypes as C
+        pos = (C.c_int32 * P)()
+        _abi.lib().azg_tape_shuffle_pos(self.seed, AGENT_STREAM + self.slot_base, 0, P, pos)
+        self.player_to_index = [0] * P
+        for i in range(P):
+            self.player_to_index[pos[i]] = i
+        self.engine = DeviceEngine(self.game, self.B, arena=True, cpuct=args.get('cpuct', 1.25),
+                                   fpu_reduction=args.get('fpu_reduction', 0.2), arena_temp=args.get('arenaTemp', 0.25),
+                                   games_per_iteration=int(args.get('gamesPerIteration', 1 << 30)), seed=seed,
+                                   slot_base=slot_base, device=device, sims_hint=int(args.get('numMCTSSims', 100)))
+        e = self.engine
+        hip = all(getattr(n, '_hip', None) is not None or (n.refresh() and n._hip is not None) for n in self.nnets)
+        self.nhwc8 = bool(hip)
+        self.obs = (torch.zeros((self.B, e.gi.obs_h * e.gi.obs_w, 8), dtype=torch.float16, device=e.device) if self.nhwc8
+                    else e.new_obs(torch.float16))
+        self.policy = torch.zeros((self.B, e.A), dtype=torch.float32, device=e.device)
+        self.value = torch.zeros((self.B, e.NV), dtype=torch.float32, device=e.device)
+
+    def step(self):
+        e = self.engine
+        row_of_slot, rpm = e.arena_rows(self.player_to_index)
+        e.select(self.obs, row_of_slot)
+        counts = rpm.cpu().tolist()                                  # the one host read per simulation (batch split)
+        off = 0
+        for mi, n in enumerate(counts):
+            if n:
+                x = self.obs[off:off + n]
+                p, v = (self.nnets[mi]._hip.forward_nhwc8(x, key=100 + mi) if self.nhwc8 else self.nnets[mi].process(x))
+                self.policy[off:off + n] = p; self.value[off:off + n] = v
+            off += n
+        e.backup(self.policy, self.value, row_of_slot)
+
+    def play_round(self):
+        for _ in range(int(self.args.get('numMCTSSims', 100))):
+            self.step()
+        self.engine.advance(record_history=False)
+
+    def run(self, games=None):
+        games = int(self.args.get('gamesPerIteration') if games is None else games)
+        while True:
+            self.play_round()
+            c = self.engine.counters()
+            if c['games_played'] >= games:
+                return c
+
+    def results(self):
+        """(wins per MODEL, draws, winrates) like Arena.play_games: winstate index -> model via player_to_index."""
+        ws, turns, slot = self.engine.results()
+        P = self.game_cls.num_players()
+        wins, draws = [0] * P, 0
+        for w in ws:
+            for p in range(P + 1):
+                if w[p]:
+                    if p == P:
+                        draws += 1
+                    else:
+                        wins[self.player_to_index[p]] += 1
+        n = max(len(ws), 1)
+        return wins, draws, [x / n for x in wins]

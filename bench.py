@@ -76,12 +76,67 @@ def cpu_baseline(net, seconds=12.0):
             'tree_only_value': round(ag.expansions / t_tree, 1), 'host_cpus': os.cpu_count()}
 
 
+WORKLOADS = {
+    # name: (game module, net args, games/GPU, sims, cpuct, fpu)   -- BASELINE.json configs 2..5
+    'connect4': ('connect4', 'CONNECT4_NET_ARGS', 2048, 100, 4.0, 0.4),
+    'brandubh': ('brandubh', 'BRANDUBH_NET_ARGS', 512, 200, 1.25, 0.2),
+    'trimok': ('trimok', 'DEFAULT_NET_ARGS', 256, 50, 1.25, 0.2),
+    'arena': ('connect4', 'CONNECT4_NET_ARGS', 256, 100, 4.0, 0.4),
+}
+
+
+def run_other_workload(a, rank, local_rank, world):
+    """configs 3-5: not the headline bench line; same timing protocol, reported with their own config.workload."""
+    import importlib
+    from alphazero_general_amd import nnet as nn_mod
+    from alphazero_general_amd.selfplay import ArenaRunner
+    gmod, netargs, B, sims, cpuct, fpu = WORKLOADS[a.workload]
+    B = a.slots or B
+    Game_ = importlib.import_module('alphazero_general_amd.envs.' + gmod).Game
+    dev = torch.device('cuda', local_rank)
+    args = selfplay_args(1 << 30)
+    args.update(cpuct=cpuct, fpu_reduction=fpu, numMCTSSims=sims)
+    if a.workload == 'arena':
+        nets = []
+        for sd in (0, 1):                                            # two differently seeded random-init nets
+            torch.manual_seed(sd)
+            nets.append(NNetWrapper(Game_, getattr(nn_mod, netargs), device=dev, dtype=torch.float16))
+        runner = ArenaRunner(Game_, nets, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank)
+        counters = lambda: runner.engine.counters()
+    else:
+        torch.manual_seed(0)
+        net = NNetWrapper(Game_, getattr(nn_mod, netargs), device=dev, dtype=torch.float16)
+        per_game = (Game_.max_turns() + 1) * len(Game_().symmetries(np.zeros(Game_.action_size(), np.float32)))
+        runner = SelfPlayRunner(Game_, net, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
+                                example_capacity=int(B * (a.steps + a.warmup + 4) / 5.0 + 2 * B) * per_game)
+        counters = lambda: runner.counters()
+    for _ in range(a.warmup):
+        runner.play_round()
+    c0 = counters()
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(a.steps):
+        runner.play_round()
+    c1 = counters()
+    torch.cuda.synchronize(); D.barrier()
+    dt = D.max_over_ranks(time.time() - t0)
+    tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'], c1['games_played'] - c0['games_played']])
+    if rank == 0:
+        exp, sm, gm = [int(x) for x in tall]
+        print(json.dumps({'metric': 'mcts_node_expansions_per_sec', 'value': round(exp / dt, 1), 'unit': 'expansions/s',
+                          'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net',
+                          'data': 'synthetic', 'games_per_sec': round(gm / dt, 2), 'simulations_per_sec': round(sm / dt, 1),
+                          'config': {'workload': '%s, %d games/GPU x %d sims/move, net %s' % (a.workload, B, sims, netargs)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=45)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--slots', type=int, default=B_PER_GPU)
+    ap.add_argument('--slots', type=int, default=0)
+    ap.add_argument('--workload', default='connect4', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--pipelines', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -91,9 +146,11 @@ def main():
     assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (there is no CPU fallback)'
     torch.cuda.set_device(local_rank)
+    if a.workload != 'connect4':
+        return run_other_workload(a, rank, local_rank, world)
     dev = torch.device('cuda', local_rank)
     torch.manual_seed(0)                                            # same random-init weights on every rank
-    B = a.slots
+    B = a.slots or B_PER_GPU
     net = NNetWrapper(Game, CONNECT4_NET_ARGS, device=dev, dtype=torch.float16)
     games = 1 << 30
     per_game = 43 * 2
