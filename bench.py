@@ -209,7 +209,11 @@ def main():
         'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(sims / dt, 1),
         'games_finished': games_done, 'samples_gathered': nsamples,
         'roofline': {'kernel': 'k_select<C4>', 'bound': 'hbm', 'achieved': round(sel_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(sel_gbs / HBM_PEAK_GBS, 6), 'traffic': None, 'avg_launch_us': round(sel_us, 2),
+                     'frac': round(sel_gbs / HBM_PEAK_GBS, 6),
+                     # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_tree.py):
+                     # 2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE, profiles/r01_pmc_summary.csv; only valid for the
+                     # default 2048-slot launch
+                     'traffic': 5995000 if Bl == 2048 else None, 'avg_launch_us': round(sel_us, 2),
                      'algorithmic_bytes_per_launch': C4_SELECT_BYTES_PER_SIM * Bl},
         'tree_kernels_us': {'select': round(sel_us, 2), 'backup': round(bak_us, 2), 'advance': round(adv_us, 2),
                             'backup_GBps': round(C4_BACKUP_BYTES_PER_SIM * Bl / (bak_us * 1e-6) / 1e9, 2)},
