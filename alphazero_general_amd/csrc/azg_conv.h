@@ -168,8 +168,13 @@ struct TowerParams {
     const float *bias;        // [1 + 2*nblocks][128]
     const float *pre_scale;   // [nblocks][128]
     const float *pre_shift;   // [nblocks][128]
-    void *y;                  // [boards*H*W, 128] fp16: final residual stream
+    void *y;                  // [boards*H*W, 128] fp16: final residual stream (written when head_w == null)
     int boards, nblocks;
+    // optional fused heads (A + NV <= 16): logits = s_final . head_w + head_b, two softmaxes, written as f32 probabilities
+    const void *head_w;       // packed fragments [H*W][4][64] x 16 B: lane g*16+i holds Wfull[p*128 + ks*32 + g*8 + j][out i]
+    const float *head_b;      // [16]
+    float *policy, *value;    // [boards, A], [boards, NV]
+    int A, NV;
 };
 
 // LDS image of the tower: every board is stored with one pad line above and two pad columns to the right
@@ -343,13 +348,55 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams P, const int16_t *
             }
             __syncthreads();
         }
-        // ---- final residual stream -> HBM (dense rows) ----
-        {
+        if (P.head_w == nullptr) {
+            // ---- final residual stream -> HBM (dense rows) ----
             uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * 16;
             for (int c = tid; c < rows_here * 16; c += 256) {
                 const int p = c >> 4, chunk = c & 15;
                 yg[c] = *reinterpret_cast<const uint4 *>(buf0 + GEO::qrow(p) * RS + chunk * 16);
             }
+        } else {
+            // ---- fused heads: the 1x1 convs + BN + flatten + Linear chains of both heads are one linear map of the
+            // final stream (NNetArchitecture.py:88-102,112-118): logits^T[out, board] = sum_k Wfull^T[out, k] s[board, k],
+            // k = (pixel, channel); one MFMA per (pixel, 32-channel step), pixels dealt round-robin to the 4 waves
+            floatx4 hacc = {0.f, 0.f, 0.f, 0.f};
+            const bool bvalid = i16 < BOARDS;
+            const unsigned bbase = (unsigned)((GEO::LEAD + (bvalid ? i16 : 0) * GEO::BSTRIDE) * RS + g * 16);
+            const half8 *hw = reinterpret_cast<const half8 *>(P.head_w) + lane;
+            for (int p = wave; p < HW; p += 4) {
+                const int y = p / W, x = p - y * W;
+                const unsigned poff = (unsigned)(((y + 1) * GEO::PW + x) * RS);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const half8 af = hw[(size_t)(p * 4 + ks) * 64];
+                    half8 bf = *reinterpret_cast<const half8 *>(buf0 + bbase + poff + ks * 64);
+                    if (!bvalid) bf = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+                    hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, hacc, 0, 0, 0);
+                }
+            }
+            float *red = reinterpret_cast<float *>(buf1);       // [4 waves][16 outs][16 boards]
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[(wave * 16 + g * 4 + r) * 16 + i16] = hacc[r];
+            __syncthreads();
+            const int nb_here = min(BOARDS, P.boards - tile * BOARDS);
+            if (tid < nb_here) {
+                float lg[16];
+#pragma unroll
+                for (int o = 0; o < 16; o++) lg[o] = red[(0 * 16 + o) * 16 + tid] + red[(1 * 16 + o) * 16 + tid] + red[(2 * 16 + o) * 16 + tid]
+                                                    + red[(3 * 16 + o) * 16 + tid] + P.head_b[o];
+                const int A = P.A, NV = P.NV;
+                float m = lg[0]; for (int o = 1; o < A; o++) m = fmaxf(m, lg[o]);
+                float sum = 0.f; for (int o = 0; o < A; o++) { lg[o] = __expf(lg[o] - m); sum += lg[o]; }
+                float *po = P.policy + (size_t)(tile * BOARDS + tid) * A;
+                for (int o = 0; o < A; o++) po[o] = lg[o] / sum;
+                m = lg[A]; for (int o = 1; o < NV; o++) m = fmaxf(m, lg[A + o]);
+                sum = 0.f; for (int o = 0; o < NV; o++) { lg[A + o] = __expf(lg[A + o] - m); sum += lg[A + o]; }
+                float *vo = P.value + (size_t)(tile * BOARDS + tid) * NV;
+                for (int o = 0; o < NV; o++) vo[o] = lg[A + o] / sum;
+            }
+            __syncthreads();
+            reinterpret_cast<uint4 *>(buf1)[tid] = make_uint4(0, 0, 0, 0);     // the scratch overlapped pad rows: restore the zeros
         }
         __syncthreads();
     }

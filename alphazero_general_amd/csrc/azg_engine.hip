@@ -537,7 +537,20 @@ extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const
                                     const float *pre_shift, void *y, int boards, int nblocks) {
     if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
-    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks};
+    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    switch (game) {
+    case AZG_GAME_CONNECT4: return launch_tower<C4::H, C4::W, 4>((hipStream_t)stream, P);
+    default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
+    }
+}
+
+extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
+                                           const float *pre_shift, int boards, int nblocks, const void *head_w, const float *head_b,
+                                           int A, int NV, float *policy, float *value) {
+    if (!x || !w || !bias || !head_w || !head_b || !policy || !value || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (A <= 0 || NV <= 0 || A + NV > 16) return fail(AZG_E_UNSUPPORTED, "fused heads need A + NV <= 16");
+    if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
+    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV};
     switch (game) {
     case AZG_GAME_CONNECT4: return launch_tower<C4::H, C4::W, 4>((hipStream_t)stream, P);
     default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");

@@ -191,6 +191,15 @@ class HipResNet:
             bfv = bv + torch.einsum('ocp,c->o', Wv.reshape(NV, vc, HW), hb[:vc])
             bfp = bp + torch.einsum('ocp,c->o', Wp.reshape(A, -1, HW), hb[vc:])
             self.head_b = torch.cat([bfp, bfv]).to(**f32).contiguous()
+            self.fused_head = (A + NV) <= 16
+            if self.fused_head:                                  # MFMA fragment order for the in-tower heads
+                wf = torch.zeros((HW, 128, 16), dtype=torch.float32, device=fp.device)
+                wf[:, :, :A + NV] = torch.cat([fp, fv], dim=2)
+                # [p, k=ks*32+g*8+j, out i] -> [p][ks][g][i][j]
+                self.head_w_packed = wf.reshape(HW, 4, 4, 8, 16).permute(0, 1, 2, 4, 3).contiguous().reshape(-1) \
+                                       .to(self.device, torch.float16).contiguous()
+                self.head_b16 = torch.zeros(16, **f32)
+                self.head_b16[:A + NV] = self.head_b
         self._bufs = {}
 
     def _buffers(self, B, key=0):
@@ -211,6 +220,18 @@ class HipResNet:
         of activation buffers (one per captured graph, so that graphs on different streams never share scratch)."""
         B = x.shape[0]
         s, u, t = self._buffers(B, key)
+        if self.fused and self.fused_head:                       # tower + heads + softmax in ONE launch
+            import ctypes as C
+            vp = lambda q: C.c_void_p(q.data_ptr())
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if ('pv', B, key) not in self._bufs:
+                self._bufs[('pv', B, key)] = (torch.empty((B, self.A), dtype=torch.float32, device=self.device),
+                                              torch.empty((B, self.NV), dtype=torch.float32, device=self.device))
+            pol, val = self._bufs[('pv', B, key)]
+            self._check(self.L.azg_resnet_policy_value_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
+                                                           vp(self.tower_pt), int(B), len(self.blocks), vp(self.head_w_packed),
+                                                           vp(self.head_b16), int(self.A), int(self.NV), vp(pol), vp(val)))
+            return pol, val
         if self.fused:                                           # one persistent launch, activations resident in LDS
             import ctypes as C
             vp = lambda q: C.c_void_p(q.data_ptr())

@@ -197,6 +197,14 @@ int  azg_conv3x3_f16(void *stream, int game, const void *x_dev, const void *w_pa
  * y: [boards*H*W, 128] fp16 = the final residual stream (input of the collapsed heads GEMM). */
 int  azg_resnet_tower_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
                           const float *pre_scale_dev, const float *pre_shift_dev, void *y_dev, int boards, int nblocks);
+/* The tower with both heads fused behind it (A + NV <= 16): head_w_packed = the collapsed heads matrix
+ * Wfull[H*W*128, A+NV] in MFMA fragment order [H*W][4][64 lanes][8 halves] (nnet.pack_head_weight), head_b f32[16];
+ * writes softmax probabilities policy f32[boards, A] and value f32[boards, NV] -- what NNetWrapper.process returns
+ * (alphazero/NNetWrapper.py:225-232) -- without storing the final stream. */
+int  azg_resnet_policy_value_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
+                                 const float *pre_scale_dev, const float *pre_shift_dev, int boards, int nblocks,
+                                 const void *head_w_packed_dev, const float *head_b_dev, int A, int NV,
+                                 float *policy_dev, float *value_dev);
 
 /* ---- timing hooks for bench.py (HIP events on `stream` around the engine's own kernels) -------------------- */
 int  azg_profile_enable(azg_engine *e, int on);

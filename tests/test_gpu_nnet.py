@@ -33,10 +33,10 @@ def _boards(torch, B, seed=0):
     return torch.from_numpy(np.array(obs, np.float32))
 
 
-@pytest.mark.parametrize('backend', ['torch', 'hip', 'hip_layers'])
+@pytest.mark.parametrize('backend', ['torch', 'hip', 'hip_layers', 'hip_tower_only'])
 def test_inference_paths_vs_fp32_reference(backend):
-    layers = backend == 'hip_layers'
-    backend = 'hip' if layers else backend
+    layers, tower_only = backend == 'hip_layers', backend == 'hip_tower_only'
+    backend = 'hip' if (layers or tower_only) else backend
     import torch
     from alphazero_general_amd.envs.connect4 import Game
     from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
@@ -49,6 +49,8 @@ def test_inference_paths_vs_fp32_reference(backend):
         rp, rv = torch.exp(lp).cpu(), torch.exp(lv).cpu()
     if layers:
         net.refresh(); net._hip.fused = False
+    if tower_only:
+        net.refresh(); net._hip.fused_head = False
     p, v = net.process(x)
     assert (net._hip is not None) == (backend == 'hip')
     assert p.shape == rp.shape and v.shape == rv.shape and p.dtype == torch.float32
