@@ -175,6 +175,7 @@ struct TowerParams {
     const float *head_b;      // [16]
     float *policy, *value;    // [boards, A], [boards, NV]
     int A, NV;
+    unsigned long long *dbg;  // AZG_TOWER_TIMING builds only: s_memtime stamps of workgroup 0 [layer][wave][5]
 };
 
 // LDS image of the tower: every board is stored with one pad line above and two pad columns to the right
@@ -275,11 +276,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams P, const int16_t *
         live[ps] = p >= 0;
         const int q = p >= 0 ? GEO::qrow(p) : GEO::LEAD;                     // spare lanes read (and discard) pad rows
         lb[ps] = (unsigned)(TILE + q * RS + g * 16 - GEO::BIAS);             // absolute LDS offset inside buf1 (the conv input)
-        eb[ps] = (unsigned)(q * RS + g * 8);
+        eb[ps] = (unsigned)(q * RS) + (unsigned)(((g & 1) ? (2 * wave + 1) * 16 + (g - 1) * 4 : (2 * wave) * 16 + g * 4) * 2);
     }
     const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
     half8 a[4][2];
     floatx4 acc[2][NSUB];
+    half2v sreg[NSUB][4];                               // the residual stream of this lane's cells (fp16, 8 channels x NSUB)
+    const int ecol = (g & 1) ? (2 * wave + 1) * 16 + (g - 1) * 4 : (2 * wave) * 16 + g * 4;   // first channel this lane owns in the epilogue
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -299,19 +302,16 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams P, const int16_t *
 #pragma unroll
         for (int i = 0; i < 3; i++) { a[i][0] = wt[(size_t)i * 512]; a[i][1] = wt[(size_t)i * 512 + 64]; }
         __syncthreads();
+#ifdef AZG_TOWER_TIMING
+#define AZG_STAMP(i) do { if (P.dbg && blockIdx.x == 0 && tile == 0 && lane == 0) P.dbg[(layer * 4 + wave) * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZG_STAMP(i) do { } while (0)
+#endif
         for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
+            AZG_STAMP(0);
             const float *bias = P.bias + (size_t)layer * 128;
-#pragma unroll
-            for (int m = 0; m < 2; m++) {                       // accumulators start at the bias
-                const int c0 = (2 * wave + m) * 16 + g * 4;
-                const floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
-#pragma unroll
-                for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
-            }
-            if (layer == 0) { conv_main<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
-            else { conv_main<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
-            __syncthreads();                                    // every wave is done reading buf1
-            // layer 0 (stem) and even layers (conv2): s -> buf0 and t = relu(affine(s)) -> buf1;  odd layers: u -> buf1
+            // layer 0 (stem) and even layers (conv2) produce the residual stream s (kept in REGISTERS: each lane owns the
+            // same (pixel, 4-channel) cells in every layer) and t = relu(affine(s)) -> LDS; odd layers (conv1): u -> LDS
             const bool is_s = (layer & 1) == 0;
             const int nb = layer >> 1;
             const bool has_next = nb < P.nblocks;
@@ -319,34 +319,67 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams P, const int16_t *
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const int c0 = (2 * wave + m) * 16 + g * 4;
-                half2v sc0 = zero2, sc1 = zero2, sh0 = zero2, sh1 = zero2;
-                if (is_s && has_next) {
-                    const float *ps_ = P.pre_scale + (size_t)nb * 128 + c0, *pt_ = P.pre_shift + (size_t)nb * 128 + c0;
-                    sc0 = (half2v){(_Float16)ps_[0], (_Float16)ps_[1]}; sc1 = (half2v){(_Float16)ps_[2], (_Float16)ps_[3]};
-                    sh0 = (half2v){(_Float16)pt_[0], (_Float16)pt_[1]}; sh1 = (half2v){(_Float16)pt_[2], (_Float16)pt_[3]};
-                }
+                const floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};      // accumulators start at the bias
 #pragma unroll
-                for (int ps = 0; ps < NSUB; ps++) {
+                for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
+            }
+            // Epilogue layout: after a v_permlane16_swap of the two cout-subtiles, a lane with even g holds 8 consecutive
+            // channels of subtile 2w, a lane with odd g 8 consecutive channels of subtile 2w+1 (ecol = first channel), i.e.
+            // ONE 16-byte LDS access per pixel instead of two 8-byte ones (half the LDS instructions, half the conflicts).
+            half2v sc[4], sh[4];                                // next block's pre-activation affine, fetched under the main loop
+#pragma unroll
+            for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
+            if (is_s && has_next) {
+                const float *ps_ = P.pre_scale + (size_t)nb * 128 + ecol, *pt_ = P.pre_shift + (size_t)nb * 128 + ecol;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
+                    sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
+                }
+            }
+            if (layer == 0) { conv_main<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
+            else { conv_main<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
+            AZG_STAMP(1);
+            __syncthreads();                                    // every wave is done reading buf1
+            AZG_STAMP(2);
+            const bool last = layer == 2 * P.nblocks;
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) {
+                half2v v[4];
+                {
+                    union { half2v h; unsigned u; } a0, a1, b0, b1;
+                    a0.h = (half2v){(_Float16)acc[0][ps][0], (_Float16)acc[0][ps][1]}; a1.h = (half2v){(_Float16)acc[0][ps][2], (_Float16)acc[0][ps][3]};
+                    b0.h = (half2v){(_Float16)acc[1][ps][0], (_Float16)acc[1][ps][1]}; b1.h = (half2v){(_Float16)acc[1][ps][2], (_Float16)acc[1][ps][3]};
+                    auto r0 = __builtin_amdgcn_permlane16_swap(a0.u, b0.u, false, false);   // odd rows of subtile-0 regs <-> even rows of subtile-1 regs
+                    auto r1 = __builtin_amdgcn_permlane16_swap(a1.u, b1.u, false, false);
+                    a0.u = r0[0]; b0.u = r0[1]; a1.u = r1[0]; b1.u = r1[1];
+                    v[0] = a0.h; v[1] = a1.h; v[2] = b0.h; v[3] = b1.h;
+                }
+                const unsigned off = eb[ps];
+                if (!is_s) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = __builtin_elementwise_max(v[j], zero2);
+                    if (live[ps]) *reinterpret_cast<uint4 *>(buf1 + off) = *reinterpret_cast<uint4 *>(v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (layer == 0) v[j] = __builtin_elementwise_max(v[j], zero2); else v[j] += sreg[ps][j];
+                        sreg[ps][j] = v[j];
+                    }
                     if (live[ps]) {
-                        const unsigned off = eb[ps] + (2 * wave + m) * 32;
-                        half2v lo = {(_Float16)acc[m][ps][0], (_Float16)acc[m][ps][1]};
-                        half2v hi = {(_Float16)acc[m][ps][2], (_Float16)acc[m][ps][3]};
-                        if (!is_s) {
-                            lo = __builtin_elementwise_max(lo, zero2); hi = __builtin_elementwise_max(hi, zero2);
-                            *reinterpret_cast<half2v *>(buf1 + off) = lo; *reinterpret_cast<half2v *>(buf1 + off + 4) = hi;
-                        } else {
-                            if (layer == 0) { lo = __builtin_elementwise_max(lo, zero2); hi = __builtin_elementwise_max(hi, zero2); }
-                            else { lo += *reinterpret_cast<const half2v *>(buf0 + off); hi += *reinterpret_cast<const half2v *>(buf0 + off + 4); }
-                            *reinterpret_cast<half2v *>(buf0 + off) = lo; *reinterpret_cast<half2v *>(buf0 + off + 4) = hi;
-                            if (has_next) {
-                                half2v t0 = __builtin_elementwise_max(lo * sc0 + sh0, zero2), t1 = __builtin_elementwise_max(hi * sc1 + sh1, zero2);
-                                *reinterpret_cast<half2v *>(buf1 + off) = t0; *reinterpret_cast<half2v *>(buf1 + off + 4) = t1;
-                            }
+                        if (last) *reinterpret_cast<uint4 *>(buf0 + off) = *reinterpret_cast<uint4 *>(v);
+                        if (has_next) {
+                            half2v t[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) t[j] = __builtin_elementwise_max(v[j] * sc[j] + sh[j], zero2);
+                            *reinterpret_cast<uint4 *>(buf1 + off) = *reinterpret_cast<uint4 *>(t);
                         }
                     }
                 }
             }
+            AZG_STAMP(3);
             __syncthreads();
+            AZG_STAMP(4);
         }
         if (P.head_w == nullptr) {
             // ---- final residual stream -> HBM (dense rows) ----

@@ -537,7 +537,7 @@ extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const
                                     const float *pre_shift, void *y, int boards, int nblocks) {
     if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
-    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
     switch (game) {
     case AZG_GAME_CONNECT4: return launch_tower<C4::H, C4::W, 4>((hipStream_t)stream, P);
     default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
@@ -550,7 +550,21 @@ extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x
     if (!x || !w || !bias || !head_w || !head_b || !policy || !value || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (A <= 0 || NV <= 0 || A + NV > 16) return fail(AZG_E_UNSUPPORTED, "fused heads need A + NV <= 16");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
-    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV};
+    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr};
+#ifdef AZG_TOWER_TIMING
+    static unsigned long long *d_dbg = nullptr;
+    if (!d_dbg) { HIPCHK(hipMalloc((void **)&d_dbg, 8 * 5 * 4 * 64)); }
+    P.dbg = d_dbg;
+    if (getenv("AZG_TOWER_DUMP")) {
+        HIPCHK(hipDeviceSynchronize());
+        unsigned long long h[5 * 4 * 64];
+        HIPCHK(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (int l = 0; l <= 2 * nblocks; l++) for (int wv = 0; wv < 4; wv++) {
+            unsigned long long *t = h + (l * 4 + wv) * 5;
+            printf("layer %2d wave %d main %6llu bar1 %6llu epi %6llu bar2 %6llu\n", l, wv, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]);
+        }
+    }
+#endif
     switch (game) {
     case AZG_GAME_CONNECT4: return launch_tower<C4::H, C4::W, 4>((hipStream_t)stream, P);
     default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
