@@ -172,6 +172,13 @@ AZG_DEV float wave_max(float m) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     return m;
 }
+// max over lanes [0, N) only (N a power of two <= 64; the other lanes must hold -inf or be ignored by the caller):
+// log2(N) butterfly steps instead of 6 -- the connect4 child block is 7 wide
+template <int N> AZG_DEV float wave_max_n(float m) {
+#pragma unroll
+    for (int o = N / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return rl(m, 0);
+}
 AZG_DEV int wave_sum_i(int m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);

@@ -424,6 +424,7 @@ extern "C" int azg_read_counters(azg_engine *e, void *stream, azg_counters *out)
     hipStream_t s = (hipStream_t)stream;
     int32_t gc[8];
     std::vector<int64_t> sims((size_t)e->v.B), exps((size_t)e->v.B);
+    hipLaunchKernelGGL(k_max_nodes, dim3(1), dim3(256), 0, s, e->v);
     HIPCHK(hipMemcpyAsync(gc, e->v.gcount, sizeof(gc), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(sims.data(), e->v.slot_sims, sizeof(int64_t) * e->v.B, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(exps.data(), e->v.slot_exp, sizeof(int64_t) * e->v.B, hipMemcpyDeviceToHost, s));

@@ -69,8 +69,7 @@ AZG_DEV int add_children(const View &ev, int slot, Node *nodes, TreeHdr *h, int 
     }
     if (lane == 0) {
         h->alloc = fc + k;
-        ev.tape_ctr[slot] = ctr + (uint64_t)k;
-        atomicMax(&ev.gcount[GC_MAXNODES], fc + k);
+        ev.tape_ctr[slot] = ctr + (uint64_t)k;          // (no global high-water atomic here: 2048 waves on one word cost ~20 us)
     }
     return fc;
 }
@@ -107,7 +106,9 @@ __global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *
         }
         const float seen_f = (float)seen;
         const float fpu = (float)((double)cn.v - ((double)ev.fpu_reduction * sqrt((double)seen_f)));   // :92
-        const float sqn = (float)sqrt((double)cn.n);                                                       // :94
+        // :94 (float)sqrt((double)n): a correctly rounded f32 sqrt of the (exactly representable) count gives the same
+        // float -- rounding a 53-bit sqrt to 24 bits is innocuous double rounding (53 >= 2*24 + 2)
+        const float sqn = cn.n < (1 << 24) ? sqrtf((float)cn.n) : (float)sqrt((double)cn.n);
         float best = -INFINITY; int bi = 0; NodeR sel = cn;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *
             float t = ni == 0 ? fpu : __uint_as_float(lo[c].y);
             float u = t + (((cpuct * __uint_as_float(lo[c].z)) * sqn) / ((float)(1 + ni)));               // :87
             if (i >= k) u = -INFINITY;
-            float m = wave_max(u);
+            constexpr int RW = G::MAXK <= 8 ? 8 : G::MAXK <= 16 ? 16 : G::MAXK <= 32 ? 32 : 64;
+            float m = RW == 64 ? wave_max(u) : wave_max_n<RW>(u);
             if (m > best) {                                                  // strict '>' : first max wins (:100)
                 uint64_t bal = __ballot(i < k && u == m);
                 int b = __ffsll((unsigned long long)bal) - 1;
@@ -512,6 +514,13 @@ __global__ __launch_bounds__(64) void k_reset(View ev, int first, int count, int
     if (reset_state) { typename G::S st; G::init(st); G::store(st, &ev.states[slot], lane); }
     if (lane == 0) { ev.hist_len[slot] = 0; ev.next_reset[slot] = 0; ev.fin_flag[slot] = 0; }
     for (int t = 0; t < ev.T; t++) init_tree(ev, slot * ev.T + t, lane);
+}
+
+// high-water mark of the tree arenas, computed when the counters are read
+__global__ __launch_bounds__(256) void k_max_nodes(View ev) {
+    int m = 0;
+    for (int t = threadIdx.x; t < ev.B * ev.T; t += 256) m = max(m, ev.hdr[t].alloc);
+    atomicMax(&ev.gcount[GC_MAXNODES], m);
 }
 
 __global__ __launch_bounds__(64) void k_reset_max_depth(View ev) {
