@@ -435,6 +435,211 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams P, const int16_t *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ k_tower2
+// Two workgroups per CU.  With the residual stream in registers only ONE LDS image is needed (t / u / final s take
+// turns in it), 81 KB per workgroup, so two workgroups (two tiles) are resident per CU and one runs its epilogue /
+// barriers while the other keeps the MFMA pipe busy.  To fit 2 waves per SIMD (<= 256 registers per wave) the B
+// fragments are a short rolling window (PF reads ahead of their MFMAs) instead of a double-buffered k-step.
+template <class GEO, int KS, int NSUB>
+struct FragOff {                                             // LDS immediate of fragment t = kk * NSUB + ps
+    static constexpr int get(int t) {
+        const int kk = t / NSUB, tap = kk / KS, ks = kk % KS;
+        return GEO::BIAS + ((tap / 3 - 1) * GEO::PW + (tap % 3 - 1)) * GEO::RSTRIDE + ks * 64;
+    }
+};
+
+template <class GEO, int KS, int NSUB, int RB>
+__device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[2][2],
+                                           floatx4 (&acc)[2][NSUB]) {
+    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = 4, RING = 6;
+    static_assert(NSUB == 11 || NSUB <= RING, "slot = ps % RING is collision-free with PF = 4 for NSUB = 11 (checked case by case)");
+    using FO = FragOff<GEO, KS, NSUB>;
+    half8 bb[RING];                                          // fragment (kk, ps) lives in slot ps % RING, read PF fragments ahead
+#pragma unroll
+    for (int t = 0; t < PF; t++) bb[t % RING] = *reinterpret_cast<const half8 *>(in + lb[t] + FO::get(t));
+#pragma clang loop unroll(full)
+    for (int kk = 0; kk < NSTEP; kk++) {
+        const int an = (RB + kk + 1) & 1, ac = (RB + kk) & 1;
+        a[an][0] = wfrag[(size_t)(kk + 1) * 512]; a[an][1] = wfrag[(size_t)(kk + 1) * 512 + 64];
+#pragma clang loop unroll(full)
+        for (int ps = 0; ps < NSUB; ps++) {
+            const int t = kk * NSUB + ps, psn = (ps + PF) % NSUB;
+            if (t + PF < TOT) bb[psn % RING] = *reinterpret_cast<const half8 *>(in + lb[psn] + FO::get(t + PF));
+            acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[ps % RING], acc[0][ps], 0, 0, 0);
+            acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[ps % RING], acc[1][ps], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+        for (int ps = 0; ps < NSUB; ps++) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int H, int W, int BOARDS>
+__global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t *pixmap) {
+    using GEO = TowerGeom<H, W, BOARDS>;
+    constexpr int HW = GEO::HW, ROWS = GEO::ROWS, NSUB = GEO::NSUB, TILE = GEO::TILE, RS = GEO::RSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *img = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
+    for (int c = tid; c < TILE / 16; c += 256) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
+    unsigned lb[NSUB];
+    unsigned livemask = 0;
+    const int ecol = (g & 1) ? (2 * wave + 1) * 16 + (g - 1) * 4 : (2 * wave) * 16 + g * 4;
+#pragma unroll
+    for (int ps = 0; ps < NSUB; ps++) {
+        const int p = pixmap[ps * 16 + i16];
+        if (p >= 0) livemask |= 1u << ps;
+        const int q = p >= 0 ? GEO::qrow(p) : GEO::LEAD;
+        lb[ps] = (unsigned)(q * RS + g * 16 - GEO::BIAS);
+    }
+    const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
+    const unsigned edelta = (unsigned)(GEO::BIAS - g * 16 + ecol * 2);      // epilogue cell of a pixel = fragment base + edelta
+    half8 a[2][2];
+    floatx4 acc[2][NSUB];
+    half2v sreg[NSUB][4];
+    // The two workgroups of a CU start together and do identical work: without a phase offset their epilogues coincide
+    // and nothing overlaps.  Hold the second half of the grid back by about half a layer.
+    if (blockIdx.x >= gridDim.x / 2) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        const int rows_here = min(ROWS, P.boards * HW - row0);
+        {
+            const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
+            for (int c = tid; c < ROWS * 4; c += 256) {
+                const int p = c >> 2, chunk = c & 3;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (chunk == 0 && p < rows_here) v = xg[p];
+                *reinterpret_cast<uint4 *>(img + GEO::qrow(p) * RS + chunk * 16) = v;
+            }
+        }
+        const half8 *wt = wl;
+        a[0][0] = wt[0]; a[0][1] = wt[64];
+        __syncthreads();
+        for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
+            const float *bias = P.bias + (size_t)layer * 128;
+            const bool is_s = (layer & 1) == 0;
+            const int nb = layer >> 1;
+            const bool has_next = nb < P.nblocks;
+            const half2v zero2 = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int c0 = (2 * wave + m) * 16 + g * 4;
+                const floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
+#pragma unroll
+                for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
+            }
+            half2v sc[4], sh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
+            if (is_s && has_next) {
+                const float *ps_ = P.pre_scale + (size_t)nb * 128 + ecol, *pt_ = P.pre_shift + (size_t)nb * 128 + ecol;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
+                    sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
+                }
+            }
+            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
+            else { conv_main2<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
+            __syncthreads();                                    // every wave is done reading the image
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) {
+                half2v v[4];
+                {
+                    union { half2v h; unsigned u; } a0, a1, b0, b1;
+                    a0.h = (half2v){(_Float16)acc[0][ps][0], (_Float16)acc[0][ps][1]}; a1.h = (half2v){(_Float16)acc[0][ps][2], (_Float16)acc[0][ps][3]};
+                    b0.h = (half2v){(_Float16)acc[1][ps][0], (_Float16)acc[1][ps][1]}; b1.h = (half2v){(_Float16)acc[1][ps][2], (_Float16)acc[1][ps][3]};
+                    auto r0 = __builtin_amdgcn_permlane16_swap(a0.u, b0.u, false, false);
+                    auto r1 = __builtin_amdgcn_permlane16_swap(a1.u, b1.u, false, false);
+                    a0.u = r0[0]; b0.u = r0[1]; a1.u = r1[0]; b1.u = r1[1];
+                    v[0] = a0.h; v[1] = a1.h; v[2] = b0.h; v[3] = b1.h;
+                }
+                const unsigned off = lb[ps] + edelta;
+                const bool lv = (livemask >> ps) & 1;
+                if (!is_s) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = __builtin_elementwise_max(v[j], zero2);
+                    if (lv) *reinterpret_cast<uint4 *>(img + off) = *reinterpret_cast<uint4 *>(v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (layer == 0) v[j] = __builtin_elementwise_max(v[j], zero2); else v[j] += sreg[ps][j];
+                        sreg[ps][j] = v[j];
+                    }
+                    if (lv) {
+                        if (has_next) {
+                            half2v t[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) t[j] = __builtin_elementwise_max(v[j] * sc[j] + sh[j], zero2);
+                            *reinterpret_cast<uint4 *>(img + off) = *reinterpret_cast<uint4 *>(t);
+                        } else {
+                            *reinterpret_cast<uint4 *>(img + off) = *reinterpret_cast<uint4 *>(v);     // final stream for the heads
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (P.head_w == nullptr) {
+            uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * 16;
+            for (int c = tid; c < rows_here * 16; c += 256) {
+                const int p = c >> 4, chunk = c & 15;
+                yg[c] = *reinterpret_cast<const uint4 *>(img + GEO::qrow(p) * RS + chunk * 16);
+            }
+        } else {
+            floatx4 hacc = {0.f, 0.f, 0.f, 0.f};
+            const bool bvalid = i16 < BOARDS;
+            const unsigned bbase = (unsigned)((GEO::LEAD + (bvalid ? i16 : 0) * GEO::BSTRIDE) * RS + g * 16);
+            const half8 *hw = reinterpret_cast<const half8 *>(P.head_w) + lane;
+            for (int p = wave; p < HW; p += 4) {
+                const int y = p / W, x = p - y * W;
+                const unsigned poff = (unsigned)(((y + 1) * GEO::PW + x) * RS);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const half8 af = hw[(size_t)(p * 4 + ks) * 64];
+                    half8 bf = *reinterpret_cast<const half8 *>(img + bbase + poff + ks * 64);
+                    if (!bvalid) bf = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+                    hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, hacc, 0, 0, 0);
+                }
+            }
+            // the reduction scratch lives in the pad rows at the top of the image (zeroed again below) -- but real data of
+            // board 0 must not be clobbered before every wave has finished reading it
+            __syncthreads();
+            float *red = reinterpret_cast<float *>(img);
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[(wave * 16 + g * 4 + r) * 16 + i16] = hacc[r];
+            __syncthreads();
+            const int nb_here = min(BOARDS, P.boards - tile * BOARDS);
+            if (tid < nb_here) {
+                float lg[16];
+#pragma unroll
+                for (int o = 0; o < 16; o++) lg[o] = red[(0 * 16 + o) * 16 + tid] + red[(1 * 16 + o) * 16 + tid] + red[(2 * 16 + o) * 16 + tid]
+                                                    + red[(3 * 16 + o) * 16 + tid] + P.head_b[o];
+                const int A = P.A, NV = P.NV;
+                float m = lg[0]; for (int o = 1; o < A; o++) m = fmaxf(m, lg[o]);
+                float sum = 0.f; for (int o = 0; o < A; o++) { lg[o] = __expf(lg[o] - m); sum += lg[o]; }
+                float *po = P.policy + (size_t)(tile * BOARDS + tid) * A;
+                for (int o = 0; o < A; o++) po[o] = lg[o] / sum;
+                m = lg[A]; for (int o = 1; o < NV; o++) m = fmaxf(m, lg[A + o]);
+                sum = 0.f; for (int o = 0; o < NV; o++) { lg[A + o] = __expf(lg[A + o] - m); sum += lg[A + o]; }
+                float *vo = P.value + (size_t)(tile * BOARDS + tid) * NV;
+                for (int o = 0; o < NV; o++) vo[o] = lg[A + o] / sum;
+            }
+            __syncthreads();
+            reinterpret_cast<uint4 *>(img)[tid] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+}
+
 // leaf observation planes [B, C, H, W] (any of the engine's obs dtypes) are written by k_select directly as the stem's
 // NHWC8 fp16 rows when obs_dtype == 2 (see G::write_obs_nhwc8).
 

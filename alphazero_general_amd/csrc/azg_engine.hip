@@ -528,6 +528,16 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
     }
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
+    static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
+    if (variant == 2) {                                      // one LDS image, two workgroups per CU
+        static bool attr2 = false;
+        const size_t lds2 = (size_t)GEO::TILE;
+        if (!attr2) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); attr2 = true; }
+        const int grid2 = ntiles < 2 * cus ? ntiles : 2 * cus;
+        hipLaunchKernelGGL((k_tower2<H, W, BOARDS>), dim3(grid2), dim3(256), lds2, s, P, (const int16_t *)d_map[dev]);
+        HIPCHK(hipGetLastError());
+        return AZG_OK;
+    }
     const int grid = ntiles < cus ? ntiles : cus;
     hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), lds, s, P, (const int16_t *)d_map[dev]);
     HIPCHK(hipGetLastError());
