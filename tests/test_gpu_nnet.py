@@ -84,3 +84,24 @@ def test_mfma_conv_single_layer_vs_torch():
     got = y.float().reshape(B, 6, 7, 128).permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
     assert err < 2e-2 * max(1.0, ref.abs().max().item()) / 4, err
+
+
+def test_tower_multi_tile_loop_and_determinism():
+    """more tiles than resident workgroups (each workgroup loops over several tiles) + run-to-run bit determinism."""
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
+    torch.manual_seed(5)
+    net = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', backend='hip')
+    _randomize(net.nnet.cpu(), torch, seed=2); net.nnet.to('cuda:0'); net.refresh()
+    base = _boards(torch, 300, seed=4)
+    x = base.repeat(8, 1, 1, 1)[:2101]                      # 526 tiles of 4 boards > 512 resident workgroups
+    p, v = net.process(x)
+    p, v = p.clone(), v.clone()
+    p2, v2 = net.process(x)
+    assert torch.equal(p, p2) and torch.equal(v, v2)
+    assert torch.equal(p[:300], p[300:600]) and torch.equal(p[:1], p[2100:2101])     # same board -> same output in any tile
+    with torch.no_grad():
+        lp, lv = net.nnet(x[:300].to('cuda:0'))
+    assert float((p[:300].cpu() - torch.exp(lp).cpu()).abs().max()) < 3e-3
+    assert float((v[:300].cpu() - torch.exp(lv).cpu()).abs().max()) < 3e-3
