@@ -503,9 +503,6 @@ __global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t 
     half8 a[2][2];
     floatx4 acc[2][NSUB];
     half2v sreg[NSUB][4];
-    // The two workgroups of a CU start together and do identical work: without a phase offset their epilogues coincide
-    // and nothing overlaps.  Hold the second half of the grid back by about half a layer.
-    if (blockIdx.x >= gridDim.x / 2) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
