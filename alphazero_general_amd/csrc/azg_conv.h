@@ -533,8 +533,10 @@ __global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t 
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
             }
-            half2v sc[4], sh[4];
-#pragma unroll
+            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
+            else { conv_main2<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
+            half2v sc[4], sh[4];                                // (fetched here, not under the main loop: registers are the
+#pragma unroll                                                  //  scarce resource at 2 waves per SIMD, the co-resident wave hides it)
             for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
             if (is_s && has_next) {
                 const float *ps_ = P.pre_scale + (size_t)nb * 128 + ecol, *pt_ = P.pre_shift + (size_t)nb * 128 + ecol;
@@ -544,8 +546,6 @@ __global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t 
                     sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
                 }
             }
-            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
-            else { conv_main2<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
             __syncthreads();                                    // every wave is done reading the image
 #pragma unroll
             for (int ps = 0; ps < NSUB; ps++) {

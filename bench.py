@@ -35,6 +35,8 @@ C4_SELECT_BYTES_PER_SIM = 5 * (32 + 7 * 32) + (32 + 7 * 32) + 2 * 80 + 336 + 5 *
 C4_BACKUP_BYTES_PER_SIM = 7 * 4 + 12 + 7 * 4 + 5 * (4 + 16) + 32
 C4_NET_FLOPS_PER_LEAF = 205e6
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
+TOWER_TRAFFIC_BYTES = 86335000   # PMC per launch @2048 boards: 2 x FETCH_SIZE + WRITE_SIZE (profiles/r01_pmc_summary.csv):
+                                 # the 5 MB weight stream fetched per XCD + input planes + register-spill traffic
 
 
 def selfplay_args(games):
@@ -199,6 +201,25 @@ def main():
     adv_us = prof['advance_ms'] * 1e3 / max(prof['advance_n'], 1)
     Bl = B // a.pipelines                                           # slots per launch
     sel_gbs = C4_SELECT_BYTES_PER_SIM * Bl / (sel_us * 1e-6) / 1e9
+    nn_ms = ev_nn[0][0].elapsed_time(ev_nn[0][1]) / 8 if ev_nn else None
+    tree = {'kernel': 'k_select<C4>', 'bound': 'hbm', 'achieved': round(sel_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(sel_gbs / HBM_PEAK_GBS, 6),
+            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_tree.py):
+            # 2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE, profiles/r01_pmc_summary.csv; 2048-slot launch only
+            'traffic': 5995000 if Bl == 2048 else None, 'avg_launch_us': round(sel_us, 2),
+            'algorithmic_bytes_per_launch': C4_SELECT_BYTES_PER_SIM * Bl,
+            'backup_us': round(bak_us, 2), 'advance_us': round(adv_us, 2),
+            'backup_GBps': round(C4_BACKUP_BYTES_PER_SIM * Bl / (bak_us * 1e-6) / 1e9, 2)}
+    if nn_ms is not None:
+        # the dominant kernel of the step (~94 % of the time): the network tower + heads, ONE launch (k_tower2), MFMA-bound
+        tf = C4_NET_FLOPS_PER_LEAF * Bl / (nn_ms * 1e-3) / 1e12
+        roof = {'kernel': 'k_tower2<6,7,4> (ResNet 128ch x 8 tower + heads, one launch per evaluation)', 'bound': 'mfma',
+                'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                'avg_launch_us': round(nn_ms * 1e3, 1), 'algorithmic_flops_per_launch': C4_NET_FLOPS_PER_LEAF * Bl,
+                # HBM bytes per launch (PMC, profiles/r01_pmc_summary.csv): weights + input planes + probabilities
+                'traffic': TOWER_TRAFFIC_BYTES if Bl == 2048 else None}
+    else:
+        roof = tree
     out = {
         'metric': 'mcts_node_expansions_per_sec', 'value': round(expansions / dt, 1), 'unit': 'expansions/s',
         'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
@@ -208,21 +229,8 @@ def main():
                    'stream_pipelines': a.pipelines},
         'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(sims / dt, 1),
         'games_finished': games_done, 'samples_gathered': nsamples,
-        'roofline': {'kernel': 'k_select<C4>', 'bound': 'hbm', 'achieved': round(sel_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(sel_gbs / HBM_PEAK_GBS, 6),
-                     # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_tree.py):
-                     # 2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE, profiles/r01_pmc_summary.csv; only valid for the
-                     # default 2048-slot launch
-                     'traffic': 5995000 if Bl == 2048 else None, 'avg_launch_us': round(sel_us, 2),
-                     'algorithmic_bytes_per_launch': C4_SELECT_BYTES_PER_SIM * Bl},
-        'tree_kernels_us': {'select': round(sel_us, 2), 'backup': round(bak_us, 2), 'advance': round(adv_us, 2),
-                            'backup_GBps': round(C4_BACKUP_BYTES_PER_SIM * Bl / (bak_us * 1e-6) / 1e9, 2)},
+        'roofline': roof, 'tree_roofline': tree,
     }
-    if ev_nn:
-        nn_ms = ev_nn[0][0].elapsed_time(ev_nn[0][1]) / 8
-        tf = C4_NET_FLOPS_PER_LEAF * (B // a.pipelines) / (nn_ms * 1e-3) / 1e12
-        out['nn_roofline'] = {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'ms_per_batch': round(nn_ms, 3)}
     if a.gpus == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(net)
     print(json.dumps(out))
