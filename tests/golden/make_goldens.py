@@ -334,6 +334,64 @@ def gen_arena(game_cls, game_id, name, B=8, sims=12, games=10, seed=555):
     np.savez_compressed(os.path.join(OUT, name + '_arena.npz'), **out)
 
 
+def fill_deterministic(sd):
+    """Deterministic weights from the key order, identical for the reference net and the build's net."""
+    import torch
+    out = {}
+    for i, k in enumerate(sorted(sd)):
+        t = sd[k]
+        if t.dtype in (torch.int64, torch.int32):
+            out[k] = t.clone()
+            continue
+        n = t.numel()
+        x = torch.sin(torch.arange(n, dtype=torch.float64) * 0.37 + i * 1.7)
+        if k.endswith('running_var'):
+            x = x.abs() * 0.8 + 0.4
+        elif k.endswith('running_mean') or k.endswith('.bias'):
+            x = x * 0.1
+        elif 'bn' in k and k.endswith('.weight'):
+            x = x * 0.3 + 1.0
+        else:
+            x = x * (1.5 / max(t[0].numel(), 1) ** 0.5)
+        out[k] = x.reshape(t.shape).to(t.dtype)
+    return out
+
+
+def gen_net():
+    """Reference ResNet (alphazero/NNetArchitecture.py:69-120) forward on fixed boards with deterministic weights."""
+    import torch
+    from alphazero.NNetArchitecture import ResNet
+    from alphazero.envs.connect4.connect4 import Game
+    from alphazero.utils import dotdict
+    out = {}
+    rng = np.random.RandomState(3)
+    obs = []
+    for b in range(12):
+        g = Game()
+        for _ in range(rng.randint(0, 25)):
+            v = np.flatnonzero(np.asarray(g.valid_moves()))
+            if np.asarray(g.win_state()).any():
+                break
+            g.play_action(int(rng.choice(v)))
+        obs.append(g.observation())
+    obs = np.array(obs, np.float32)
+    out['obs'] = obs
+    for name, a in (('default', dict(num_channels=32, depth=4, value_head_channels=16, policy_head_channels=16,
+                                      value_dense_layers=[512, 64], policy_dense_layers=[512, 256])),
+                    ('c4train', dict(num_channels=128, depth=8, value_head_channels=32, policy_head_channels=32,
+                                     value_dense_layers=[1024, 256], policy_dense_layers=[1024]))):
+        net = ResNet(Game, dotdict(a))
+        net.load_state_dict(fill_deterministic(net.state_dict()))
+        net.eval()
+        with torch.no_grad():
+            lp, lv = net(torch.from_numpy(obs))
+        out[name + '_policy'] = torch.exp(lp).numpy(); out[name + '_value'] = torch.exp(lv).numpy()
+        out[name + '_keys'] = np.array(sorted(net.state_dict().keys()))
+        out[name + '_shapes'] = np.array([str(tuple(net.state_dict()[k].shape)) for k in sorted(net.state_dict())])
+    np.savez_compressed(os.path.join(OUT, 'c4_net.npz'), **out)
+    print('c4_net: %d boards' % len(obs))
+
+
 def main():
     which = sys.argv[1:] or ['c4_rules', 'c4_tree', 'c4_agent', 'c4_arena']
     rh.import_reference()
@@ -346,6 +404,8 @@ def main():
         gen_agent(C4, ol.GAME_CONNECT4, 'c4')
     if 'c4_arena' in which:
         gen_arena(C4, ol.GAME_CONNECT4, 'c4')
+    if 'c4_net' in which:
+        gen_net()
     if 'br_rules' in which:
         gen_br_rules()
     if 'br_tree' in which:

@@ -105,3 +105,20 @@ def test_tower_multi_tile_loop_and_determinism():
         lp, lv = net.nnet(x[:300].to('cuda:0'))
     assert float((p[:300].cpu() - torch.exp(lp).cpu()).abs().max()) < 3e-3
     assert float((v[:300].cpu() - torch.exp(lv).cpu()).abs().max()) < 3e-3
+
+
+def test_mfma_tower_vs_reference_golden():
+    """the hand-written tower (fp16, MFMA) against outputs of the REFERENCE ResNet (fp32) on the committed fixture."""
+    import os
+    import torch
+    from test_nnet_cpu import fill_deterministic, G
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
+    d = np.load(os.path.join(G, 'c4_net.npz'))
+    w = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', backend='hip')
+    w.nnet.load_state_dict(fill_deterministic(w.nnet.state_dict()))
+    w.refresh()
+    assert w._hip is not None
+    p, v = w.process(torch.from_numpy(d['obs']))
+    assert float(np.abs(p.cpu().numpy() - d['c4train_policy']).max()) < 3e-3
+    assert float(np.abs(v.cpu().numpy() - d['c4train_value']).max()) < 3e-3

@@ -1,0 +1,57 @@
+"""The network architecture against the REFERENCE ResNet (alphazero/NNetArchitecture.py:69-120): golden outputs made by
+tests/golden/make_goldens.py with deterministic weights; checkpoint keys and shapes interchange.  CPU, fp32."""
+import os
+
+import numpy as np
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def fill_deterministic(sd):
+    out = {}
+    for i, k in enumerate(sorted(sd)):
+        t = sd[k]
+        if t.dtype in (torch.int64, torch.int32):
+            out[k] = t.clone()
+            continue
+        n = t.numel()
+        x = torch.sin(torch.arange(n, dtype=torch.float64) * 0.37 + i * 1.7)
+        if k.endswith('running_var'):
+            x = x.abs() * 0.8 + 0.4
+        elif k.endswith('running_mean') or k.endswith('.bias'):
+            x = x * 0.1
+        elif 'bn' in k and k.endswith('.weight'):
+            x = x * 0.3 + 1.0
+        else:
+            x = x * (1.5 / max(t[0].numel(), 1) ** 0.5)
+        out[k] = x.reshape(t.shape).to(t.dtype)
+    return out
+
+
+def _check(name, args):
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import FoldedResNet, NNetWrapper
+    d = np.load(os.path.join(G, 'c4_net.npz'))
+    w = NNetWrapper(Game, args, device='cpu', fast=False)
+    sd = w.nnet.state_dict()
+    assert sorted(sd.keys()) == list(d[name + '_keys'])                       # checkpoints interchange key for key
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(d[name + '_shapes'])
+    w.nnet.load_state_dict(fill_deterministic(sd))
+    x = torch.from_numpy(d['obs'])
+    p, v = w.process(x)
+    assert np.allclose(p.numpy(), d[name + '_policy'], atol=2e-6) and np.allclose(v.numpy(), d[name + '_value'], atol=2e-6)
+    fp, fv = FoldedResNet(w.nnet).eval()(x)                                   # BN folding + collapsed linear chains
+    assert np.allclose(fp.detach().numpy(), d[name + '_policy'], atol=2e-5) and np.allclose(fv.detach().numpy(), d[name + '_value'], atol=2e-5)
+    pp, pv = w.predict(d['obs'][0])
+    assert np.allclose(pp, d[name + '_policy'][0], atol=2e-6) and np.allclose(pv, d[name + '_value'][0], atol=2e-6)
+
+
+def test_default_net_vs_reference():
+    from alphazero_general_amd.nnet import DEFAULT_NET_ARGS
+    _check('default', DEFAULT_NET_ARGS)
+
+
+def test_connect4_train_net_vs_reference():
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS
+    _check('c4train', CONNECT4_NET_ARGS)
