@@ -188,13 +188,16 @@ struct TowerParams {
 // needs is that the 8 lanes {0-3,12-15} and the 8 lanes {4-11} of a fragment each cover all residues q mod 8; padded
 // rows are not consecutive, so the pixel -> (subtile, lane) assignment is a host-built table (tower_pixmap) that
 // deals every 8-lane set one pixel of each residue class.  The board stride (== 2 mod 8) makes the classes equal.
-template <int H, int W, int BOARDS>
+template <int H, int W, int BOARDS, int C = 128>
 struct TowerGeom {
     static constexpr int HW = H * W, ROWS = BOARDS * HW, NSUB = (ROWS + 15) / 16;
     static constexpr int PW = W + 2, LEAD = PW + 1;
     static constexpr int BS0 = (H + 1) * PW, BSTRIDE = BS0 + ((2 - BS0 % 8) + 8) % 8;     // == 2 (mod 8)
     static constexpr int TROWS = LEAD + (BOARDS - 1) * BSTRIDE + BS0 + PW + 1;
-    static constexpr int RSTRIDE = 288, TILE = TROWS * RSTRIDE;
+    // row stride = channels * 2 B + 32 B pad: RSTRIDE/16 == 2 (mod 4) puts chunk c of row q at slot (c + k q) mod 16 with k in
+    // {2,6,10,14} -- 288 B for 128 channels, 160 B for 64 (see the conflict-freeness argument above)
+    static constexpr int CH = C, KSC = C / 32, NW = C / 32, WSTEP = C * 4;   // k-steps per tap, waves, fragments (16 B) per k-step
+    static constexpr int RSTRIDE = 2 * C + 32, TILE = TROWS * RSTRIDE;
     static constexpr int BIAS = (PW + 1) * RSTRIDE;                          // makes every tap offset non-negative
     __host__ __device__ static __forceinline__ int qrow(int p) {             // padded row of pixel p (tile-local)
         const int b = p / HW, pos = p - b * HW, y = pos / W, x = pos - y * W;
@@ -452,8 +455,8 @@ struct FragOff {                                             // LDS immediate of
 template <class GEO, int KS, int NSUB, int RB>
 __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[2][2],
                                            floatx4 (&acc)[2][NSUB]) {
-    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = 4, RING = 6;
-    static_assert(NSUB == 11 || NSUB <= RING, "slot = ps % RING is collision-free with PF = 4 for NSUB = 11 (checked case by case)");
+    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = 4, RING = NSUB == 11 ? 6 : NSUB;
+    static_assert(NSUB == 11 || NSUB > PF, "slot = ps % 6 is collision-free with PF = 4 for NSUB = 11 (checked case by case); otherwise one slot per subtile");
     using FO = FragOff<GEO, KS, NSUB>;
     half8 bb[RING];                                          // fragment (kk, ps) lives in slot ps % RING, read PF fragments ahead
 #pragma unroll
@@ -461,7 +464,7 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
 #pragma clang loop unroll(full)
     for (int kk = 0; kk < NSTEP; kk++) {
         const int an = (RB + kk + 1) & 1, ac = (RB + kk) & 1;
-        a[an][0] = wfrag[(size_t)(kk + 1) * 512]; a[an][1] = wfrag[(size_t)(kk + 1) * 512 + 64];
+        a[an][0] = wfrag[(size_t)(kk + 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + 1) * GEO::WSTEP + 64];
 #pragma clang loop unroll(full)
         for (int ps = 0; ps < NSUB; ps++) {
             const int t = kk * NSUB + ps, psn = (ps + PF) % NSUB;
@@ -479,15 +482,16 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
     }
 }
 
-template <int H, int W, int BOARDS>
-__global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t *pixmap) {
-    using GEO = TowerGeom<H, W, BOARDS>;
+template <int H, int W, int BOARDS, int C>
+__global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_t *pixmap) {
+    using GEO = TowerGeom<H, W, BOARDS, C>;
+    constexpr int NT = C * 2, KS = C / 32, CPR = C / 8;      // threads (C/32 waves: 32 couts each), k-steps per tap, 16-B chunks per row
     constexpr int HW = GEO::HW, ROWS = GEO::ROWS, NSUB = GEO::NSUB, TILE = GEO::TILE, RS = GEO::RSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
-    for (int c = tid; c < TILE / 16; c += 256) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
+    for (int c = tid; c < TILE / 16; c += NT) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
     unsigned lb[NSUB];
     unsigned livemask = 0;
     const int ecol = (g & 1) ? (2 * wave + 1) * 16 + (g - 1) * 4 : (2 * wave) * 16 + g * 4;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t 
         const int rows_here = min(ROWS, P.boards * HW - row0);
         {
             const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
-            for (int c = tid; c < ROWS * 4; c += 256) {
+            for (int c = tid; c < ROWS * 4; c += NT) {
                 const int p = c >> 2, chunk = c & 3;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (chunk == 0 && p < rows_here) v = xg[p];
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t 
         a[0][0] = wt[0]; a[0][1] = wt[64];
         __syncthreads();
         for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
-            const float *bias = P.bias + (size_t)layer * 128;
+            const float *bias = P.bias + (size_t)layer * C;
             const bool is_s = (layer & 1) == 0;
             const int nb = layer >> 1;
             const bool has_next = nb < P.nblocks;
@@ -533,13 +537,13 @@ __global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t 
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
             }
-            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
-            else { conv_main2<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
+            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
+            else { conv_main2<GEO, KS, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
             half2v sc[4], sh[4];                                // (fetched here, not under the main loop: registers are the
 #pragma unroll                                                  //  scarce resource at 2 waves per SIMD, the co-resident wave hides it)
             for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
             if (is_s && has_next) {
-                const float *ps_ = P.pre_scale + (size_t)nb * 128 + ecol, *pt_ = P.pre_shift + (size_t)nb * 128 + ecol;
+                const float *ps_ = P.pre_scale + (size_t)nb * C + ecol, *pt_ = P.pre_shift + (size_t)nb * C + ecol;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
@@ -586,12 +590,12 @@ __global__ __launch_bounds__(256, 2) void k_tower2(TowerParams P, const int16_t 
             __syncthreads();
         }
         if (P.head_w == nullptr) {
-            uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * 16;
-            for (int c = tid; c < rows_here * 16; c += 256) {
-                const int p = c >> 4, chunk = c & 15;
+            uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * CPR;
+            for (int c = tid; c < rows_here * CPR; c += NT) {
+                const int p = c / CPR, chunk = c - p * CPR;
                 yg[c] = *reinterpret_cast<const uint4 *>(img + GEO::qrow(p) * RS + chunk * 16);
             }
-        } else {
+        } else if constexpr (C == 128) {
             floatx4 hacc = {0.f, 0.f, 0.f, 0.f};
             const bool bvalid = i16 < BOARDS;
             const unsigned bbase = (unsigned)((GEO::LEAD + (bvalid ? i16 : 0) * GEO::BSTRIDE) * RS + g * 16);

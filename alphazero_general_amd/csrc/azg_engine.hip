@@ -511,10 +511,9 @@ extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void
     }
 }
 
-template <int H, int W, int BOARDS>
+template <int H, int W, int BOARDS, int C>
 static int launch_tower(hipStream_t s, const TowerParams &P) {
-    using GEO = TowerGeom<H, W, BOARDS>;
-    const size_t lds = (size_t)2 * GEO::TILE;
+    using GEO = TowerGeom<H, W, BOARDS, C>;
     static int16_t *d_map[16] = {nullptr};                                  // per device: pixel -> (subtile, lane) table
     int dev = 0, cus = 256;
     HIPCHK(hipGetDevice(&dev));
@@ -524,35 +523,41 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
         tower_pixmap<GEO>(map);
         HIPCHK(hipMalloc((void **)&d_map[dev], sizeof(map)));
         HIPCHK(hipMemcpy(d_map[dev], map, sizeof(map), hipMemcpyHostToDevice));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
+        if constexpr (C == 128)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)GEO::TILE));
     }
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
     static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
-    if (variant == 2) {                                      // one LDS image, two workgroups per CU
-        static bool attr2 = false;
-        const size_t lds2 = (size_t)GEO::TILE;
-        if (!attr2) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); attr2 = true; }
-        const int grid2 = ntiles < 2 * cus ? ntiles : 2 * cus;
-        hipLaunchKernelGGL((k_tower2<H, W, BOARDS>), dim3(grid2), dim3(256), lds2, s, P, (const int16_t *)d_map[dev]);
-        HIPCHK(hipGetLastError());
-        return AZG_OK;
+    if (C == 128 && variant == 1) {                          // one workgroup per CU, two LDS images, deep prefetch
+        if constexpr (C == 128) {
+            const int grid = ntiles < cus ? ntiles : cus;
+            hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), (size_t)2 * GEO::TILE, s, P, (const int16_t *)d_map[dev]);
+        }
+    } else {                                                 // one LDS image, residual stream in registers, >= 2 workgroups per CU
+        const int per_cu = (int)(160 * 1024 / GEO::TILE) > 0 ? (int)(160 * 1024 / GEO::TILE) : 1;
+        const int grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
+        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C>), dim3(grid), dim3(C * 2), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev]);
     }
-    const int grid = ntiles < cus ? ntiles : cus;
-    hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), lds, s, P, (const int16_t *)d_map[dev]);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }
 
+static int dispatch_tower(hipStream_t s, int game, int channels, const TowerParams &P) {
+    if (game == AZG_GAME_CONNECT4 && channels == 128) return launch_tower<C4::H, C4::W, 4, 128>(s, P);
+    if (game == AZG_GAME_CONNECT4 && channels == 64) return launch_tower<C4::H, C4::W, 4, 64>(s, P);
+    if (game == AZG_GAME_BRANDUBH && channels == 64) return launch_tower<BR::H, BR::W, 2, 64>(s, P);
+    if (game == AZG_GAME_BRANDUBH && channels == 128) return launch_tower<BR::H, BR::W, 2, 128>(s, P);
+    return fail(AZG_E_UNSUPPORTED, "no MFMA tower for this game / channel count (supported: connect4, brandubh x 64, 128 channels)");
+}
+
 extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
-                                    const float *pre_shift, void *y, int boards, int nblocks) {
+                                    const float *pre_shift, void *y, int boards, int nblocks, int channels) {
     if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
-    switch (game) {
-    case AZG_GAME_CONNECT4: return launch_tower<C4::H, C4::W, 4>((hipStream_t)stream, P);
-    default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
-    }
+    return dispatch_tower((hipStream_t)stream, game, channels, P);
 }
 
 extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
@@ -562,24 +567,7 @@ extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x
     if (A <= 0 || NV <= 0 || A + NV > 16) return fail(AZG_E_UNSUPPORTED, "fused heads need A + NV <= 16");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr};
-#ifdef AZG_TOWER_TIMING
-    static unsigned long long *d_dbg = nullptr;
-    if (!d_dbg) { HIPCHK(hipMalloc((void **)&d_dbg, 8 * 5 * 4 * 64)); }
-    P.dbg = d_dbg;
-    if (getenv("AZG_TOWER_DUMP")) {
-        HIPCHK(hipDeviceSynchronize());
-        unsigned long long h[5 * 4 * 64];
-        HIPCHK(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
-        for (int l = 0; l <= 2 * nblocks; l++) for (int wv = 0; wv < 4; wv++) {
-            unsigned long long *t = h + (l * 4 + wv) * 5;
-            printf("layer %2d wave %d main %6llu bar1 %6llu epi %6llu bar2 %6llu\n", l, wv, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]);
-        }
-    }
-#endif
-    switch (game) {
-    case AZG_GAME_CONNECT4: return launch_tower<C4::H, C4::W, 4>((hipStream_t)stream, P);
-    default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
-    }
+    return dispatch_tower((hipStream_t)stream, game, 128, P);
 }
 
 extern "C" int azg_profile_enable(azg_engine *e, int on) {

@@ -137,10 +137,10 @@ def pack_conv_weight(w, ks):
     """[128, Cin, 3, 3] float -> fp16 MFMA A-fragment order [9 taps][ks][8 cout-subtiles][64 lanes][8] that
     csrc/azg_conv.h reads: lane = g*16 + i holds W[cout = ms*16 + i, cin = ks*32 + g*8 + j, tap]."""
     cout, cin = w.shape[0], w.shape[1]
-    assert cout == 128 and cin <= ks * 32
+    assert cout % 32 == 0 and cin <= ks * 32
     wp = torch.zeros((cout, ks * 32, 3, 3), dtype=torch.float32, device=w.device)
     wp[:, :cin] = w.float()
-    t = wp.permute(2, 3, 0, 1).reshape(9, 8, 16, ks, 4, 8)            # [tap, ms, i, ks, g, j]
+    t = wp.permute(2, 3, 0, 1).reshape(9, cout // 16, 16, ks, 4, 8)   # [tap, ms, i, ks, g, j]
     return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1).to(torch.float16)
 
 
@@ -157,7 +157,8 @@ class HipResNet:
         self._check = _abi.check
         C, H, W = folded.shape
         self.C, self.HW = C, H * W
-        assert folded.stem_w.shape[0] == 128 and C <= 8, 'the MFMA tower is built for 128 channels'
+        self.CH = CH = int(folded.stem_w.shape[0])                      # tower width
+        assert CH in (64, 128) and C <= 8, 'the MFMA tower is built for 64 or 128 channels'
         f32 = dict(dtype=torch.float32, device=self.device)
         with torch.no_grad():
             self.stem_w = pack_conv_weight(folded.stem_w.float(), 1).to(self.device)
@@ -167,19 +168,19 @@ class HipResNet:
                 self.blocks.append(dict(
                     ps=folded.pre_scale[i].float().reshape(-1).to(**f32).contiguous(),
                     pt=folded.pre_shift[i].float().reshape(-1).to(**f32).contiguous(),
-                    w1=pack_conv_weight(folded.w1[i].float(), 4).to(self.device), b1=folded.b1[i].float().to(**f32).contiguous(),
-                    w2=pack_conv_weight(folded.w2[i].float(), 4).to(self.device)))
-            self.zero_b = torch.zeros(128, **f32)
+                    w1=pack_conv_weight(folded.w1[i].float(), CH // 32).to(self.device), b1=folded.b1[i].float().to(**f32).contiguous(),
+                    w2=pack_conv_weight(folded.w2[i].float(), CH // 32).to(self.device)))
+            self.zero_b = torch.zeros(CH, **f32)
             # the same parameters laid out for the fused persistent tower (azg_resnet_tower_f16)
             self.tower_w = torch.cat([self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])] +
-                                     [torch.zeros(3 * 512 * 8, dtype=torch.float16, device=self.device)]).contiguous()   # ring slack
+                                     [torch.zeros(3 * CH * 4 * 8, dtype=torch.float16, device=self.device)]).contiguous()   # ring slack
             self.tower_b = torch.stack([self.stem_b] + [t for b in self.blocks for t in (b['b1'], self.zero_b)]).contiguous()
             nb = len(self.blocks)
-            self.tower_ps = torch.stack([b['ps'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, 128), **f32)
-            self.tower_pt = torch.stack([b['pt'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, 128), **f32)
+            self.tower_ps = torch.stack([b['ps'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, CH), **f32)
+            self.tower_pt = torch.stack([b['pt'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, CH), **f32)
             self.fused = True
             # heads: logits[b, o] = sum_{pos,k} s[b,pos,k] * Wfull[pos*128+k, o] + bfull[o]
-            hw, hb = folded.head_w.float().reshape(-1, 128), folded.head_b.float()           # [vc+pc, 128], [vc+pc]
+            hw, hb = folded.head_w.float().reshape(-1, CH), folded.head_b.float()            # [vc+pc, CH], [vc+pc]
             vc = folded.vc
             Wv, bv = folded.v_fc.weight.float(), folded.v_fc.bias.float()                     # [NV, vc*HW] (index c*HW+pos)
             Wp, bp = folded.pi_fc.weight.float(), folded.pi_fc.bias.float()
@@ -187,11 +188,11 @@ class HipResNet:
             fv = torch.einsum('ocp,ck->pko', Wv.reshape(NV, vc, HW), hw[:vc])                 # [HW, 128, NV]
             fp = torch.einsum('ocp,ck->pko', Wp.reshape(A, -1, HW), hw[vc:])                  # [HW, 128, A]
             self.A, self.NV = A, NV
-            self.head_w = torch.cat([fp, fv], dim=2).reshape(HW * 128, A + NV).to(self.device, torch.float16).contiguous()
+            self.head_w = torch.cat([fp, fv], dim=2).reshape(HW * CH, A + NV).to(self.device, torch.float16).contiguous()
             bfv = bv + torch.einsum('ocp,c->o', Wv.reshape(NV, vc, HW), hb[:vc])
             bfp = bp + torch.einsum('ocp,c->o', Wp.reshape(A, -1, HW), hb[vc:])
             self.head_b = torch.cat([bfp, bfv]).to(**f32).contiguous()
-            self.fused_head = (A + NV) <= 16
+            self.fused_head = (A + NV) <= 16 and CH == 128
             if self.fused_head:                                  # MFMA fragment order for the in-tower heads
                 wf = torch.zeros((HW, 128, 16), dtype=torch.float32, device=fp.device)
                 wf[:, :, :A + NV] = torch.cat([fp, fv], dim=2)
@@ -204,7 +205,7 @@ class HipResNet:
 
     def _buffers(self, B, key=0):
         if (B, key) not in self._bufs:
-            mk = lambda: torch.empty((B * self.HW, 128), dtype=torch.float16, device=self.device)
+            mk = lambda: torch.empty((B * self.HW, self.CH), dtype=torch.float16, device=self.device)
             self._bufs[(B, key)] = (mk(), mk(), mk())
         return self._bufs[(B, key)]
 
@@ -237,14 +238,14 @@ class HipResNet:
             vp = lambda q: C.c_void_p(q.data_ptr())
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             self._check(self.L.azg_resnet_tower_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
-                                                    vp(self.tower_pt), vp(s), int(B), len(self.blocks)))
+                                                    vp(self.tower_pt), vp(s), int(B), len(self.blocks), int(self.CH)))
         else:                                                    # one launch per convolution
             self._conv(x, self.stem_w, self.stem_b, s, B, stem=True, relu=True)
             for blk in self.blocks:
                 self._conv(s, blk['w1'], blk['b1'], u, B, pre=(blk['ps'], blk['pt']), relu=True)
                 self._conv(u, blk['w2'], self.zero_b, t, B, res=s, relu=False)
                 s, t = t, s
-        logits = torch.matmul(s.view(B, self.HW * 128), self.head_w).float() + self.head_b
+        logits = torch.matmul(s.view(B, self.HW * self.CH), self.head_w).float() + self.head_b
         return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
 
     def to_nhwc8(self, batch):
@@ -297,7 +298,8 @@ class NNetWrapper:
             net = net.to(memory_format=torch.channels_last)
         self._infer, self._graph, self._hip = net.eval(), None, None
         use_hip = self.backend == 'hip' or (self.backend == 'auto' and self.device.type == 'cuda'
-                                            and self.args.num_channels == 128 and getattr(self.game_cls, 'AZG_GAME_ID', None) == 0)
+                                            and self.args.num_channels in (64, 128)
+                                            and getattr(self.game_cls, 'AZG_GAME_ID', None) in (0, 1))
         if use_hip:
             self._hip = HipResNet(FoldedResNet(self.nnet).to(self.device), self.game_cls.AZG_GAME_ID, self.device)
         return self

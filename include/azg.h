@@ -196,7 +196,8 @@ int  azg_conv3x3_f16(void *stream, int game, const void *x_dev, const void *w_pa
  * bias: f32 [1 + 2*nblocks][128] (stem, then b1, b2 per block); pre_scale/pre_shift: f32 [nblocks][128];
  * y: [boards*H*W, 128] fp16 = the final residual stream (input of the collapsed heads GEMM). */
 int  azg_resnet_tower_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
-                          const float *pre_scale_dev, const float *pre_shift_dev, void *y_dev, int boards, int nblocks);
+                          const float *pre_scale_dev, const float *pre_shift_dev, void *y_dev, int boards, int nblocks,
+                          int channels /* 128 or 64; every array above is sized by it instead of 128 */);
 /* The tower with both heads fused behind it (A + NV <= 16): head_w_packed = the collapsed heads matrix
  * Wfull[H*W*128, A+NV] in MFMA fragment order [H*W][4][64 lanes][8 halves] (nnet.pack_head_weight), head_b f32[16];
  * writes softmax probabilities policy f32[boards, A] and value f32[boards, NV] -- what NNetWrapper.process returns

@@ -122,3 +122,31 @@ def test_mfma_tower_vs_reference_golden():
     p, v = w.process(torch.from_numpy(d['obs']))
     assert float(np.abs(p.cpu().numpy() - d['c4train_policy']).max()) < 3e-3
     assert float(np.abs(v.cpu().numpy() - d['c4train_value']).max()) < 3e-3
+
+
+def test_mfma_tower_brandubh_64ch_vs_fp32_reference():
+    """the same tower kernel at 64 channels on the 7x7 board (brandubh net of envs/hnefatafl/train_brandubh.py:50-55),
+    heads unfused (A + NV = 591)."""
+    import torch
+    from alphazero_general_amd.envs.brandubh import Game
+    from alphazero_general_amd.nnet import BRANDUBH_NET_ARGS, NNetWrapper
+    torch.manual_seed(9)
+    net = NNetWrapper(Game, BRANDUBH_NET_ARGS, device='cuda:0', backend='hip')
+    _randomize(net.nnet.cpu(), torch, seed=5); net.nnet.to('cuda:0'); net.refresh()
+    assert net._hip is not None and net._hip.CH == 64 and not net._hip.fused_head
+    rng = np.random.RandomState(1)
+    obs = []
+    for b in range(301):
+        g = Game()
+        for _ in range(rng.randint(0, 40)):
+            if g.win_state().any():
+                break
+            g.play_action(int(rng.choice(np.flatnonzero(g.valid_moves()))))
+        obs.append(g.observation())
+    x = torch.from_numpy(np.array(obs, np.float32))
+    with torch.no_grad():
+        lp, lv = net.nnet(x.to('cuda:0'))
+    p, v = net.process(x)
+    assert p.shape == (301, 588) and v.shape == (301, 3)
+    assert float((p.cpu() - torch.exp(lp).cpu()).abs().max()) < 3e-3
+    assert float((v.cpu() - torch.exp(lv).cpu()).abs().max()) < 3e-3
