@@ -452,25 +452,35 @@ struct FragOff {                                             // LDS immediate of
     }
 };
 
-template <class GEO, int KS, int NSUB, int RB>
-__device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[2][2],
+// weight ring depth: a k-step of a small tile (NSUB <= 4: 6-8 MFMAs) is far shorter than an L2 round trip, so the small
+// shapes fetch 8 k-steps ahead; the big ones (22 MFMAs per k-step, registers scarce) one.  9 divides every layer's k-step count,
+// so the 9-deep ring always starts a layer at slot 0; the 2-deep one starts layers >= 1 at slot 9 % 2.
+template <int NSUB> struct WeightRing { static constexpr int N = NSUB <= 4 ? 9 : 2; };
+
+template <class GEO, int KS, int NSUB, int RB, int WR>
+__device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[WR][2],
                                            floatx4 (&acc)[2][NSUB]) {
-    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = 4, RING = NSUB == 11 ? 6 : NSUB;
-    static_assert(NSUB == 11 || NSUB > PF, "slot = ps % 6 is collision-free with PF = 4 for NSUB = 11 (checked case by case); otherwise one slot per subtile");
+    // fragment t = (kk, ps) is read PF fragments ahead into a register ring.  Large tiles index the ring by subtile (slot
+    // ps % RING: collision-free with PF = 4 for NSUB = 11 at RING = 6, checked case by case; one slot per subtile otherwise);
+    // small tiles (NSUB <= PF, the low-latency shapes for small batches) by fragment number, RING = PF + 1
+    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = 4;
+    constexpr bool TRING = NSUB <= PF;
+    constexpr int RING = TRING ? PF + 1 : NSUB == 11 ? 6 : NSUB;
     using FO = FragOff<GEO, KS, NSUB>;
-    half8 bb[RING];                                          // fragment (kk, ps) lives in slot ps % RING, read PF fragments ahead
+    half8 bb[RING];
 #pragma unroll
-    for (int t = 0; t < PF; t++) bb[t % RING] = *reinterpret_cast<const half8 *>(in + lb[t] + FO::get(t));
+    for (int t = 0; t < PF; t++) bb[(TRING ? t : t % NSUB) % RING] = *reinterpret_cast<const half8 *>(in + lb[t % NSUB] + FO::get(t));
 #pragma clang loop unroll(full)
     for (int kk = 0; kk < NSTEP; kk++) {
-        const int an = (RB + kk + 1) & 1, ac = (RB + kk) & 1;
-        a[an][0] = wfrag[(size_t)(kk + 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + 1) * GEO::WSTEP + 64];
+        const int an = (RB + kk + WR - 1) % WR, ac = (RB + kk) % WR;
+        a[an][0] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP + 64];
 #pragma clang loop unroll(full)
         for (int ps = 0; ps < NSUB; ps++) {
             const int t = kk * NSUB + ps, psn = (ps + PF) % NSUB;
-            if (t + PF < TOT) bb[psn % RING] = *reinterpret_cast<const half8 *>(in + lb[psn] + FO::get(t + PF));
-            acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[ps % RING], acc[0][ps], 0, 0, 0);
-            acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[ps % RING], acc[1][ps], 0, 0, 0);
+            const int cur = (TRING ? t : ps) % RING, nxt = (TRING ? t + PF : psn) % RING;
+            if (t + PF < TOT) bb[nxt] = *reinterpret_cast<const half8 *>(in + lb[psn] + FO::get(t + PF));
+            acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur], acc[0][ps], 0, 0, 0);
+            acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur], acc[1][ps], 0, 0, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 #pragma unroll
@@ -504,7 +514,8 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
     }
     const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
     const unsigned edelta = (unsigned)(GEO::BIAS - g * 16 + ecol * 2);      // epilogue cell of a pixel = fragment base + edelta
-    half8 a[2][2];
+    constexpr int WR = WeightRing<NSUB>::N;
+    half8 a[WR][2];
     floatx4 acc[2][NSUB];
     half2v sreg[NSUB][4];
     __syncthreads();
@@ -522,7 +533,8 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
             }
         }
         const half8 *wt = wl;
-        a[0][0] = wt[0]; a[0][1] = wt[64];
+#pragma unroll
+        for (int j = 0; j < WR - 1; j++) { a[j][0] = wt[(size_t)j * GEO::WSTEP]; a[j][1] = wt[(size_t)j * GEO::WSTEP + 64]; }
         __syncthreads();
         for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
             const float *bias = P.bias + (size_t)layer * C;
@@ -537,8 +549,8 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
             }
-            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
-            else { conv_main2<GEO, KS, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
+            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
+            else { conv_main2<GEO, KS, NSUB, 9 % WR, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
             half2v sc[4], sh[4];                                // (fetched here, not under the main loop: registers are the
 #pragma unroll                                                  //  scarce resource at 2 waves per SIMD, the co-resident wave hides it)
             for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
@@ -639,6 +651,74 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
         }
         __syncthreads();
     }
+}
+
+// ---- collapsed heads for large action spaces (brandubh: A + NV = 591) ------------------------------------------------------
+// logits[b, o] = sum_k y[b, k] * Wh[k, o] + bias[o] over the tower's final stream y [boards, K = H*W*C] (fp16 rows), then the
+// two softmaxes of NNetArchitecture.py:112-118.  Too wide to fuse behind the tower (every tile would stream the whole 3.7 MB
+// matrix), so it is its own launch: workgroup = (16 boards) x (HEAD_NS output subtiles of 16); its four waves split K, each
+// streaming activation fragments (A operand: 16 boards x 32 k) and pre-packed weight fragments (B operand: 32 k x 16 outputs,
+// [k-step][subtile][64 lanes][8 halves]) straight from L2 -- no reuse inside a workgroup, so no LDS staging.  With
+// blockIdx = group * nchunks + chunk and 8 chunks, the workgroups sharing a weight chunk sit on one XCD (blockIdx mod 8).
+// The job is L2->CU bandwidth bound: (HEAD_NS*16 + 16) * K * 2 bytes per workgroup.
+constexpr int HEAD_NS = 5;
+
+__global__ __launch_bounds__(256) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
+                                               int ksteps, int osub) {
+    __shared__ float red[4][HEAD_NS * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int nchunks = (osub + HEAD_NS - 1) / HEAD_NS, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
+    const int b0 = grp * 16, s0 = chunk * HEAD_NS, opad = osub * 16;
+    const size_t K8 = (size_t)ksteps * 4;                                     // half8 per board row
+    const half8 *yrow = reinterpret_cast<const half8 *>(y) + (size_t)min(b0 + i16, boards - 1) * K8 + g;
+    const half8 *wl = wp + (size_t)s0 * 64 + lane;
+    floatx4 acc[HEAD_NS];
+#pragma unroll
+    for (int s = 0; s < HEAD_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int ks = wave; ks < ksteps; ks += 4) {
+        const half8 a = yrow[(size_t)ks * 4];
+        half8 b[HEAD_NS];
+#pragma unroll
+        for (int s = 0; s < HEAD_NS; s++) b[s] = s0 + s < osub ? wl[((size_t)ks * osub + s) * 64] : zero8;
+#pragma unroll
+        for (int s = 0; s < HEAD_NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[s], acc[s], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < HEAD_NS; s++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][(s * 4 + r) * 64 + lane] = acc[s][r];
+    __syncthreads();
+    for (int e = tid; e < HEAD_NS * 256; e += 256) {                          // D[m = board g*4 + r][n = output i16]
+        const int s = e >> 8, r = (e >> 6) & 3, ln = e & 63, board = b0 + (ln >> 4) * 4 + r, out = (s0 + s) * 16 + (ln & 15);
+        if (board < boards && s0 + s < osub)
+            logits[(size_t)board * opad + out] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + bias[out];
+    }
+}
+
+// one wave per board: softmax over the A policy logits and over the NV value logits
+__global__ __launch_bounds__(256) void k_heads_softmax(const float *logits, float *policy, float *value, int boards, int opad, int A, int NV) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= boards) return;
+    const float *lg = logits + (size_t)b * opad;
+    float m = -INFINITY;
+    for (int o = lane; o < A; o += 64) m = fmaxf(m, lg[o]);
+#pragma unroll
+    for (int d = 32; d; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    float sum = 0.f;
+    for (int o = lane; o < A; o += 64) sum += __expf(lg[o] - m);
+#pragma unroll
+    for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+    for (int o = lane; o < A; o += 64) policy[(size_t)b * A + o] = __expf(lg[o] - m) / sum;
+    float v = lane < NV ? lg[A + lane] : -INFINITY, vm = v;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) vm = fmaxf(vm, __shfl_xor(vm, d));
+    const float ev = lane < NV ? __expf(v - vm) : 0.f;
+    float vs = ev;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) vs += __shfl_xor(vs, d);
+    if (lane < NV) value[(size_t)b * NV + lane] = ev / vs;
 }
 
 // leaf observation planes [B, C, H, W] (any of the engine's obs dtypes) are written by k_select directly as the stem's

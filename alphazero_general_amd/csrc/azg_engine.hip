@@ -544,10 +544,23 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
     return AZG_OK;
 }
 
+// Boards per workgroup tile: the big tile has the least MFMA padding, small ones fill the chip at small batches (the arena,
+// the single-tree API, brandubh's 512 games per GPU).  AZG_TOWER_BOARDS overrides the choice (measurement knob).
 static int dispatch_tower(hipStream_t s, int game, int channels, const TowerParams &P) {
-    if (game == AZG_GAME_CONNECT4 && channels == 128) return launch_tower<C4::H, C4::W, 4, 128>(s, P);
+    static const int forced = getenv("AZG_TOWER_BOARDS") ? atoi(getenv("AZG_TOWER_BOARDS")) : 0;
+    const int n = P.boards;
+    if (game == AZG_GAME_CONNECT4 && channels == 128) {
+        const int bt = forced ? forced : n <= 640 ? 1 : n <= 1280 ? 2 : 4;
+        if (bt == 1) return launch_tower<C4::H, C4::W, 1, 128>(s, P);
+        if (bt == 2) return launch_tower<C4::H, C4::W, 2, 128>(s, P);
+        return launch_tower<C4::H, C4::W, 4, 128>(s, P);
+    }
     if (game == AZG_GAME_CONNECT4 && channels == 64) return launch_tower<C4::H, C4::W, 4, 64>(s, P);
-    if (game == AZG_GAME_BRANDUBH && channels == 64) return launch_tower<BR::H, BR::W, 2, 64>(s, P);
+    if (game == AZG_GAME_BRANDUBH && channels == 64) {
+        const int bt = forced ? forced : n <= 1024 ? 1 : 2;
+        if (bt == 1) return launch_tower<BR::H, BR::W, 1, 64>(s, P);
+        return launch_tower<BR::H, BR::W, 2, 64>(s, P);
+    }
     if (game == AZG_GAME_BRANDUBH && channels == 128) return launch_tower<BR::H, BR::W, 2, 128>(s, P);
     return fail(AZG_E_UNSUPPORTED, "no MFMA tower for this game / channel count (supported: connect4, brandubh x 64, 128 channels)");
 }
@@ -568,6 +581,19 @@ extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr};
     return dispatch_tower((hipStream_t)stream, game, 128, P);
+}
+
+extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,
+                                          int A, int NV, float *logits_ws, float *policy, float *value) {
+    if (!y || !head_w_packed || !head_b || !logits_ws || !policy || !value) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (boards <= 0 || k <= 0 || (k & 31) || A <= 0 || NV <= 0 || NV > 64) return fail(AZG_E_INVALID_ARG, "boards > 0, k a multiple of 32, 0 < NV <= 64");
+    const int osub = (A + NV + 15) / 16, nchunks = (osub + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_heads, dim3(groups * nchunks), dim3(256), 0, s, (const _Float16 *)y, (const half8 *)head_w_packed, head_b, logits_ws,
+                       boards, k / 32, osub);
+    hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
 }
 
 extern "C" int azg_profile_enable(azg_engine *e, int on) {

@@ -173,7 +173,7 @@ class HipResNet:
             self.zero_b = torch.zeros(CH, **f32)
             # the same parameters laid out for the fused persistent tower (azg_resnet_tower_f16)
             self.tower_w = torch.cat([self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])] +
-                                     [torch.zeros(3 * CH * 4 * 8, dtype=torch.float16, device=self.device)]).contiguous()   # ring slack
+                                     [torch.zeros(9 * CH * 4 * 8, dtype=torch.float16, device=self.device)]).contiguous()   # ring slack (<= 8 k-steps)
             self.tower_b = torch.stack([self.stem_b] + [t for b in self.blocks for t in (b['b1'], self.zero_b)]).contiguous()
             nb = len(self.blocks)
             self.tower_ps = torch.stack([b['ps'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, CH), **f32)
@@ -201,6 +201,17 @@ class HipResNet:
                                        .to(self.device, torch.float16).contiguous()
                 self.head_b16 = torch.zeros(16, **f32)
                 self.head_b16[:A + NV] = self.head_b
+            else:                                                # own launch (azg_policy_value_heads_f16): [k/32][OS][64 lanes][8]
+                OS, KS = (A + NV + 15) // 16, HW * CH // 32
+                wf = torch.zeros((HW * CH, OS * 16), dtype=torch.float32, device=fp.device)
+                wf[:, :A + NV] = torch.cat([fp, fv], dim=2).reshape(HW * CH, A + NV)
+                # [k = ks*32 + g*8 + j, out = sub*16 + i] -> [ks][sub][g][i][j]
+                self.head_w_wide = wf.reshape(KS, 4, 8, OS, 16).permute(0, 3, 1, 4, 2).contiguous().reshape(-1) \
+                                     .to(self.device, torch.float16).contiguous()
+                self.head_b_wide = torch.zeros(OS * 16, **f32)
+                self.head_b_wide[:A + NV] = self.head_b
+                self.head_opad = OS * 16
+            self.wide_head = not self.fused_head
         self._bufs = {}
 
     def _buffers(self, B, key=0):
@@ -245,6 +256,17 @@ class HipResNet:
                 self._conv(s, blk['w1'], blk['b1'], u, B, pre=(blk['ps'], blk['pt']), relu=True)
                 self._conv(u, blk['w2'], self.zero_b, t, B, res=s, relu=False)
                 s, t = t, s
+        if self.wide_head:                                       # heads GEMM + both softmaxes: two launches
+            import ctypes as C
+            vp = lambda q: C.c_void_p(q.data_ptr())
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if ('pvw', B, key) not in self._bufs:
+                mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=self.device)
+                self._bufs[('pvw', B, key)] = (mk(self.A), mk(self.NV), mk(self.head_opad))
+            pol, val, ws = self._bufs[('pvw', B, key)]
+            self._check(self.L.azg_policy_value_heads_f16(st, vp(s), vp(self.head_w_wide), vp(self.head_b_wide), int(B), self.HW * self.CH,
+                                                          int(self.A), int(self.NV), vp(ws), vp(pol), vp(val)))
+            return pol, val
         logits = torch.matmul(s.view(B, self.HW * self.CH), self.head_w).float() + self.head_b
         return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
 

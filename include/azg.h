@@ -192,9 +192,11 @@ int  azg_conv3x3_f16(void *stream, int game, const void *x_dev, const void *w_pa
                      int boards, int stem, int relu);
 
 /* The whole residual tower (stem + 2*nblocks convolutions) in ONE persistent launch with activations resident in
- * LDS (csrc/azg_conv.h k_tower).  x: [boards*H*W, 8] fp16; w_packed: stem fragments then conv1, conv2 of every block;
- * bias: f32 [1 + 2*nblocks][128] (stem, then b1, b2 per block); pre_scale/pre_shift: f32 [nblocks][128];
- * y: [boards*H*W, 128] fp16 = the final residual stream (input of the collapsed heads GEMM). */
+ * LDS (csrc/azg_conv.h k_tower2), `channels` = 64 or 128 wide (C below).  x: [boards*H*W, 8] fp16; w_packed: stem fragments
+ * then conv1, conv2 of every block, followed by 9 k-steps (9 * C*32 halves) of readable slack -- the weight prefetch ring
+ * runs past the last layer; bias: f32 [1 + 2*nblocks][C] (stem, then b1, b2 per block); pre_scale/pre_shift: f32 [nblocks][C];
+ * y: [boards*H*W, C] fp16 = the final residual stream (input of the collapsed heads GEMM).
+ * The kernel evaluates 1, 2 or 4 boards per workgroup tile, chosen by `boards` (small batches: small tiles, more workgroups). */
 int  azg_resnet_tower_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
                           const float *pre_scale_dev, const float *pre_shift_dev, void *y_dev, int boards, int nblocks,
                           int channels /* 128 or 64; every array above is sized by it instead of 128 */);
@@ -206,6 +208,13 @@ int  azg_resnet_policy_value_f16(void *stream, int game, const void *x_dev, cons
                                  const float *pre_scale_dev, const float *pre_shift_dev, int boards, int nblocks,
                                  const void *head_w_packed_dev, const float *head_b_dev, int A, int NV,
                                  float *policy_dev, float *value_dev);
+
+/* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same
+ * [k = H*W*C, A+NV] matrix applied to the final stream y [boards, k] fp16 that azg_resnet_tower_f16 stores, then the
+ * two softmaxes.  head_w_packed: fragment order [k/32][OS = ceil((A+NV)/16)][64 lanes][8 halves], lane g*16+i, half j
+ * = Wfull[ks*32 + g*8 + j, sub*16 + i] (zero beyond A+NV); head_b: f32[OS*16]; logits_ws: f32[boards * OS*16] scratch. */
+int  azg_policy_value_heads_f16(void *stream, const void *y_dev, const void *head_w_packed_dev, const float *head_b_dev,
+                                int boards, int k, int A, int NV, float *logits_ws_dev, float *policy_dev, float *value_dev);
 
 /* ---- timing hooks for bench.py (HIP events on `stream` around the engine's own kernels) -------------------- */
 int  azg_profile_enable(azg_engine *e, int on);

@@ -150,3 +150,43 @@ def test_mfma_tower_brandubh_64ch_vs_fp32_reference():
     assert p.shape == (301, 588) and v.shape == (301, 3)
     assert float((p.cpu() - torch.exp(lp).cpu()).abs().max()) < 3e-3
     assert float((v.cpu() - torch.exp(lv).cpu()).abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize('game', ['connect4', 'brandubh'])
+def test_tower_tile_shapes_agree(game):
+    """the tower picks 1, 2 or 4 boards per workgroup tile by batch size; a board's outputs must not depend on the tile it
+    is evaluated in (same MFMA accumulation order per pixel): bit-identical across the shapes."""
+    import torch
+    if game == 'connect4':
+        from alphazero_general_amd.envs.connect4 import Game
+        from alphazero_general_amd.nnet import CONNECT4_NET_ARGS as NA, NNetWrapper
+        base, sizes = _boards(torch, 200, seed=11), (200, 900, 1400)      # 1, 2, 4 boards per tile
+    else:
+        from alphazero_general_amd.envs.brandubh import Game
+        from alphazero_general_amd.nnet import BRANDUBH_NET_ARGS as NA, NNetWrapper
+        rng = np.random.RandomState(2)
+        obs = []
+        for b in range(200):
+            g = Game()
+            for _ in range(rng.randint(0, 30)):
+                if g.win_state().any():
+                    break
+                g.play_action(int(rng.choice(np.flatnonzero(g.valid_moves()))))
+            obs.append(g.observation())
+        base, sizes = torch.from_numpy(np.array(obs, np.float32)), (200, 1100)   # 1, 2 boards per tile
+    torch.manual_seed(13)
+    net = NNetWrapper(Game, NA, device='cuda:0', backend='hip')
+    _randomize(net.nnet.cpu(), torch, seed=6); net.nnet.to('cuda:0'); net.refresh()
+    outs = []
+    for n in sizes:
+        x = base.repeat((n + 199) // 200, 1, 1, 1)[:n]
+        p, v = net.process(x)
+        outs.append((p[:200].clone(), v[:200].clone()))
+    with torch.no_grad():
+        lp, lv = net.nnet(base.to('cuda:0'))
+    assert float((outs[0][0].cpu() - torch.exp(lp).cpu()).abs().max()) < 3e-3
+    for p, v in outs[1:]:
+        if game == 'connect4':                     # heads fused in the kernel: the whole evaluation is tile-independent
+            assert torch.equal(p, outs[0][0]) and torch.equal(v, outs[0][1])
+        else:                                      # heads GEMM is a library call whose k-split depends on the batch size
+            assert float((p - outs[0][0]).abs().max()) < 1e-4 and float((v - outs[0][1]).abs().max()) < 1e-4
