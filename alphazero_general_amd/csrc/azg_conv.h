@@ -515,11 +515,18 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
     const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
     const unsigned edelta = (unsigned)(GEO::BIAS - g * 16 + ecol * 2);      // epilogue cell of a pixel = fragment base + edelta
     constexpr int WR = WeightRing<NSUB>::N;
+    const unsigned slot_role = __builtin_amdgcn_s_getreg(63492) & 1;       // HW_ID.wave_id parity: the two waves of a SIMD differ
     half8 a[WR][2];
     floatx4 acc[2][NSUB];
     half2v sreg[NSUB][4];
     __syncthreads();
 
+#ifdef AZG_TOWER_TIMING
+    if (P.dbg && tid == 0) {
+        unsigned long long *d = P.dbg + 2048 + (size_t)blockIdx.x * 4;
+        d[0] = __builtin_amdgcn_s_memtime(); d[2] = __builtin_amdgcn_s_getreg(63492); d[3] = __builtin_amdgcn_s_getreg(63508);
+    }
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
         const int rows_here = min(ROWS, P.boards * HW - row0);
@@ -536,7 +543,18 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
 #pragma unroll
         for (int j = 0; j < WR - 1; j++) { a[j][0] = wt[(size_t)j * GEO::WSTEP]; a[j][1] = wt[(size_t)j * GEO::WSTEP + 64]; }
         __syncthreads();
+#ifdef AZG_TOWER_TIMING
+#define AZG_STAMP2(i) do { if (P.dbg && blockIdx.x == 0 && tile == 0 && lane == 0) P.dbg[(layer * 4 + wave) * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZG_STAMP2(i) do { } while (0)
+#endif
         for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
+            AZG_STAMP2(0);
+            // The co-resident workgroups of a CU take turns at issue priority, layer by layer.  Left alone the arbiter favours
+            // the older wave of each SIMD throughout: that workgroup runs at solo speed, the other one in its gaps, and the
+            // kernel ends with the second one alone on the CU for the last quarter (s_memtime: 441k vs 610k cycles).  Alternating
+            // makes both finish together: -5 % wall.
+            if ((layer ^ slot_role) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
             const float *bias = P.bias + (size_t)layer * C;
             const bool is_s = (layer & 1) == 0;
             const int nb = layer >> 1;
@@ -551,6 +569,7 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
             }
             if (layer == 0) { conv_main2<GEO, 1, NSUB, 0, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
             else { conv_main2<GEO, KS, NSUB, 9 % WR, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
+            AZG_STAMP2(1);
             half2v sc[4], sh[4];                                // (fetched here, not under the main loop: registers are the
 #pragma unroll                                                  //  scarce resource at 2 waves per SIMD, the co-resident wave hides it)
             for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
@@ -563,6 +582,7 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
                 }
             }
             __syncthreads();                                    // every wave is done reading the image
+            AZG_STAMP2(2);
 #pragma unroll
             for (int ps = 0; ps < NSUB; ps++) {
                 half2v v[4];
@@ -599,7 +619,9 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
                     }
                 }
             }
+            AZG_STAMP2(3);
             __syncthreads();
+            AZG_STAMP2(4);
         }
         if (P.head_w == nullptr) {
             uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * CPR;
@@ -651,6 +673,9 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
         }
         __syncthreads();
     }
+#ifdef AZG_TOWER_TIMING
+    if (P.dbg && tid == 0) P.dbg[2048 + (size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // ---- collapsed heads for large action spaces (brandubh: A + NV = 591) ------------------------------------------------------

@@ -538,7 +538,25 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
     } else {                                                 // one LDS image, residual stream in registers, >= 2 workgroups per CU
         const int per_cu = (int)(160 * 1024 / GEO::TILE) > 0 ? (int)(160 * 1024 / GEO::TILE) : 1;
         const int grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
+#ifdef AZG_TOWER_TIMING
+        static unsigned long long *dbg = nullptr; static int calls = 0;
+        if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 4) * 8)); }
+        TowerParams Q = P; Q.dbg = dbg;
+        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C>), dim3(grid), dim3(C * 2), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev]);
+        if (++calls == 8) {
+            unsigned long long h[64 * 4 * 5];
+            HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            for (int l = 0; l <= 2 * P.nblocks; l++) for (int w = 0; w < C / 32; w++) {
+                unsigned long long *t = h + (l * 4 + w) * 5;
+                fprintf(stderr, "layer %2d wave %d: main %6llu wait %6llu epi %6llu bar %6llu | start %llu\n", l, w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[0] - h[0]);
+            }
+            static unsigned long long w[4096 * 4];
+            HIPCHK(hipMemcpy(w, dbg + 2048, sizeof(unsigned long long) * 4 * grid, hipMemcpyDeviceToHost));
+            for (int b = 0; b < grid; b++) fprintf(stderr, "wg %4d xcc %llu hwid %08llx start %llu end %llu\n", b, w[b * 4 + 3] & 15, w[b * 4 + 2], w[b * 4], w[b * 4 + 1]);
+        }
+#else
         hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C>), dim3(grid), dim3(C * 2), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev]);
+#endif
     }
     HIPCHK(hipGetLastError());
     return AZG_OK;
