@@ -176,6 +176,13 @@ struct TowerParams {
     float *policy, *value;    // [boards, A], [boards, NV]
     int A, NV;
     unsigned long long *dbg;  // AZG_TOWER_TIMING builds only: s_memtime stamps of workgroup 0 [layer][wave][5]
+    // optional multi-model launch (the arena: every model evaluates its own contiguous slice of the leaf batch and the split
+    // is only known on the device): model m owns boards [sum(rows_per_model[0..m)), + rows_per_model[m]) of x / policy /
+    // value / y and brings its own parameters (model 0: the fields above, model m > 0: alt[m-1]); tiles never straddle
+    // models; `boards` is then only the upper bound the grid is sized for (k_tower2 only)
+    const int32_t *rows_per_model;
+    int nmodels;
+    struct Model { const void *w; const float *bias, *pre_scale, *pre_shift; const void *head_w; const float *head_b; } alt[3];
 };
 
 // LDS image of the tower: every board is stored with one pad line above and two pad columns to the right
@@ -493,14 +500,19 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
 }
 
 template <int H, int W, int BOARDS, int C>
-__global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_t *pixmap) {
+__global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int16_t *pixmap) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
+    TowerParams P = Pin;
     constexpr int NT = C * 2, KS = C / 32, CPR = C / 8;      // threads (C/32 waves: 32 couts each), k-steps per tap, 16-B chunks per row
     constexpr int HW = GEO::HW, ROWS = GEO::ROWS, NSUB = GEO::NSUB, TILE = GEO::TILE, RS = GEO::RSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
-    const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
+    int ntiles = (Pin.boards + BOARDS - 1) / BOARDS;
+    if (Pin.rows_per_model) {
+        ntiles = 0;
+        for (int m = 0; m < Pin.nmodels; m++) ntiles += (min(Pin.rows_per_model[m], Pin.boards) + BOARDS - 1) / BOARDS;
+    }
     for (int c = tid; c < TILE / 16; c += NT) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
     unsigned lb[NSUB];
     unsigned livemask = 0;
@@ -512,7 +524,6 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
         const int q = p >= 0 ? GEO::qrow(p) : GEO::LEAD;
         lb[ps] = (unsigned)(q * RS + g * 16 - GEO::BIAS);
     }
-    const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
     const unsigned edelta = (unsigned)(GEO::BIAS - g * 16 + ecol * 2);      // epilogue cell of a pixel = fragment base + edelta
     constexpr int WR = WeightRing<NSUB>::N;
     const unsigned slot_role = __builtin_amdgcn_s_getreg(63492) & 1;       // HW_ID.wave_id parity: the two waves of a SIMD differ
@@ -527,7 +538,27 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
         d[0] = __builtin_amdgcn_s_memtime(); d[2] = __builtin_amdgcn_s_getreg(63492); d[3] = __builtin_amdgcn_s_getreg(63508);
     }
 #endif
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int gtile = blockIdx.x; gtile < ntiles; gtile += gridDim.x) {
+        int tile = gtile;
+        if (Pin.rows_per_model) {                                // which model's slice, which tile of it
+            int m = 0, first = 0;
+            for (; m + 1 < Pin.nmodels; m++) {
+                const int n = min(Pin.rows_per_model[m], Pin.boards), t = (n + BOARDS - 1) / BOARDS;
+                if (tile < t) break;
+                tile -= t; first += n;
+            }
+            P.boards = min(Pin.rows_per_model[m], Pin.boards);
+            P.x = reinterpret_cast<const uint4 *>(Pin.x) + (size_t)first * HW;
+            if (Pin.y) P.y = reinterpret_cast<char *>(Pin.y) + (size_t)first * HW * C * 2;
+            if (Pin.policy) { P.policy = Pin.policy + (size_t)first * Pin.A; P.value = Pin.value + (size_t)first * Pin.NV; }
+            if (m > 0) {
+                const TowerParams::Model &M = Pin.alt[m - 1];
+                P.w = M.w; P.bias = M.bias; P.pre_scale = M.pre_scale; P.pre_shift = M.pre_shift; P.head_w = M.head_w; P.head_b = M.head_b;
+            } else {
+                P.w = Pin.w; P.bias = Pin.bias; P.pre_scale = Pin.pre_scale; P.pre_shift = Pin.pre_shift; P.head_w = Pin.head_w; P.head_b = Pin.head_b;
+            }
+        }
+        const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
         const int row0 = tile * ROWS;
         const int rows_here = min(ROWS, P.boards * HW - row0);
         {
@@ -686,11 +717,11 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams P, const int16_
 // [k-step][subtile][64 lanes][8 halves]) straight from L2 -- no reuse inside a workgroup, so no LDS staging.  With
 // blockIdx = group * nchunks + chunk and 8 chunks, the workgroups sharing a weight chunk sit on one XCD (blockIdx mod 8).
 // The job is L2->CU bandwidth bound: (HEAD_NS*16 + 16) * K * 2 bytes per workgroup.
-constexpr int HEAD_NS = 5;
+constexpr int HEAD_NS = 5, HEAD_WAVES = 8, HEAD_U = 7;
 
-__global__ __launch_bounds__(256) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
-                                               int ksteps, int osub) {
-    __shared__ float red[4][HEAD_NS * 256];
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
+                                                          int ksteps, int osub) {
+    __shared__ float red[HEAD_WAVES][HEAD_NS * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int nchunks = (osub + HEAD_NS - 1) / HEAD_NS, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
     const int b0 = grp * 16, s0 = chunk * HEAD_NS, opad = osub * 16;
@@ -700,43 +731,68 @@ __global__ __launch_bounds__(256) void k_heads(const _Float16 *y, const half8 *w
     floatx4 acc[HEAD_NS];
 #pragma unroll
     for (int s = 0; s < HEAD_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    // The waves split K (k-steps wave, wave + 8, ...) and work in batches of HEAD_U k-steps: all 6 * HEAD_U fragment loads of a
+    // batch are issued back to back (the job is L2 latency, not MFMA), branch-free: subtiles past the end re-read the last real
+    // one (their accumulators are never stored), k-steps past the end re-read the last one with the A fragment zeroed.
+    size_t soff[HEAD_NS];
+#pragma unroll
+    for (int s = 0; s < HEAD_NS; s++) soff[s] = (size_t)(min(s0 + s, osub - 1) - s0) * 64;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int ks = wave; ks < ksteps; ks += 4) {
-        const half8 a = yrow[(size_t)ks * 4];
-        half8 b[HEAD_NS];
+    for (int k0 = wave; k0 < ksteps; k0 += HEAD_WAVES * HEAD_U) {
+        half8 a[HEAD_U], b[HEAD_U][HEAD_NS];
 #pragma unroll
-        for (int s = 0; s < HEAD_NS; s++) b[s] = s0 + s < osub ? wl[((size_t)ks * osub + s) * 64] : zero8;
+        for (int u = 0; u < HEAD_U; u++) {
+            const int ks = k0 + u * HEAD_WAVES, kc = min(ks, ksteps - 1);
+            a[u] = yrow[(size_t)kc * 4];
+            if (ks >= ksteps) a[u] = zero8;
 #pragma unroll
-        for (int s = 0; s < HEAD_NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[s], acc[s], 0, 0, 0);
+            for (int s = 0; s < HEAD_NS; s++) b[u][s] = wl[(size_t)kc * osub * 64 + soff[s]];
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // (left alone hipcc sinks every load next to its MFMA and waits)
+#pragma unroll
+        for (int u = 0; u < HEAD_U; u++)
+#pragma unroll
+            for (int s = 0; s < HEAD_NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][s], acc[s], 0, 0, 0);
     }
 #pragma unroll
     for (int s = 0; s < HEAD_NS; s++)
 #pragma unroll
         for (int r = 0; r < 4; r++) red[wave][(s * 4 + r) * 64 + lane] = acc[s][r];
     __syncthreads();
-    for (int e = tid; e < HEAD_NS * 256; e += 256) {                          // D[m = board g*4 + r][n = output i16]
+    for (int e = tid; e < HEAD_NS * 256; e += HEAD_WAVES * 64) {              // D[m = board g*4 + r][n = output i16]
         const int s = e >> 8, r = (e >> 6) & 3, ln = e & 63, board = b0 + (ln >> 4) * 4 + r, out = (s0 + s) * 16 + (ln & 15);
-        if (board < boards && s0 + s < osub)
-            logits[(size_t)board * opad + out] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + bias[out];
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < HEAD_WAVES; w++) sum += red[w][e];
+        if (board < boards && s0 + s < osub) logits[(size_t)board * opad + out] = sum + bias[out];
     }
 }
 
-// one wave per board: softmax over the A policy logits and over the NV value logits
+// one wave per board: softmax over the A policy logits (held in registers: up to 16 per lane, A <= 1024) and the NV value logits
 __global__ __launch_bounds__(256) void k_heads_softmax(const float *logits, float *policy, float *value, int boards, int opad, int A, int NV) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= boards) return;
     const float *lg = logits + (size_t)b * opad;
-    float m = -INFINITY;
-    for (int o = lane; o < A; o += 64) m = fmaxf(m, lg[o]);
+    float x[16], m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int o = lane + 64 * j;
+        x[j] = lg[min(o, A - 1)];
+        if (o >= A) x[j] = -INFINITY;
+        m = fmaxf(m, x[j]);
+    }
+    const float v = lg[A + min(lane, NV - 1)];
 #pragma unroll
     for (int d = 32; d; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     float sum = 0.f;
-    for (int o = lane; o < A; o += 64) sum += __expf(lg[o] - m);
+#pragma unroll
+    for (int j = 0; j < 16; j++) { x[j] = __expf(x[j] - m); sum += x[j]; }    // exp(-inf) = 0 for the padding
 #pragma unroll
     for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
-    for (int o = lane; o < A; o += 64) policy[(size_t)b * A + o] = __expf(lg[o] - m) / sum;
-    float v = lane < NV ? lg[A + lane] : -INFINITY, vm = v;
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int o = lane + 64 * j; if (o < A) policy[(size_t)b * A + o] = x[j] * inv; }
+    float vm = lane < NV ? v : -INFINITY;
 #pragma unroll
     for (int d = 32; d; d >>= 1) vm = fmaxf(vm, __shfl_xor(vm, d));
     const float ev = lane < NV ? __expf(v - vm) : 0.f;

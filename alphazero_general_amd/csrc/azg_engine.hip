@@ -90,21 +90,21 @@ template <typename T> static int dalloc(azg_engine *e, T **p, size_t count) {
 static void prof_begin(azg_engine *e, hipStream_t s, int fam, EvPair &p) {
     if (!e->profile) return;
     if (!e->pool.empty()) { p = e->pool.back(); e->pool.pop_back(); }
-    else { hipEventCreate(&p.a); hipEventCreate(&p.b); }
-    hipEventRecord(p.a, s);
+    else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    (void)hipEventRecord(p.a, s);
     (void)fam;
 }
 static void prof_end(azg_engine *e, hipStream_t s, int fam, EvPair &p) {
     if (!e->profile) return;
-    hipEventRecord(p.b, s);
+    (void)hipEventRecord(p.b, s);
     e->ev[fam].push_back(p);
     e->launches[fam]++;
 }
 static void prof_drain(azg_engine *e) {
     for (int f = 0; f < 3; f++) {
         for (auto &p : e->ev[f]) {
-            hipEventSynchronize(p.b);
-            float t = 0; hipEventElapsedTime(&t, p.a, p.b);
+            (void)hipEventSynchronize(p.b);
+            float t = 0; (void)hipEventElapsedTime(&t, p.a, p.b);
             e->ms[f] += t;
             e->pool.push_back(p);
         }
@@ -174,10 +174,10 @@ extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
 
 extern "C" int azg_engine_destroy(azg_engine *e) {
     if (!e) return AZG_OK;
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     prof_drain(e);
-    for (auto &p : e->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-    for (void *p : e->allocs) hipFree(p);
+    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (void *p : e->allocs) (void)hipFree(p);
     delete e;
     return AZG_OK;
 }
@@ -253,8 +253,10 @@ extern "C" int azg_select(azg_engine *e, void *stream, void *obs, int obs_dtype,
 extern "C" int azg_arena_rows(azg_engine *e, void *stream, const int32_t *p2i_host, int32_t *row_of_slot, int32_t *rows_per_model) {
     if (!e || !p2i_host || !row_of_slot || !rows_per_model) return fail(AZG_E_INVALID_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(e->d_p2i, p2i_host, sizeof(int32_t) * e->gi.num_players, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_arena_rows, dim3(1), dim3(64), 0, s, e->v, e->d_p2i, row_of_slot, rows_per_model);
+    if (e->gi.num_players > 8) return fail(AZG_E_UNSUPPORTED, "more than 8 players");
+    SeatMap seat{};
+    for (int i = 0; i < e->gi.num_players; i++) seat.v[i] = p2i_host[i];
+    hipLaunchKernelGGL(k_arena_rows, dim3(1), dim3(64), 0, s, e->v, seat, row_of_slot, rows_per_model);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }
@@ -528,7 +530,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)GEO::TILE));
     }
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
+    const int ntiles = (P.boards + BOARDS - 1) / BOARDS + (P.rows_per_model ? P.nmodels - 1 : 0);
     static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
     if (C == 128 && variant == 1) {                          // one workgroup per CU, two LDS images, deep prefetch
         if constexpr (C == 128) {
@@ -587,7 +589,7 @@ extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const
                                     const float *pre_shift, void *y, int boards, int nblocks, int channels) {
     if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
-    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, {}};
     return dispatch_tower((hipStream_t)stream, game, channels, P);
 }
 
@@ -597,17 +599,38 @@ extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x
     if (!x || !w || !bias || !head_w || !head_b || !policy || !value || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (A <= 0 || NV <= 0 || A + NV > 16) return fail(AZG_E_UNSUPPORTED, "fused heads need A + NV <= 16");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
-    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr};
+    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr, nullptr, 0, {}};
+    return dispatch_tower((hipStream_t)stream, game, 128, P);
+}
+
+extern "C" int azg_resnet_policy_value_multi_f16(void *stream, int game, const void *x, int nmodels, const void *const *w, const float *const *bias,
+                                                 const float *const *pre_scale, const float *const *pre_shift, int max_boards, int nblocks,
+                                                 const void *const *head_w, const float *const *head_b, int A, int NV, float *policy, float *value,
+                                                 const int32_t *rows_per_model) {
+    if (!x || !w || !bias || !head_w || !head_b || !policy || !value || !rows_per_model || max_boards <= 0 || nblocks < 0)
+        return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
+    if (nmodels < 1 || nmodels > 4) return fail(AZG_E_UNSUPPORTED, "1 to 4 models per launch");
+    if (A <= 0 || NV <= 0 || A + NV > 16) return fail(AZG_E_UNSUPPORTED, "fused heads need A + NV <= 16");
+    if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
+    for (int m = 0; m < nmodels; m++)
+        if (!w[m] || !bias[m] || !head_w[m] || !head_b[m] || (nblocks > 0 && (!pre_scale[m] || !pre_shift[m]))) return fail(AZG_E_INVALID_ARG, "null model parameter");
+    static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
+    if (variant == 1) return fail(AZG_E_UNSUPPORTED, "multi-model launches need the default tower kernel (AZG_TOWER_VARIANT unset)");
+    // the grid is sized for max_boards rows plus one partial tile per extra model
+    TowerParams P{x, w[0], bias[0], nblocks ? pre_scale[0] : nullptr, nblocks ? pre_shift[0] : nullptr, nullptr, max_boards, nblocks,
+                  head_w[0], head_b[0], policy, value, A, NV, nullptr, rows_per_model, nmodels, {}};
+    for (int m = 1; m < nmodels; m++)
+        P.alt[m - 1] = TowerParams::Model{w[m], bias[m], nblocks ? pre_scale[m] : nullptr, nblocks ? pre_shift[m] : nullptr, head_w[m], head_b[m]};
     return dispatch_tower((hipStream_t)stream, game, 128, P);
 }
 
 extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,
                                           int A, int NV, float *logits_ws, float *policy, float *value) {
     if (!y || !head_w_packed || !head_b || !logits_ws || !policy || !value) return fail(AZG_E_INVALID_ARG, "null argument");
-    if (boards <= 0 || k <= 0 || (k & 31) || A <= 0 || NV <= 0 || NV > 64) return fail(AZG_E_INVALID_ARG, "boards > 0, k a multiple of 32, 0 < NV <= 64");
+    if (boards <= 0 || k <= 0 || (k & 31) || A <= 0 || A > 1024 || NV <= 0 || NV > 64) return fail(AZG_E_INVALID_ARG, "boards > 0, k a multiple of 32, 0 < A <= 1024, 0 < NV <= 64");
     const int osub = (A + NV + 15) / 16, nchunks = (osub + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_heads, dim3(groups * nchunks), dim3(256), 0, s, (const _Float16 *)y, (const half8 *)head_w_packed, head_b, logits_ws,
+    hipLaunchKernelGGL(k_heads, dim3(groups * nchunks), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)y, (const half8 *)head_w_packed, head_b, logits_ws,
                        boards, k / 32, osub);
     hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
     HIPCHK(hipGetLastError());

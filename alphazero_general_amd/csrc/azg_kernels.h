@@ -529,8 +529,11 @@ __global__ __launch_bounds__(64) void k_reset_max_depth(View ev) {
 }
 
 // arena rows (SelfPlayAgent.pyx:117-132): rows grouped by model = player_to_index[mover], slot order inside a group
-__global__ __launch_bounds__(64) void k_arena_rows(View ev, const int32_t *p2i, int32_t *row_of_slot, int32_t *rows_per_model) {
+struct SeatMap { int32_t v[8]; };                            // player_to_index by value: no host copy, graph-capturable
+
+__global__ __launch_bounds__(64) void k_arena_rows(View ev, SeatMap seat, int32_t *row_of_slot, int32_t *rows_per_model) {
     const int lane = threadIdx.x;
+    const int32_t *p2i = seat.v;
     int base = 0;
     for (int mi = 0; mi < ev.T; mi++) {
         int cntm = 0;

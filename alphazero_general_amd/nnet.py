@@ -270,6 +270,26 @@ class HipResNet:
         logits = torch.matmul(s.view(B, self.HW * self.CH), self.head_w).float() + self.head_b
         return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
 
+    @staticmethod
+    def forward_models(nets, x_all, policy_all, value_all, rows_per_model):
+        """Arena evaluation in ONE launch without a host read of the batch split: nets[m] (HipResNets of one architecture)
+        evaluates rows [sum(rows_per_model[:m]), + rows_per_model[m]) of x_all [B, H*W, 8] into policy_all / value_all
+        (rows_per_model: int32 device tensor from DeviceEngine.arena_rows).  Needs the fused tower + heads kernel."""
+        import ctypes as C
+        n0 = nets[0]
+        for n in nets:
+            if not (n.fused and n.fused_head):
+                raise NotImplementedError('multi-model launches need the fused tower + heads kernel (128 channels, A + NV <= 16)')
+            assert (n.game, n.CH, len(n.blocks), n.A, n.NV) == (n0.game, n0.CH, len(n0.blocks), n0.A, n0.NV)
+        arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        vp = lambda q: C.c_void_p(q.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        n0._check(n0.L.azg_resnet_policy_value_multi_f16(
+            st, n0.game, vp(x_all), len(nets), arr([n.tower_w for n in nets]), arr([n.tower_b for n in nets]),
+            arr([n.tower_ps for n in nets]), arr([n.tower_pt for n in nets]), int(x_all.shape[0]), len(n0.blocks),
+            arr([n.head_w_packed for n in nets]), arr([n.head_b16 for n in nets]), int(n0.A), int(n0.NV), vp(policy_all), vp(value_all),
+            vp(rows_per_model)))
+
     def to_nhwc8(self, batch):
         """[B, C, H, W] (any float dtype) -> [B, H*W, 8] fp16."""
         B, C = batch.shape[0], batch.shape[1]

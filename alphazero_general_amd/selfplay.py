@@ -11,6 +11,7 @@ import torch
 
 from . import _abi
 from .engine import DeviceEngine
+from .nnet import HipResNet
 from .Game import azg_game_id
 from .utils import AGENT_STREAM, default_temp_scaling
 
@@ -178,7 +179,7 @@ class ArenaRunner:
     correct row <-> game map (the reference's mis-routing, SURVEY.md Q15, is not reproduced).  Returns the
     (wins, draws, winrates) contract of Arena.play_games (:376) via get_game_results semantics (utils.py:34-54)."""
 
-    def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None):
+    def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None, use_graph=True):
         self.game_cls, self.nnets, self.args = game_cls, list(nnets), args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -203,12 +204,23 @@ class ArenaRunner:
                     else e.new_obs(torch.float16))
         self.policy = torch.zeros((self.B, e.A), dtype=torch.float32, device=e.device)
         self.value = torch.zeros((self.B, e.NV), dtype=torch.float32, device=e.device)
+        # fused tower + heads on every model: the per-model batch split never leaves the device
+        self.device_split = bool(hip) and all(n._hip.fused and n._hip.fused_head for n in self.nnets)
+        self._graph = None
+        if self.device_split and use_graph:
+            self.capture()
 
     def step(self):
+        if self.device_split:
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._step_device_split()
+            return
         e = self.engine
         row_of_slot, rpm = e.arena_rows(self.player_to_index)
         e.select(self.obs, row_of_slot)
-        counts = rpm.cpu().tolist()                                  # the one host read per simulation (batch split)
+        counts = rpm.cpu().tolist()                                  # host read of the batch split, once per simulation
         off = 0
         for mi, n in enumerate(counts):
             if n:
@@ -217,6 +229,26 @@ class ArenaRunner:
                 self.policy[off:off + n] = p; self.value[off:off + n] = v
             off += n
         e.backup(self.policy, self.value, row_of_slot)
+
+    def _step_device_split(self):
+        """rows -> select -> every model on its own slice (the split stays on the device) -> backup: no host read, so the
+        whole simulation step is one hipGraph."""
+        e = self.engine
+        row_of_slot, rpm = e.arena_rows(self.player_to_index)
+        e.select(self.obs, row_of_slot)
+        HipResNet.forward_models([n._hip for n in self.nnets], self.obs, self.policy, self.value, rpm)    # one launch
+        e.backup(self.policy, self.value, row_of_slot)
+
+    def capture(self):
+        """Capture one simulation step as a hipGraph (device-side split only)."""
+        assert self.device_split
+        self._step_device_split()                                    # warm: lazy allocations happen outside the capture
+        self.engine.reset()                                          # (the warm step is not part of any game)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_device_split()
+        self._graph = g
 
     def play_round(self):
         for _ in range(int(self.args.get('numMCTSSims', 100))):

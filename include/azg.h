@@ -209,6 +209,17 @@ int  azg_resnet_policy_value_f16(void *stream, int game, const void *x_dev, cons
                                  const void *head_w_packed_dev, const float *head_b_dev, int A, int NV,
                                  float *policy_dev, float *value_dev);
 
+/* Several models in ONE launch, each on a row range only the device knows -- the arena (Arena.pyx:262-281,
+ * SelfPlayAgent.pyx:117-132): model m evaluates rows [sum(rows_per_model_dev[0..m)), + rows_per_model_dev[m]) of
+ * x_dev / policy_dev / value_dev (whole-batch base pointers; rows_per_model_dev as written by azg_arena_rows) with
+ * its own parameters w[m], bias[m], ... (host arrays of nmodels device pointers, nmodels <= 4, same architecture).
+ * max_boards bounds the launch.  No host read of the split: rows -> select -> all models -> backup is one graph. */
+int  azg_resnet_policy_value_multi_f16(void *stream, int game, const void *x_dev, int nmodels, const void *const *w_packed_dev,
+                                       const float *const *bias_dev, const float *const *pre_scale_dev,
+                                       const float *const *pre_shift_dev, int max_boards, int nblocks,
+                                       const void *const *head_w_packed_dev, const float *const *head_b_dev, int A, int NV,
+                                       float *policy_dev, float *value_dev, const int32_t *rows_per_model_dev);
+
 /* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same
  * [k = H*W*C, A+NV] matrix applied to the final stream y [boards, k] fp16 that azg_resnet_tower_f16 stores, then the
  * two softmaxes.  head_w_packed: fragment order [k/32][OS = ceil((A+NV)/16)][64 lanes][8 halves], lane g*16+i, half j

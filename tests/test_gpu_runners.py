@@ -1,0 +1,78 @@
+"""The native drivers over the C ABI (selfplay.SelfPlayRunner = Coach.processSelfPlayBatches' loop, Coach.py:291-361;
+selfplay.ArenaRunner = the batched branch of Arena.play_games, Arena.pyx:208-328) with a real network in the loop:
+launch strategy (hipGraph replay, device-side batch split, stream pipelines) must not change a single move."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(**kw):
+    from alphazero_general_amd.utils import dotdict, default_temp_scaling
+    a = dotdict(numMCTSSims=12, numFastSims=4, probFastSim=0.0, gamesPerIteration=1 << 30, cpuct=4.0, fpu_reduction=0.4,
+                root_noise_frac=0.3, root_policy_temp=1.3, min_discount=1.0, add_root_noise=True, add_root_temp=True,
+                symmetricSamples=True, mctsResetThreshold=0, startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
+    a.update(kw)
+    return a
+
+
+def _net(seed):
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
+    torch.manual_seed(seed)
+    return NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', dtype=torch.float16)
+
+
+def test_arena_runner_device_split_graph_equals_host_split():
+    """ArenaRunner: every model evaluating its slice through a device-side row range inside one captured graph plays
+    exactly the games the host-split loop (one .cpu() read of the split per simulation) plays."""
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.selfplay import ArenaRunner
+    nets = [_net(0), _net(1)]
+    runs = []
+    for mode in ('graph', 'eager', 'host'):
+        r = ArenaRunner(Game, nets, _args(), num_slots=96, seed=5, use_graph=(mode == 'graph'))
+        assert r.device_split and (r._graph is not None) == (mode == 'graph')
+        if mode == 'host':
+            r.device_split = False
+        acts = []
+        for _ in range(14):
+            r.play_round()
+            acts.append(r.engine.last_actions().cpu().numpy().copy())
+        runs.append((np.array(acts), r.engine.counters(), r.results()))
+    a0, c0, res0 = runs[0]
+    assert c0['games_played'] > 0 and (a0 >= 0).any()
+    for a, c, res in runs[1:]:
+        assert (a == a0).all()
+        assert c['games_played'] == c0['games_played'] and c['sims'] == c0['sims'] and c['expansions'] == c0['expansions']
+        assert res == res0
+    wins, draws, rates = res0
+    assert sum(wins) + draws == c0['games_played']                   # Arena.play_games contract (Arena.pyx:376)
+
+
+@pytest.mark.parametrize('variant', ['no_graph', 'pipelines2'])
+def test_selfplay_runner_launch_strategy_is_invisible(variant):
+    """SelfPlayRunner: hipGraph replay of the network / two stream pipelines give bit-identical samples and results to
+    the plain launch sequence (slots are sharded by global id, so the pipelines play the same games)."""
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    net = _net(3)
+    outs = []
+    for kw in (dict(), dict(use_graph=False) if variant == 'no_graph' else dict(pipelines=2)):
+        r = SelfPlayRunner(Game, net, _args(), num_slots=64, seed=9, example_capacity=64 * 43 * 2 * 4, **kw)
+        for _ in range(30):
+            r.play_round()
+        obs, pi, z = r.samples()
+        ws, turns, slot = r.results()
+        outs.append((obs.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy(), np.asarray(ws), np.asarray(turns), np.asarray(slot), r.counters()))
+    a, b = outs
+    assert a[6]['games_played'] == b[6]['games_played'] > 0
+    if variant == 'no_graph':
+        for x, y in zip(a[:6], b[:6]):
+            assert x.shape == y.shape and (x == y).all()
+    else:                                                            # lanes emit in their own order: compare as multisets
+        key = lambda o, p, zz: sorted(map(bytes, np.concatenate([o.reshape(len(o), -1), p, zz], axis=1)))
+        assert key(a[0], a[1], a[2]) == key(b[0], b[1], b[2])
+        assert sorted(zip(a[5].tolist(), a[4].tolist())) == sorted(zip(b[5].tolist(), b[4].tolist()))
