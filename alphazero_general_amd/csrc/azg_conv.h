@@ -460,9 +460,10 @@ struct FragOff {                                             // LDS immediate of
 };
 
 // weight ring depth: a k-step of a small tile (NSUB <= 4: 6-8 MFMAs) is far shorter than an L2 round trip, so the small
-// shapes fetch 8 k-steps ahead; the big ones (22 MFMAs per k-step, registers scarce) one.  9 divides every layer's k-step count,
-// so the 9-deep ring always starts a layer at slot 0; the 2-deep one starts layers >= 1 at slot 9 % 2.
-template <int NSUB> struct WeightRing { static constexpr int N = NSUB <= 4 ? 9 : 2; };
+// shapes fetch 8 k-steps ahead; the big ones (22 MFMAs per k-step, registers scarce) one or two.  Every layer after the stem
+// must advance the ring by whole turns (9 * KS k-steps), so that it always starts at slot 9 % N (the stem's 9 k-steps):
+// N = 9 for small tiles, 2 for even KS, 3 for odd KS (32 channels).
+template <int NSUB, int KS> struct WeightRing { static constexpr int N = NSUB <= 4 ? 9 : (KS % 2 ? 3 : 2); };
 
 template <class GEO, int KS, int NSUB, int RB, int WR>
 __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[WR][2],
@@ -525,7 +526,8 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
         lb[ps] = (unsigned)(q * RS + g * 16 - GEO::BIAS);
     }
     const unsigned edelta = (unsigned)(GEO::BIAS - g * 16 + ecol * 2);      // epilogue cell of a pixel = fragment base + edelta
-    constexpr int WR = WeightRing<NSUB>::N;
+    constexpr int WR = WeightRing<NSUB, C / 32>::N;
+    static_assert((9 * (C / 32)) % WR == 0, "a layer must advance the weight ring by whole turns");
     const unsigned slot_role = __builtin_amdgcn_s_getreg(63492) & 1;       // HW_ID.wave_id parity: the two waves of a SIMD differ
     half8 a[WR][2];
     floatx4 acc[2][NSUB];

@@ -582,7 +582,12 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
         return launch_tower<BR::H, BR::W, 2, 64>(s, P);
     }
     if (game == AZG_GAME_BRANDUBH && channels == 128) return launch_tower<BR::H, BR::W, 2, 128>(s, P);
-    return fail(AZG_E_UNSUPPORTED, "no MFMA tower for this game / channel count (supported: connect4, brandubh x 64, 128 channels)");
+    if (game == AZG_GAME_TRIMOK && channels == 32) {             // one wave per workgroup
+        const int bt = forced ? forced : n <= 2048 ? 2 : 5;
+        if (bt == 2) return launch_tower<TM::H, TM::W, 2, 32>(s, P);
+        return launch_tower<TM::H, TM::W, 5, 32>(s, P);
+    }
+    return fail(AZG_E_UNSUPPORTED, "no MFMA tower for this game / channel count (supported: connect4 x {64,128}, brandubh x {64,128}, trimok x 32 channels)");
 }
 
 extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,

@@ -158,7 +158,7 @@ class HipResNet:
         C, H, W = folded.shape
         self.C, self.HW = C, H * W
         self.CH = CH = int(folded.stem_w.shape[0])                      # tower width
-        assert CH in (64, 128) and C <= 8, 'the MFMA tower is built for 64 or 128 channels'
+        assert CH in (32, 64, 128) and C <= 8, 'the MFMA tower is built for 32, 64 or 128 channels'
         f32 = dict(dtype=torch.float32, device=self.device)
         with torch.no_grad():
             self.stem_w = pack_conv_weight(folded.stem_w.float(), 1).to(self.device)
@@ -340,8 +340,8 @@ class NNetWrapper:
             net = net.to(memory_format=torch.channels_last)
         self._infer, self._graph, self._hip = net.eval(), None, None
         use_hip = self.backend == 'hip' or (self.backend == 'auto' and self.device.type == 'cuda'
-                                            and self.args.num_channels in (64, 128)
-                                            and getattr(self.game_cls, 'AZG_GAME_ID', None) in (0, 1))
+                                            and (getattr(self.game_cls, 'AZG_GAME_ID', None), self.args.num_channels) in
+                                            ((0, 64), (0, 128), (1, 64), (1, 128), (2, 32)))
         if use_hip:
             self._hip = HipResNet(FoldedResNet(self.nnet).to(self.device), self.game_cls.AZG_GAME_ID, self.device)
         return self

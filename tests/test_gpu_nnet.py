@@ -190,3 +190,32 @@ def test_tower_tile_shapes_agree(game):
             assert torch.equal(p, outs[0][0]) and torch.equal(v, outs[0][1])
         else:                                      # heads GEMM is a library call whose k-split depends on the batch size
             assert float((p - outs[0][0]).abs().max()) < 1e-4 and float((v - outs[0][1]).abs().max()) < 1e-4
+
+
+def test_mfma_tower_trimok_32ch_vs_fp32_reference():
+    """the tower at 32 channels (one wave per workgroup) on the 5x5 three-player board, 5 input planes, default net of
+    Coach.py:108-116; heads through the wide-head kernel (A + NV = 29)."""
+    import torch
+    from alphazero_general_amd.envs.trimok import Game
+    from alphazero_general_amd.nnet import DEFAULT_NET_ARGS, NNetWrapper
+    torch.manual_seed(21)
+    net = NNetWrapper(Game, DEFAULT_NET_ARGS, device='cuda:0', backend='auto')
+    _randomize(net.nnet.cpu(), torch, seed=8); net.nnet.to('cuda:0'); net.refresh()
+    assert net._hip is not None and net._hip.CH == 32 and net._hip.wide_head
+    rng = np.random.RandomState(4)
+    obs = []
+    for b in range(2500):                                   # 2500 boards: both tile shapes (2 and 5 boards per workgroup)
+        g = Game()
+        for _ in range(rng.randint(0, 20)):
+            if g.win_state().any():
+                break
+            g.play_action(int(rng.choice(np.flatnonzero(g.valid_moves()))))
+        obs.append(g.observation())
+    x = torch.from_numpy(np.array(obs, np.float32))
+    with torch.no_grad():
+        lp, lv = net.nnet(x.to('cuda:0'))
+    for n in (2500, 301):
+        p, v = net.process(x[:n])
+        assert p.shape == (n, 25) and v.shape == (n, 4)
+        assert float((p.cpu() - torch.exp(lp[:n]).cpu()).abs().max()) < 3e-3
+        assert float((v.cpu() - torch.exp(lv[:n]).cpu()).abs().max()) < 3e-3
