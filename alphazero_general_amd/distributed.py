@@ -17,7 +17,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
-    if world > 1 and not dist.is_initialized():
+    # under torch.distributed.run (WORLD_SIZE set) the group is initialised even for one rank, so that a 1-GPU launch
+    # exercises the same RCCL calls as an 8-GPU one
+    if (world > 1 or 'WORLD_SIZE' in os.environ and 'MASTER_ADDR' in os.environ) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -41,7 +43,7 @@ def slot_base(rank, slots_per_rank):
 def all_gather_examples(obs, pi, z, group=None):
     """Variable-length all-gather of example shards.  Returns (obs, pi, z) holding every rank's samples, rank order,
     each rank's samples in its own output order."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return obs, pi, z
     world = dist.get_world_size(group)
     n = torch.tensor([obs.shape[0]], dtype=torch.int64, device=obs.device)
@@ -62,7 +64,7 @@ def all_gather_examples(obs, pi, z, group=None):
 def all_reduce_tallies(values, group=None):
     """Sum small integer tallies (wins per player, draws, game-length sum, games, expansions ...) over ranks."""
     t = torch.as_tensor(values, dtype=torch.int64)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return t
     dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
     t = t.to(dev)
@@ -71,7 +73,7 @@ def all_reduce_tallies(values, group=None):
 
 
 def max_over_ranks(x, group=None):
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return float(x)
     dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
     t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
@@ -80,5 +82,10 @@ def max_over_ranks(x, group=None):
 
 
 def barrier(group=None):
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.barrier(group=group)
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
