@@ -253,6 +253,7 @@ class DeviceEngine:
 
     def profile(self, on=True):
         _abi.check(self.L.azg_profile_enable(self.h, int(on)))
+        self.profiling = bool(on)
 
     def profile_read(self):
         ms = (C.c_double * 3)(); n = (C.c_int64 * 3)()

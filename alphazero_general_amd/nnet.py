@@ -301,8 +301,10 @@ class HipResNet:
 class CapturedNet:
     """One hipGraph-captured fixed-batch evaluation: static input x, static outputs policy / value."""
 
-    def __init__(self, graph, x, policy, value):
+    def __init__(self, graph, x, policy, value, run=None):
         self.graph, self.x, self.policy, self.value = graph, x, policy, value
+        self.run = run                   # the same evaluation as plain launches on the current stream -> (policy, value); lets a
+                                         # caller capture it inside a larger graph (selfplay: a whole round of simulations)
 
     def replay(self):
         self.graph.replay()
@@ -399,7 +401,7 @@ class NNetWrapper:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g), torch.no_grad():
             p, v = run()
-        return CapturedNet(g, x, p, v)
+        return CapturedNet(g, x, p, v, run)
 
     @property
     def input_is_nhwc8(self):

@@ -23,6 +23,7 @@ class _Lane:
     def __init__(self, engine, stream):
         self.engine, self.stream = engine, stream
         self.obs = self.policy = self.value = self.net = None
+        self.round_graphs = {}
 
 
 class SelfPlayRunner:
@@ -32,7 +33,7 @@ class SelfPlayRunner:
     independent and every random draw is keyed by the global slot id, so the split changes no result."""
 
     def __init__(self, game_cls, nnet, args, *, num_slots, seed=0, slot_base=0, device=None, example_capacity=None,
-                 use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1):
+                 use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None):
         self.game_cls, self.nnet, self.args = game_cls, nnet, args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -48,6 +49,8 @@ class SelfPlayRunner:
         self.seed, self.slot_base = int(seed), int(slot_base)
         self._actr = 0
         self.use_graph = bool(use_graph) and not self.warmup and nnet is not None
+        # whole-round graphs need a capturable evaluation: the captured net's launch sequence, or warm-up's constants
+        self.round_graph = (self.use_graph or (self.warmup and bool(use_graph))) if round_graph is None else bool(round_graph)
         self.lanes = []
         for li in range(self.pipelines):
             eng = DeviceEngine(
@@ -112,13 +115,39 @@ class SelfPlayRunner:
             with torch.cuda.stream(ln.stream):
                 self._step_lane(ln)
 
+    def _round_graph(self, ln, sims, fast):
+        """One whole round of a lane -- sims x (select, network, backup) + advance -- as ONE hipGraph: every launch is
+        stream-ordered and nothing is read on the host, so the host issues one replay per move instead of 3 calls per
+        simulation (the small configs are otherwise bound by host launch rate, not by the GPU)."""
+        key = (sims, fast)
+        if key not in ln.round_graphs:
+            e = ln.engine
+            torch.cuda.synchronize(e.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                for _ in range(sims):
+                    e.select(ln.obs)
+                    if self.warmup:
+                        e.backup(ln.policy, ln.value)
+                    else:
+                        p, v = ln.net.run()
+                        e.backup(p, v)
+                e.advance(record_history=not fast)
+            ln.round_graphs[key] = g
+        return ln.round_graphs[key]
+
     def play_round(self):
         sims, fast = self._sims_for_round()
-        for _ in range(sims):
-            self.step()
-        for ln in self.lanes:                                        # playMoves :153-202
-            with torch.cuda.stream(ln.stream):
-                ln.engine.advance(record_history=not fast)
+        if self.round_graph and not any(getattr(ln.engine, 'profiling', False) for ln in self.lanes):
+            for ln in self.lanes:
+                with torch.cuda.stream(ln.stream):
+                    self._round_graph(ln, sims, fast).replay()
+        else:
+            for _ in range(sims):
+                self.step()
+            for ln in self.lanes:                                    # playMoves :153-202
+                with torch.cuda.stream(ln.stream):
+                    ln.engine.advance(record_history=not fast)
         self.sims_per_round.append(sims)
         return sims
 
