@@ -536,7 +536,7 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
 
 #ifdef AZG_TOWER_TIMING
     if (P.dbg && tid == 0) {
-        unsigned long long *d = P.dbg + 2048 + (size_t)blockIdx.x * 4;
+        unsigned long long *d = P.dbg + 2048 + (size_t)blockIdx.x * 8;
         d[0] = __builtin_amdgcn_s_memtime(); d[2] = __builtin_amdgcn_s_getreg(63492); d[3] = __builtin_amdgcn_s_getreg(63508);
     }
 #endif
@@ -578,9 +578,12 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
         __syncthreads();
 #ifdef AZG_TOWER_TIMING
 #define AZG_STAMP2(i) do { if (P.dbg && blockIdx.x == 0 && tile == 0 && lane == 0) P.dbg[(layer * 4 + wave) * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AZG_WGSTAMP(i) do { if (P.dbg && tid == 0) P.dbg[2048 + (size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define AZG_STAMP2(i) do { } while (0)
+#define AZG_WGSTAMP(i) do { } while (0)
 #endif
+        AZG_WGSTAMP(4);
         for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
             AZG_STAMP2(0);
             // The co-resident workgroups of a CU take turns at issue priority, layer by layer.  Left alone the arbiter favours
@@ -656,6 +659,7 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
             __syncthreads();
             AZG_STAMP2(4);
         }
+        AZG_WGSTAMP(5);
         if (P.head_w == nullptr) {
             uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * CPR;
             for (int c = tid; c < rows_here * CPR; c += NT) {
@@ -663,51 +667,80 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
                 yg[c] = *reinterpret_cast<const uint4 *>(img + GEO::qrow(p) * RS + chunk * 16);
             }
         } else if constexpr (C == 128) {
-            floatx4 hacc = {0.f, 0.f, 0.f, 0.f};
+            // logits[board, o] = sum over (pixel, channel) of s_final * Wfull: one MFMA per (pixel, 32-channel step), A = head
+            // weights from L2, B = the final stream in the LDS image (column n = board).  The waves split the pixels; each
+            // batch issues its 16 weight-fragment loads back to back (branch-free: pixels past the end re-read the last one
+            // with a zeroed B fragment), four independent accumulators (one per channel step) avoid a dependent MFMA chain.
+            constexpr int NPW = (HW + 3) / 4, JB = 4;
+            floatx4 hacc4[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) hacc4[ks] = (floatx4){0.f, 0.f, 0.f, 0.f};
             const bool bvalid = i16 < BOARDS;
             const unsigned bbase = (unsigned)((GEO::LEAD + (bvalid ? i16 : 0) * GEO::BSTRIDE) * RS + g * 16);
             const half8 *hw = reinterpret_cast<const half8 *>(P.head_w) + lane;
-            for (int p = wave; p < HW; p += 4) {
-                const int y = p / W, x = p - y * W;
-                const unsigned poff = (unsigned)(((y + 1) * GEO::PW + x) * RS);
+            const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const half8 af = hw[(size_t)(p * 4 + ks) * 64];
-                    half8 bf = *reinterpret_cast<const half8 *>(img + bbase + poff + ks * 64);
-                    if (!bvalid) bf = (half8){0, 0, 0, 0, 0, 0, 0, 0};
-                    hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, hacc, 0, 0, 0);
+            for (int j0 = 0; j0 < NPW; j0 += JB) {
+                half8 af[JB][4], bf[JB][4];
+#pragma unroll
+                for (int j = 0; j < JB; j++) {
+                    if (j0 + j < NPW) {
+                        const int p = wave + 4 * (j0 + j), pc = min(p, HW - 1);
+                        const int y = pc / W, x = pc - y * W;
+                        const unsigned poff = (unsigned)(((y + 1) * GEO::PW + x) * RS);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ks++) {
+                            af[j][ks] = hw[(size_t)(pc * 4 + ks) * 64];
+                            bf[j][ks] = *reinterpret_cast<const half8 *>(img + bbase + poff + ks * 64);
+                            if (!bvalid || p >= HW) bf[j][ks] = zero8;
+                        }
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < JB; j++)
+                    if (j0 + j < NPW) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ks++) hacc4[ks] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j][ks], bf[j][ks], hacc4[ks], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const floatx4 hacc = (hacc4[0] + hacc4[1]) + (hacc4[2] + hacc4[3]);
             // the reduction scratch lives in the pad rows at the top of the image (zeroed again below) -- but real data of
             // board 0 must not be clobbered before every wave has finished reading it
+            AZG_WGSTAMP(6);
             __syncthreads();
             float *red = reinterpret_cast<float *>(img);
 #pragma unroll
             for (int r = 0; r < 4; r++) red[(wave * 16 + g * 4 + r) * 16 + i16] = hacc[r];
             __syncthreads();
             const int nb_here = min(BOARDS, P.boards - tile * BOARDS);
-            if (tid < nb_here) {
-                float lg[16];
+            if (tid < 64) {                                      // lane = (board, output): both softmaxes inside 16-lane groups
+                const int bd = tid >> 4, o = tid & 15, A = P.A, NV = P.NV;
+                const int bc = bd < BOARDS ? bd : 0;
+                const float lgt = ((red[(0 * 16 + o) * 16 + bc] + red[(1 * 16 + o) * 16 + bc]) + (red[(2 * 16 + o) * 16 + bc] + red[(3 * 16 + o) * 16 + bc]))
+                                  + P.head_b[o];
+                const bool isp = o < A, isv = o >= A && o < A + NV;
+                float mp = isp ? lgt : -INFINITY, mv = isv ? lgt : -INFINITY;
 #pragma unroll
-                for (int o = 0; o < 16; o++) lg[o] = red[(0 * 16 + o) * 16 + tid] + red[(1 * 16 + o) * 16 + tid] + red[(2 * 16 + o) * 16 + tid]
-                                                    + red[(3 * 16 + o) * 16 + tid] + P.head_b[o];
-                const int A = P.A, NV = P.NV;
-                float m = lg[0]; for (int o = 1; o < A; o++) m = fmaxf(m, lg[o]);
-                float sum = 0.f; for (int o = 0; o < A; o++) { lg[o] = __expf(lg[o] - m); sum += lg[o]; }
-                float *po = P.policy + (size_t)(tile * BOARDS + tid) * A;
-                for (int o = 0; o < A; o++) po[o] = lg[o] / sum;
-                m = lg[A]; for (int o = 1; o < NV; o++) m = fmaxf(m, lg[A + o]);
-                sum = 0.f; for (int o = 0; o < NV; o++) { lg[A + o] = __expf(lg[A + o] - m); sum += lg[A + o]; }
-                float *vo = P.value + (size_t)(tile * BOARDS + tid) * NV;
-                for (int o = 0; o < NV; o++) vo[o] = lg[A + o] / sum;
+                for (int d = 8; d; d >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, d, 16)); mv = fmaxf(mv, __shfl_xor(mv, d, 16)); }
+                const float e = isp ? __expf(lgt - mp) : isv ? __expf(lgt - mv) : 0.f;
+                float sp = isp ? e : 0.f, sv = isv ? e : 0.f;
+#pragma unroll
+                for (int d = 8; d; d >>= 1) { sp += __shfl_xor(sp, d, 16); sv += __shfl_xor(sv, d, 16); }
+                if (bd < nb_here) {
+                    if (isp) P.policy[(size_t)(tile * BOARDS + bd) * A + o] = e / sp;
+                    if (isv) P.value[(size_t)(tile * BOARDS + bd) * NV + (o - A)] = e / sv;
+                }
             }
+            AZG_WGSTAMP(7);
             __syncthreads();
             reinterpret_cast<uint4 *>(img)[tid] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
     }
 #ifdef AZG_TOWER_TIMING
-    if (P.dbg && tid == 0) P.dbg[2048 + (size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+    if (P.dbg && tid == 0) P.dbg[2048 + (size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
 #endif
 }
 

@@ -542,7 +542,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
         const int grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
 #ifdef AZG_TOWER_TIMING
         static unsigned long long *dbg = nullptr; static int calls = 0;
-        if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 4) * 8)); }
+        if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 8) * 8)); }
         TowerParams Q = P; Q.dbg = dbg;
         hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C>), dim3(grid), dim3(C * 2), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev]);
         if (++calls == 8) {
@@ -552,9 +552,10 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
                 unsigned long long *t = h + (l * 4 + w) * 5;
                 fprintf(stderr, "layer %2d wave %d: main %6llu wait %6llu epi %6llu bar %6llu | start %llu\n", l, w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[0] - h[0]);
             }
-            static unsigned long long w[4096 * 4];
-            HIPCHK(hipMemcpy(w, dbg + 2048, sizeof(unsigned long long) * 4 * grid, hipMemcpyDeviceToHost));
-            for (int b = 0; b < grid; b++) fprintf(stderr, "wg %4d xcc %llu hwid %08llx start %llu end %llu\n", b, w[b * 4 + 3] & 15, w[b * 4 + 2], w[b * 4], w[b * 4 + 1]);
+            static unsigned long long w[4096 * 8];
+            HIPCHK(hipMemcpy(w, dbg + 2048, sizeof(unsigned long long) * 8 * grid, hipMemcpyDeviceToHost));
+            for (int b = 0; b < grid; b++) fprintf(stderr, "wg %4d xcc %llu hwid %08llx start %llu end %llu | prologue %llu layers %llu headmm %llu softmax %llu tail %llu\n", b, w[b * 8 + 3] & 15, w[b * 8 + 2], w[b * 8], w[b * 8 + 1],
+                                                   w[b * 8 + 4] - w[b * 8], w[b * 8 + 5] - w[b * 8 + 4], w[b * 8 + 6] - w[b * 8 + 5], w[b * 8 + 7] - w[b * 8 + 6], w[b * 8 + 1] - w[b * 8 + 7]);
         }
 #else
         hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C>), dim3(grid), dim3(C * 2), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev]);
