@@ -46,6 +46,42 @@ def selfplay_args(games):
                    startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
 
 
+def cpu_baseline_threads(net, threads=16, seconds=6.0):
+    """The reference's own arrangement (Coach.py:291-342): `workers` agent processes, each searching its batch of games
+    on one host core, all of them queueing on ONE GPU network.  Here: `threads` oracle agents on `threads` host cores
+    (the C oracle runs outside the GIL), 256 games each, the GPU net behind a lock.  Bounded sample."""
+    import threading
+    import oracle_lib as ol
+    Bc = 256
+    threads = max(1, min(threads, (os.cpu_count() or 1) - 2))
+    lock = threading.Lock()
+    agents = [ol.OAgent(0, Bc, sims=SIMS, games_per_iteration=1 << 30, seed=100 + i, cpuct=4.0, fpu_reduction=0.4,
+                        add_root_noise=True, add_root_temp=True) for i in range(threads)]
+    stop = time.time() + seconds
+
+    def work(ag):
+        while time.time() < stop:
+            ag.begin_round()
+            for s in range(SIMS):
+                obs, _, _ = ag.generate_batch()
+                with lock:
+                    p, v = net.process(torch.from_numpy(obs))
+                    p, v = p.cpu().numpy(), v.cpu().numpy()
+                ag.process_batch(p, v)
+            ag.play_moves()
+
+    t0 = time.time()
+    ts = [threading.Thread(target=work, args=(ag,)) for ag in agents]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.time() - t0
+    total = sum(ag.expansions for ag in agents)
+    return {'value': round(total / dt, 1), 'unit': 'expansions/s', 'cores': threads,
+            'sample': '%d oracle agents x %d games x %d sims on %d host cores for %.1f s, one shared GPU net' % (threads, Bc, SIMS, threads, dt)}
+
+
 def cpu_baseline(net, seconds=12.0):
     """The CPU path timed beside the GPU number: the C oracle (bit-exact restatement of the reference Cython path,
     oracle/) drives the same workload on ONE host core, leaves evaluated by the same GPU network through host
@@ -72,7 +108,8 @@ def cpu_baseline(net, seconds=12.0):
             sims_done += Bc
         t0 = time.time(); ag.play_moves(); dt = time.time() - t0
         t_tree += dt; t_all += dt
-    return {'value': round(ag.expansions / t_all, 1), 'unit': 'expansions/s', 'cores': 1, 'kind': 'port',
+    many = cpu_baseline_threads(net)
+    return {'value': round(ag.expansions / t_all, 1), 'unit': 'expansions/s', 'cores': 1, 'kind': 'port', 'many_cores': many,
             'sample': 'connect4 %d games x %d sims, %d simulations in %.1f s on one host core, leaves evaluated by the same GPU net '
                       'through host buffers' % (Bc, SIMS, sims_done, t_all),
             'tree_only_value': round(ag.expansions / t_tree, 1), 'host_cpus': os.cpu_count()}
