@@ -747,7 +747,7 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
 // ---- collapsed heads for large action spaces (brandubh: A + NV = 591) ------------------------------------------------------
 // logits[b, o] = sum_k y[b, k] * Wh[k, o] + bias[o] over the tower's final stream y [boards, K = H*W*C] (fp16 rows), then the
 // two softmaxes of NNetArchitecture.py:112-118.  Too wide to fuse behind the tower (every tile would stream the whole 3.7 MB
-// matrix), so it is its own launch: workgroup = (16 boards) x (HEAD_NS output subtiles of 16); its four waves split K, each
+// matrix), so it is its own launch: workgroup = (16 boards) x (HEAD_NS output subtiles of 16); its eight waves split K, each
 // streaming activation fragments (A operand: 16 boards x 32 k) and pre-packed weight fragments (B operand: 32 k x 16 outputs,
 // [k-step][subtile][64 lanes][8 halves]) straight from L2 -- no reuse inside a workgroup, so no LDS staging.  With
 // blockIdx = group * nchunks + chunk and 8 chunks, the workgroups sharing a weight chunk sit on one XCD (blockIdx mod 8).

@@ -326,7 +326,7 @@ class NNetWrapper:
         self.dtype = dtype if self.device.type == 'cuda' else torch.float32
         self.fast = fast
         # backend: 'torch' = folded PyTorch modules (MIOpen); 'hip' = hand-written MFMA tower (csrc/azg_conv.h);
-        # 'auto' = hip when the net is a 128-channel tower on a GPU and the game has a conv geometry, else torch
+        # 'auto' = hip when the kernel is instantiated for (game geometry, tower width) and a GPU is present, else torch
         self.backend = backend
         self._infer = None
         self._hip = None
