@@ -563,3 +563,80 @@ def test_tm_agent_vs_reference_goldens(torch_mod, cname, kw):
     ws, turns, slot = eng.results()
     assert (ws == d[cname + '_r_ws']).all() and (turns == d[cname + '_r_turns']).all()
     eng.close()
+
+
+# --------------------------------------------------- full-size properties of the other BASELINE configs (3 and 5)
+@pytest.mark.parametrize('game,B,sims,cpuct,fpu', [(1, 512, 200, 1.25, 0.2), (2, 256, 50, 1.25, 0.2)])
+def test_other_configs_full_size_properties(torch_mod, game, B, sims, cpuct, fpu):
+    """brandubh 512 games x 200 sims (config 3, per-GPU shard) and the 3-player env 256 x 50 (config 5): visit-count
+    conservation, pi a distribution over visited children, sharding invariance, sampled action visited, noise on."""
+    torch = torch_mod
+    from alphazero_general_amd import _abi
+    gi = _abi.game_info(game)
+    A, NV = gi.action_size, gi.num_players + 1
+    seed = 11
+    kw = dict(game=game, seed=seed, cpuct=cpuct, fpu_reduction=fpu, games_per_iteration=1 << 30, sims_hint=sims,
+              add_root_noise=True, add_root_temp=True)
+    eng = engine(B=B, example_capacity=4096, **kw)
+    eng2 = engine(B=B // 4, slot_base=3 * B // 4, example_capacity=1024, **kw)
+    g = torch.Generator(device='cpu'); g.manual_seed(1)
+    obs, obs2 = eng.new_obs(torch.float16), eng2.new_obs(torch.float16)
+    for move in range(2):
+        for s in range(sims):
+            pol = torch.rand((B, A), generator=g) + 1e-3
+            pol = (pol / pol.sum(1, keepdim=True)).to(eng.device)
+            val = torch.rand((B, NV), generator=g) + 1e-3
+            val = (val / val.sum(1, keepdim=True)).to(eng.device)
+            eng.select(obs); eng.backup(pol, val)
+            eng2.select(obs2); eng2.backup(pol[3 * B // 4:].contiguous(), val[3 * B // 4:].contiguous())
+        cnt = eng.root_counts()
+        if move == 0:
+            assert (cnt.sum(1) == sims - 1).all()                    # Q8
+        pr = eng.root_probs(1.0)
+        assert torch.allclose(pr.sum(1), torch.ones(B, device=eng.device), atol=1e-5)
+        assert ((pr > 0) == (cnt > 0)).all()
+        assert (cnt[3 * B // 4:] == eng2.root_counts()).all()        # sharding invariance (global slot ids)
+        assert torch.equal(obs[3 * B // 4:], obs2)                   # ... down to the last leaf observation
+        eng.advance(True); eng2.advance(True)
+        act = eng.last_actions().long()
+        assert (act[3 * B // 4:] == eng2.last_actions().long()).all()
+        assert (cnt.gather(1, act[:, None]) > 0).all()
+    c = eng.counters()
+    assert c['sims'] == 2 * sims * B and c['expansions'] <= c['sims'] and c['max_nodes_used'] > 0
+    assert all(t == 2 for (_, _, t) in eng.get_states(0, 8))
+    eng.close(); eng2.close()
+
+
+@pytest.mark.parametrize('game', [0, 2])
+def test_whole_games_sample_invariants(torch_mod, game):
+    """play whole games on the device (uniform evaluator, few sims) and check what Coach would save (Coach.py:377-383):
+    z rows are the one-hot winstate of their game, pi rows are distributions over legal moves, every finished game
+    contributes (its length x symmetries) samples, results and counters agree."""
+    torch = torch_mod
+    from alphazero_general_amd import _abi
+    gi = _abi.game_info(game)
+    A, NV, B, sims = gi.action_size, gi.num_players + 1, 128, 6
+    nsym = gi.num_symmetries
+    eng = engine(game=game, B=B, seed=3, games_per_iteration=1 << 30, sims_hint=sims,
+                 example_capacity=B * 6 * (gi.max_turns + 1) * nsym)
+    pol = torch.full((B, A), 1.0 / A, device=eng.device); val = torch.full((B, NV), 1.0 / NV, device=eng.device)
+    rounds = 3 * gi.max_turns // 2
+    for _ in range(rounds):
+        for s in range(sims):
+            eng.select(None); eng.backup(pol, val)
+        eng.advance(True)
+    c = eng.counters()
+    assert c['games_played'] >= B                                    # every slot finished at least one game
+    o, p, z = [t.cpu().numpy() for t in eng.examples()]
+    ws, turns, slot = eng.results()
+    assert len(ws) == c['num_results'] == c['games_played'] and o.shape[0] == c['num_examples'] == int(turns.sum()) * nsym
+    assert ((z == 0) | (z == 1)).all() and (z.sum(1) == 1).all()
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5) and (p >= 0).all()
+    # samples come game by game in result order: block g has turns[g] * nsym rows, all with z == winstate of game g
+    off = 0
+    for gidx in range(len(ws)):
+        n = int(turns[gidx]) * nsym
+        assert (z[off:off + n] == ws[gidx].astype(np.float32)).all()
+        off += n
+    assert off == o.shape[0]
+    eng.close()
