@@ -46,6 +46,23 @@ def selfplay_args(games):
                    startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
 
 
+def library_gemm_tflops(dev, n=8192, reps=10):
+    """fp16 n^3 GEMM through torch (hipBLASLt), TFLOP/s."""
+    x = torch.randn(n, n, device=dev, dtype=torch.float16); y = torch.randn(n, n, device=dev, dtype=torch.float16)
+    best = 0.0
+    for _ in range(2):
+        for _ in range(3):
+            x @ y
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            x @ y
+        e1.record(); torch.cuda.synchronize()
+        best = max(best, 2 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
 def cpu_baseline_threads(net, threads=16, seconds=6.0):
     """The reference's own arrangement (Coach.py:291-342): `workers` agent processes, each searching its batch of games
     on one host core, all of them queueing on ONE GPU network.  Here: `threads` oracle agents on `threads` host cores
@@ -268,6 +285,12 @@ def main():
         'games_finished': games_done, 'samples_gathered': nsamples,
         'roofline': roof, 'tree_roofline': tree,
     }
+    if nn_ms is not None:
+        # context for the MFMA fraction: the best plain fp16 GEMM the vendor library reaches on this very GPU (outside the
+        # timed region; SURVEY.md 8d asks for it next to the datasheet peak)
+        lib_tf = library_gemm_tflops(dev)
+        out['roofline']['library_gemm_tflops'] = round(lib_tf, 1)
+        out['roofline']['vs_library_gemm'] = round(tf / lib_tf, 3)
     if a.gpus == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(net)
     print(json.dumps(out))
