@@ -500,15 +500,20 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
     }
 }
 
-template <int H, int W, int BOARDS, int C>
-__global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int16_t *pixmap) {
+// PSPLIT > 1 (narrow towers at small batches, where a workgroup of C/32 waves leaves SIMDs empty): the tile's pixel subtiles
+// are dealt to PSPLIT wave groups, wave = (cout group cg, pixel group ph); every wave still streams its own cout slice.
+template <int H, int W, int BOARDS, int C, int PSPLIT = 1>
+__global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, const int16_t *pixmap) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
+    static_assert(PSPLIT == 1 || C < 128, "the fused heads assume one wave per cout group");
     TowerParams P = Pin;
-    constexpr int NT = C * 2, KS = C / 32, CPR = C / 8;      // threads (C/32 waves: 32 couts each), k-steps per tap, 16-B chunks per row
-    constexpr int HW = GEO::HW, ROWS = GEO::ROWS, NSUB = GEO::NSUB, TILE = GEO::TILE, RS = GEO::RSTRIDE;
+    constexpr int NT = C * 2 * PSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
+    constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
+    constexpr int HW = GEO::HW, ROWS = GEO::ROWS, TILE = GEO::TILE, RS = GEO::RSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int cg = wave % (C / 32), ph = wave / (C / 32);
     int ntiles = (Pin.boards + BOARDS - 1) / BOARDS;
     if (Pin.rows_per_model) {
         ntiles = 0;
@@ -517,10 +522,11 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
     for (int c = tid; c < TILE / 16; c += NT) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
     unsigned lb[NSUB];
     unsigned livemask = 0;
-    const int ecol = (g & 1) ? (2 * wave + 1) * 16 + (g - 1) * 4 : (2 * wave) * 16 + g * 4;
+    const int ecol = (g & 1) ? (2 * cg + 1) * 16 + (g - 1) * 4 : (2 * cg) * 16 + g * 4;
 #pragma unroll
     for (int ps = 0; ps < NSUB; ps++) {
-        const int p = pixmap[ps * 16 + i16];
+        const int gs = ph * NSUB + ps;                          // the tile's subtile this wave's ps-th one is
+        const int p = gs < NSUBT ? pixmap[min(gs, NSUBT - 1) * 16 + i16] : -1;
         if (p >= 0) livemask |= 1u << ps;
         const int q = p >= 0 ? GEO::qrow(p) : GEO::LEAD;
         lb[ps] = (unsigned)(q * RS + g * 16 - GEO::BIAS);
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
                 P.w = Pin.w; P.bias = Pin.bias; P.pre_scale = Pin.pre_scale; P.pre_shift = Pin.pre_shift; P.head_w = Pin.head_w; P.head_b = Pin.head_b;
             }
         }
-        const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
+        const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * cg) * 64 + lane;
         const int row0 = tile * ROWS;
         const int rows_here = min(ROWS, P.boards * HW - row0);
         {
@@ -572,9 +578,16 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
                 *reinterpret_cast<uint4 *>(img + GEO::qrow(p) * RS + chunk * 16) = v;
             }
         }
+#ifdef AZG_TOWER_TIMING
+        if (P.dbg && tid == 0) P.dbg[1024 + blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+#endif
         const half8 *wt = wl;
 #pragma unroll
         for (int j = 0; j < WR - 1; j++) { a[j][0] = wt[(size_t)j * GEO::WSTEP]; a[j][1] = wt[(size_t)j * GEO::WSTEP + 64]; }
+#ifdef AZG_TOWER_TIMING
+        asm volatile("s_waitcnt vmcnt(0)");
+        if (P.dbg && tid == 0) P.dbg[1024 + blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
 #ifdef AZG_TOWER_TIMING
 #define AZG_STAMP2(i) do { if (P.dbg && blockIdx.x == 0 && tile == 0 && lane == 0) P.dbg[(layer * 4 + wave) * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(C * 2, 2) void k_tower2(TowerParams Pin, const int1
             const half2v zero2 = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
             for (int m = 0; m < 2; m++) {
-                const int c0 = (2 * wave + m) * 16 + g * 4;
+                const int c0 = (2 * cg + m) * 16 + g * 4;
                 const floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;

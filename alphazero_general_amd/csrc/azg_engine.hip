@@ -513,7 +513,7 @@ extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void
     }
 }
 
-template <int H, int W, int BOARDS, int C>
+template <int H, int W, int BOARDS, int C, int PSPLIT = 1>
 static int launch_tower(hipStream_t s, const TowerParams &P) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
     static int16_t *d_map[16] = {nullptr};                                  // per device: pixel -> (subtile, lane) table
@@ -525,7 +525,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
         tower_pixmap<GEO>(map);
         HIPCHK(hipMalloc((void **)&d_map[dev], sizeof(map)));
         HIPCHK(hipMemcpy(d_map[dev], map, sizeof(map), hipMemcpyHostToDevice));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
         if constexpr (C == 128)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)GEO::TILE));
     }
@@ -544,7 +544,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
         static unsigned long long *dbg = nullptr; static int calls = 0;
         if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 8) * 8)); }
         TowerParams Q = P; Q.dbg = dbg;
-        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C>), dim3(grid), dim3(C * 2), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev]);
+        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev]);
         if (++calls == 8) {
             unsigned long long h[64 * 4 * 5];
             HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
@@ -554,11 +554,14 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
             }
             static unsigned long long w[4096 * 8];
             HIPCHK(hipMemcpy(w, dbg + 2048, sizeof(unsigned long long) * 8 * grid, hipMemcpyDeviceToHost));
+            unsigned long long x2[1024];
+            HIPCHK(hipMemcpy(x2, dbg + 1024, sizeof(x2), hipMemcpyDeviceToHost));
+            for (int b = 0; b < grid && b < 512; b++) fprintf(stderr, "wgx %4d xload+store %llu weights %llu\n", b, x2[b * 2] - w[b * 8], x2[b * 2 + 1] - x2[b * 2]);
             for (int b = 0; b < grid; b++) fprintf(stderr, "wg %4d xcc %llu hwid %08llx start %llu end %llu | prologue %llu layers %llu headmm %llu softmax %llu tail %llu\n", b, w[b * 8 + 3] & 15, w[b * 8 + 2], w[b * 8], w[b * 8 + 1],
                                                    w[b * 8 + 4] - w[b * 8], w[b * 8 + 5] - w[b * 8 + 4], w[b * 8 + 6] - w[b * 8 + 5], w[b * 8 + 7] - w[b * 8 + 6], w[b * 8 + 1] - w[b * 8 + 7]);
         }
 #else
-        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C>), dim3(grid), dim3(C * 2), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev]);
+        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev]);
 #endif
     }
     HIPCHK(hipGetLastError());
@@ -577,14 +580,21 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
         return launch_tower<C4::H, C4::W, 4, 128>(s, P);
     }
     if (game == AZG_GAME_CONNECT4 && channels == 64) return launch_tower<C4::H, C4::W, 4, 64>(s, P);
-    if (game == AZG_GAME_BRANDUBH && channels == 64) {
+    static const int psplit = getenv("AZG_TOWER_PSPLIT") ? atoi(getenv("AZG_TOWER_PSPLIT")) : 0;   // measurement knob
+    if (game == AZG_GAME_BRANDUBH && channels == 64) {           // two cout groups: split the pixels too at small batches
         const int bt = forced ? forced : n <= 1024 ? 1 : 2;
+        const int sp = psplit ? psplit : 1;
+        if (bt == 1 && sp == 2) return launch_tower<BR::H, BR::W, 1, 64, 2>(s, P);
         if (bt == 1) return launch_tower<BR::H, BR::W, 1, 64>(s, P);
+        if (sp == 2) return launch_tower<BR::H, BR::W, 2, 64, 2>(s, P);
         return launch_tower<BR::H, BR::W, 2, 64>(s, P);
     }
     if (game == AZG_GAME_BRANDUBH && channels == 128) return launch_tower<BR::H, BR::W, 2, 128>(s, P);
-    if (game == AZG_GAME_TRIMOK && channels == 32) {             // one wave per workgroup
+    if (game == AZG_GAME_TRIMOK && channels == 32) {             // one cout group
         const int bt = forced ? forced : n <= 2048 ? 2 : 5;
+        const int sp = psplit ? psplit : 1;
+        if (bt == 2 && sp == 4) return launch_tower<TM::H, TM::W, 2, 32, 4>(s, P);
+        if (bt == 2 && sp == 2) return launch_tower<TM::H, TM::W, 2, 32, 2>(s, P);
         if (bt == 2) return launch_tower<TM::H, TM::W, 2, 32>(s, P);
         return launch_tower<TM::H, TM::W, 5, 32>(s, P);
     }
