@@ -75,12 +75,11 @@ AZG_DEV int add_children(const View &ev, int slot, Node *nodes, TreeHdr *h, int 
 }
 
 // ================================================================================================ select
-template <class G, typename OT, bool NHWC8 = false>
-__global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *row_of_slot) {
-    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
+// One wavefront runs find_leaf for one slot; `sink(st, lane)` receives the leaf state (it writes the observation wherever the
+// network reads it: the dense batch in HBM for k_select, straight into the tower's LDS image for the fused search kernel).
+template <class G, class Sink>
+AZG_DEV void select_slot(const View &ev, int slot, int lane, int *act_lds, Sink &&sink) {
     constexpr int NCH = (G::MAXK + 63) / 64;
-    __shared__ int act_lds[NCH * 64];
-    const int slot = blockIdx.x, lane = threadIdx.x;
     typename G::S st = G::load(&ev.states[slot], lane);
     const int tree = ev.arena ? slot * ev.T + st.player : slot;
     Node *nodes = ev.nodes + (size_t)tree * ev.cap;
@@ -153,22 +152,30 @@ __global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *
         ev.slot_exp[slot] += expanded;
     }
     G::store(st, &ev.leaf_states[slot], lane);
-    if (obs) {
-        const int row = row_of_slot ? row_of_slot[slot] : slot;
-        if constexpr (NHWC8) G::write_obs_nhwc8(st, (_Float16 *)obs + (size_t)row * G::CELLS * 8, lane);
-        else G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);     // SelfPlayAgent.pyx:116-123
-    }
+    sink(st, lane);
+}
+
+template <class G, typename OT, bool NHWC8 = false>
+__global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *row_of_slot) {
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
+    __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
+    const int slot = blockIdx.x;
+    select_slot<G>(ev, slot, threadIdx.x, act_lds, [&](const typename G::S &st, int lane) {
+        if (obs) {
+            const int row = row_of_slot ? row_of_slot[slot] : slot;
+            if constexpr (NHWC8) G::write_obs_nhwc8(st, (_Float16 *)obs + (size_t)row * G::CELLS * 8, lane);
+            else G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);     // SelfPlayAgent.pyx:116-123
+        }
+    });
 }
 
 // ================================================================================================ backup
+// One wavefront runs process_results for one slot with its policy row pi[A] and value row vrow[P+1] (HBM or LDS).
+// m_lds [max(A, 8)] and scr [64] are wave-private scratch (only used when A >= 8).
 template <class G>
-__global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, const float *value, const int32_t *row_of_slot) {
-    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
+AZG_DEV void backup_slot(const View &ev, int slot, int lane, const float *pi, const float *vrow, float *m_lds, float *scr) {
     constexpr int NCH = (G::MAXK + 63) / 64;
     constexpr int A = G::A, P = G::P, NV = P + 1, NE = P + G::HAS_DRAW;
-    __shared__ float m_lds[A < 8 ? 8 : A];
-    __shared__ float scr[64];
-    const int slot = blockIdx.x, lane = threadIdx.x;
     const int mover0 = __builtin_amdgcn_readfirstlane(ev.states[slot].player);
     const int tree = ev.arena ? slot * ev.T + mover0 : slot;
     Node *nodes = ev.nodes + (size_t)tree * ev.cap;
@@ -176,7 +183,6 @@ __global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, con
     const uint32_t *path = ev.path + (size_t)tree * ev.maxd;
     const int cur = __builtin_amdgcn_readfirstlane(h->cur), depth = __builtin_amdgcn_readfirstlane(h->depth);
     const int root = __builtin_amdgcn_readfirstlane(h->root);
-    const int row = row_of_slot ? row_of_slot[slot] : slot;
     NodeR cn;
     { uint4 lo, hi; load_node(nodes + cur, lo, hi); unpack(lo, hi, cn); }
     float val[NV > NE ? NV : NE];
@@ -187,11 +193,10 @@ __global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, con
         vsize = NE;
     } else {
 #pragma unroll
-        for (int j = 0; j < NV; j++) val[j] = value[(size_t)row * NV + j];
+        for (int j = 0; j < NV; j++) val[j] = vrow[j];
         vsize = NV;
         // ---- mask + renormalise the policy over the node's children (:239-245) ----
         const int k = cn.nchild, fc = cn.fc;
-        const float *pi = policy + (size_t)row * A;
         int ca[NCH]; float cp[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -287,6 +292,16 @@ __global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, con
         }
     }
     if (lane == 0) { nodes[root].n += 1; ev.slot_sims[slot] += 1; }          // :289
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, const float *value, const int32_t *row_of_slot) {
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
+    __shared__ float m_lds[G::A < 8 ? 8 : G::A];
+    __shared__ float scr[64];
+    const int slot = blockIdx.x;
+    const int row = row_of_slot ? row_of_slot[slot] : slot;
+    backup_slot<G>(ev, slot, threadIdx.x, policy + (size_t)row * G::A, value + (size_t)row * (G::P + 1), m_lds, scr);
 }
 
 // ================================================================================================ root stats
