@@ -82,6 +82,7 @@ SYMBOLS = {
     'azg_resnet_tower_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'azg_resnet_policy_value_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'azg_resnet_policy_value_multi_f16': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'azg_search_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     'azg_policy_value_heads_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'azg_profile_enable': (_i, [_vp, _i]),
     'azg_profile_read': (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_int64)]),

@@ -502,14 +502,29 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
 
 // PSPLIT > 1 (narrow towers at small batches, where a workgroup of C/32 waves leaves SIMDs empty): the tile's pixel subtiles
 // are dealt to PSPLIT wave groups, wave = (cout group cg, pixel group ph); every wave still streams its own cout slice.
-template <int H, int W, int BOARDS, int C, int PSPLIT = 1>
-__global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, const int16_t *pixmap) {
+//
+// SEARCH = SearchArgs<G> turns the kernel into the whole simulation loop of its games (no launch, no HBM round trip per
+// simulation): a workgroup owns BOARDS = C/32 games, wave w runs find_leaf for game w and writes the leaf observation straight
+// into the LDS image, the workgroup evaluates its boards, wave w backs game w up from the probabilities left in LDS -- `sims`
+// times.  Workgroups never synchronise with each other.  (Measured: the same throughput as three launches per simulation --
+// the tower is bound by LDS-read issue and power, not by launch gaps; staggering the two workgroups of a CU changed nothing.)
+struct NoSearch {};
+template <class G> struct SearchArgs { View ev; int sims; using Game = G; };
+
+template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
+__global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
+    constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     static_assert(PSPLIT == 1 || C < 128, "the fused heads assume one wave per cout group");
+    static_assert(!IS_SEARCH || (PSPLIT == 1 && C == 128 && BOARDS == C / 32), "search mode: one wave per game, fused heads");
     TowerParams P = Pin;
     constexpr int NT = C * 2 * PSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
     constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
     constexpr int HW = GEO::HW, ROWS = GEO::ROWS, TILE = GEO::TILE, RS = GEO::RSTRIDE;
+    // LDS scratch in the zero rows above board 0 (restored to zero after use): [0, 4096) heads reduction, then 256 B of
+    // probabilities + a flag word (search mode) -- all inside the pad line, which ends at (LEAD + PW) * RS
+    constexpr int SCRATCH_PV = 4096;
+    static_assert(!IS_SEARCH || SCRATCH_PV + 1024 <= (GEO::LEAD + GEO::PW) * RS, "scratch must stay inside the pad rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
@@ -569,7 +584,37 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
         const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * cg) * 64 + lane;
         const int row0 = tile * ROWS;
         const int rows_here = min(ROWS, P.boards * HW - row0);
-        {
+        int nsims = 1;
+        if constexpr (IS_SEARCH) nsims = sa.sims;
+        for (int sim = 0; sim < nsims; sim++) {
+        if constexpr (IS_SEARCH) {
+            using G = typename SEARCH::Game;
+            static_assert(G::CELLS == HW && G::A < 8, "search mode needs a game whose tree functions use no LDS scratch");
+            // a sticky device error (tree arena full) stops the trees; the decision must be uniform over the workgroup
+            int *flag = reinterpret_cast<int *>(img + SCRATCH_PV + 512);
+            if (tid == 0) *flag = sa.ev.gcount[GC_ERROR];
+            __syncthreads();
+            const int err = *flag;
+            __syncthreads();
+            if (tid == 0) *flag = 0;
+            if (err) break;
+            const int slot = tile * BOARDS + wave;
+            if (slot < sa.ev.B) {
+                select_slot<G>(sa.ev, slot, lane, nullptr, [&](const typename G::S &st, int ln) {
+                    if (ln < HW) {                               // leaf observation -> the image rows of board `wave`, channels 8.. zero
+                        char *row = img + GEO::qrow(wave * HW + ln) * RS;
+                        *reinterpret_cast<half8 *>(row) = G::obs8(st, ln);
+                        const uint4 z = make_uint4(0, 0, 0, 0);
+                        *reinterpret_cast<uint4 *>(row + 16) = z; *reinterpret_cast<uint4 *>(row + 32) = z; *reinterpret_cast<uint4 *>(row + 48) = z;
+                    }
+                });
+            } else if (lane < HW) {
+                char *row = img + GEO::qrow(wave * HW + lane) * RS;
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(row) = z; *reinterpret_cast<uint4 *>(row + 16) = z;
+                *reinterpret_cast<uint4 *>(row + 32) = z; *reinterpret_cast<uint4 *>(row + 48) = z;
+            }
+        } else {
             const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
             for (int c = tid; c < ROWS * 4; c += NT) {
                 const int p = c >> 2, chunk = c & 3;
@@ -741,16 +786,27 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
                 float sp = isp ? e : 0.f, sv = isv ? e : 0.f;
 #pragma unroll
                 for (int d = 8; d; d >>= 1) { sp += __shfl_xor(sp, d, 16); sv += __shfl_xor(sv, d, 16); }
-                if (bd < nb_here) {
+                if constexpr (IS_SEARCH) {                       // probabilities stay in LDS for the backup waves: [board][16]
+                    reinterpret_cast<float *>(img + SCRATCH_PV)[bd * 16 + o] = isp ? e / sp : e / sv;
+                } else if (bd < nb_here) {
                     if (isp) P.policy[(size_t)(tile * BOARDS + bd) * A + o] = e / sp;
                     if (isv) P.value[(size_t)(tile * BOARDS + bd) * NV + (o - A)] = e / sv;
                 }
             }
+            if constexpr (IS_SEARCH) {
+                using G = typename SEARCH::Game;
+                __syncthreads();
+                const int slot = tile * BOARDS + wave;
+                const float *pv = reinterpret_cast<const float *>(img + SCRATCH_PV) + wave * 16;
+                if (slot < sa.ev.B) backup_slot<G>(sa.ev, slot, lane, pv, pv + P.A, nullptr, nullptr);
+            }
             AZG_WGSTAMP(7);
             __syncthreads();
             reinterpret_cast<uint4 *>(img)[tid] = make_uint4(0, 0, 0, 0);
+            if constexpr (IS_SEARCH) { if (tid < 16) reinterpret_cast<uint4 *>(img + SCRATCH_PV)[tid] = make_uint4(0, 0, 0, 0); }
         }
         __syncthreads();
+        }                                                        // sims
     }
 #ifdef AZG_TOWER_TIMING
     if (P.dbg && tid == 0) P.dbg[2048 + (size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();

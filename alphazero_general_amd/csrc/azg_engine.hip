@@ -513,8 +513,9 @@ extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void
     }
 }
 
-template <int H, int W, int BOARDS, int C, int PSPLIT = 1>
-static int launch_tower(hipStream_t s, const TowerParams &P) {
+template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
+static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}) {
+    constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     using GEO = TowerGeom<H, W, BOARDS, C>;
     static int16_t *d_map[16] = {nullptr};                                  // per device: pixel -> (subtile, lane) table
     int dev = 0, cus = 256;
@@ -525,26 +526,27 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
         tower_pixmap<GEO>(map);
         HIPCHK(hipMalloc((void **)&d_map[dev], sizeof(map)));
         HIPCHK(hipMemcpy(d_map[dev], map, sizeof(map), hipMemcpyHostToDevice));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
         if constexpr (C == 128)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)GEO::TILE));
     }
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS + (P.rows_per_model ? P.nmodels - 1 : 0);
     static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
-    if (C == 128 && variant == 1) {                          // one workgroup per CU, two LDS images, deep prefetch
+    if (C == 128 && variant == 1 && !IS_SEARCH) {            // one workgroup per CU, two LDS images, deep prefetch
         if constexpr (C == 128) {
             const int grid = ntiles < cus ? ntiles : cus;
             hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), (size_t)2 * GEO::TILE, s, P, (const int16_t *)d_map[dev]);
         }
     } else {                                                 // one LDS image, residual stream in registers, >= 2 workgroups per CU
         const int per_cu = (int)(160 * 1024 / GEO::TILE) > 0 ? (int)(160 * 1024 / GEO::TILE) : 1;
-        const int grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
+        // (search mode: every tile is its own workgroup for the whole launch -- they never synchronise, later ones just start later)
+        const int grid = IS_SEARCH || ntiles < per_cu * cus ? ntiles : per_cu * cus;
 #ifdef AZG_TOWER_TIMING
         static unsigned long long *dbg = nullptr; static int calls = 0;
         if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 8) * 8)); }
         TowerParams Q = P; Q.dbg = dbg;
-        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev]);
+        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev], sa);
         if (++calls == 8) {
             unsigned long long h[64 * 4 * 5];
             HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
@@ -561,7 +563,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P) {
                                                    w[b * 8 + 4] - w[b * 8], w[b * 8 + 5] - w[b * 8 + 4], w[b * 8 + 6] - w[b * 8 + 5], w[b * 8 + 7] - w[b * 8 + 6], w[b * 8 + 1] - w[b * 8 + 7]);
         }
 #else
-        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev]);
+        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev], sa);
 #endif
     }
     HIPCHK(hipGetLastError());
@@ -638,6 +640,19 @@ extern "C" int azg_resnet_policy_value_multi_f16(void *stream, int game, const v
     for (int m = 1; m < nmodels; m++)
         P.alt[m - 1] = TowerParams::Model{w[m], bias[m], nblocks ? pre_scale[m] : nullptr, nblocks ? pre_shift[m] : nullptr, head_w[m], head_b[m]};
     return dispatch_tower((hipStream_t)stream, game, 128, P);
+}
+
+extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
+                              int nblocks, const void *head_w, const float *head_b, int sims) {
+    if (!e || !w || !bias || !head_w || !head_b || nblocks < 0 || sims < 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
+    if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
+    if (e->cfg.game != AZG_GAME_CONNECT4 || e->v.arena)
+        return fail(AZG_E_UNSUPPORTED, "the fused search kernel is built for connect4 self-play with a 128-channel tower (use azg_select / network / azg_backup)");
+    if (sims == 0) return AZG_OK;
+    const int A = e->gi.action_size, NV = e->gi.num_players + 1;
+    TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, head_w, head_b, nullptr, nullptr, A, NV, nullptr, nullptr, 0, {}};
+    SearchArgs<C4> sa{e->v, sims};
+    return launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa);
 }
 
 extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,

@@ -91,14 +91,14 @@ struct C4 {
         }
     }
     // the same four planes as NHWC fp16 rows with the channel dim padded to 8 (input format of the MFMA stem conv)
-    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
-        if (lane < CELLS) {
-            const int c = cell(s, lane);
-            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-            h8 v = {(_Float16)(c == 1 ? 1.f : 0.f), (_Float16)(c == -1 ? 1.f : 0.f), (_Float16)(float)s.player,
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    static AZG_DEV h8 obs8(const S &s, int lane) {               // the four planes of cell `lane` (< CELLS), channels 4..7 zero
+        const int c = cell(s, lane);
+        return (h8){(_Float16)(c == 1 ? 1.f : 0.f), (_Float16)(c == -1 ? 1.f : 0.f), (_Float16)(float)s.player,
                     (_Float16)(float)((double)s.turns / 42.0), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            *reinterpret_cast<h8 *>(out + lane * 8) = v;
-        }
+    }
+    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
+        if (lane < CELLS) *reinterpret_cast<h8 *>(out + lane * 8) = obs8(s, lane);
     }
     // connect4.pyx:96-99: k = 1 mirrors the columns, pi -> pi[::-1]
     static AZG_DEV S symmetry(const S &s, int k) {

@@ -270,6 +270,18 @@ class HipResNet:
         logits = torch.matmul(s.view(B, self.HW * self.CH), self.head_w).float() + self.head_b
         return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
 
+    def search(self, engine, sims):
+        """`sims` whole simulations (select -> this network -> backup) on every slot of `engine` in one persistent launch
+        (azg_search_f16): the trees, the leaf batch and the probabilities never leave the GPU's LDS/HBM and nothing is
+        launched per simulation.  connect4 self-play with the fused 128-channel tower + heads only."""
+        if not (self.fused and self.fused_head):
+            raise NotImplementedError('the fused search kernel needs the fused tower + heads (128 channels, A + NV <= 16)')
+        import ctypes as C
+        vp = lambda q: C.c_void_p(q.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.L.azg_search_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
+                                          len(self.blocks), vp(self.head_w_packed), vp(self.head_b16), int(sims)))
+
     @staticmethod
     def forward_models(nets, x_all, policy_all, value_all, rows_per_model):
         """Arena evaluation in ONE launch without a host read of the batch split: nets[m] (HipResNets of one architecture)

@@ -220,6 +220,15 @@ int  azg_resnet_policy_value_multi_f16(void *stream, int game, const void *x_dev
                                        const void *const *head_w_packed_dev, const float *const *head_b_dev, int A, int NV,
                                        float *policy_dev, float *value_dev, const int32_t *rows_per_model_dev);
 
+/* `sims` whole simulations -- SelfPlayAgent.run's inner loop (:87-92): generateBatch, NNetWrapper.process, processBatch --
+ * on every slot of the engine in ONE persistent launch: a workgroup owns four games, one wavefront each walks its tree
+ * (azg_select's code), the leaf observations go straight into the tower's LDS image, the workgroup evaluates them
+ * (azg_resnet_policy_value_f16's code) and each wavefront backs its game up (azg_backup's code, engine flags) from the
+ * probabilities left in LDS.  Results are identical to `sims` x [azg_select, azg_resnet_policy_value_f16, azg_backup].
+ * connect4 self-play engines with a 128-channel tower only (AZG_E_UNSUPPORTED otherwise); parameters as above. */
+int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const float *bias_dev, const float *pre_scale_dev,
+                    const float *pre_shift_dev, int nblocks, const void *head_w_packed_dev, const float *head_b_dev, int sims);
+
 /* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same
  * [k = H*W*C, A+NV] matrix applied to the final stream y [boards, k] fp16 that azg_resnet_tower_f16 stores, then the
  * two softmaxes.  head_w_packed: fragment order [k/32][OS = ceil((A+NV)/16)][64 lanes][8 halves], lane g*16+i, half j

@@ -76,3 +76,32 @@ def test_selfplay_runner_launch_strategy_is_invisible(variant):
         key = lambda o, p, zz: sorted(map(bytes, np.concatenate([o.reshape(len(o), -1), p, zz], axis=1)))
         assert key(a[0], a[1], a[2]) == key(b[0], b[1], b[2])
         assert sorted(zip(a[5].tolist(), a[4].tolist())) == sorted(zip(b[5].tolist(), b[4].tolist()))
+
+
+def test_fused_search_kernel_equals_three_kernel_path():
+    """azg_search_f16 (one persistent launch: tree walk, MFMA tower, backup for `sims` simulations) against the same number
+    of [azg_select, azg_resnet_policy_value_f16, azg_backup] rounds on a twin engine: identical trees, moves, samples."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    net = _net(4); net.refresh()
+    hip = net._hip
+    B, sims = 203, 17                                              # 203: the last workgroup owns 3 games, not 4
+    kw = dict(cpuct=4.0, fpu_reduction=0.4, add_root_noise=True, add_root_temp=True, seed=12, games_per_iteration=1 << 30,
+              example_capacity=B * 43 * 2 * 3, sims_hint=sims)
+    ea, eb = DeviceEngine(0, B, **kw), DeviceEngine(0, B, **kw)
+    obs = torch.zeros((B, 42, 8), dtype=torch.float16, device=ea.device)
+    for move in range(30):
+        hip.search(ea, sims)
+        for _ in range(sims):
+            eb.select(obs)
+            p, v = hip.forward_nhwc8(obs)
+            eb.backup(p, v)
+        ca, cb = ea.root_counts(), eb.root_counts()
+        assert torch.equal(ca, cb), move
+        assert torch.equal(ea.root_probs(1.0), eb.root_probs(1.0))
+        ea.advance(True); eb.advance(True)
+        assert torch.equal(ea.last_actions(), eb.last_actions())
+    a, b = ea.counters(), eb.counters()
+    assert a == b and a['games_played'] > 0
+    for x, y in zip(ea.examples(), eb.examples()):
+        assert torch.equal(x, y)
