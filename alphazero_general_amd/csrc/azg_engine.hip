@@ -273,6 +273,22 @@ extern "C" int azg_backup(azg_engine *e, void *stream, const float *policy, cons
     return AZG_OK;
 }
 
+extern "C" int azg_backup_select(azg_engine *e, void *stream, const float *policy, const float *value, const int32_t *row_of_slot, int flags,
+                                 void *obs, int obs_dtype) {
+    if (!e || !policy || !value) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (obs_dtype < 0 || obs_dtype > 2) return fail(AZG_E_INVALID_ARG, "obs_dtype must be 0 (f32), 1 (f16) or 2 (f16 NHWC8)");
+    hipStream_t s = (hipStream_t)stream;
+    View v = e->v;
+    if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
+    EvPair p; prof_begin(e, s, 1, p);
+    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select<G, float>), dim3(v.B), dim3(64), 0, s, v, policy, value, (float *)obs, row_of_slot)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select<G, _Float16>), dim3(v.B), dim3(64), 0, s, v, policy, value, (_Float16 *)obs, row_of_slot)); }
+    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select<G, _Float16, true>), dim3(v.B), dim3(64), 0, s, v, policy, value, (_Float16 *)obs, row_of_slot)); }
+    prof_end(e, s, 1, p);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
 extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
     if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
     hipStream_t s = (hipStream_t)stream;

@@ -304,6 +304,27 @@ __global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, con
     backup_slot<G>(ev, slot, threadIdx.x, policy + (size_t)row * G::A, value + (size_t)row * (G::P + 1), m_lds, scr);
 }
 
+// backup of simulation k and find_leaf of simulation k + 1 of the same slot in one launch (they are consecutive in the lock-step
+// loop, SelfPlayAgent.pyx:87-92, and touch the same tree): one kernel boundary and one pass over the path's cache lines less.
+template <class G, typename OT, bool NHWC8 = false>
+__global__ __launch_bounds__(64) void k_backup_select(View ev, const float *policy, const float *value, OT *obs, const int32_t *row_of_slot) {
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
+    __shared__ float m_lds[G::A < 8 ? 8 : G::A];
+    __shared__ float scr[64];
+    __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
+    const int slot = blockIdx.x;
+    const int row = row_of_slot ? row_of_slot[slot] : slot;
+    backup_slot<G>(ev, slot, threadIdx.x, policy + (size_t)row * G::A, value + (size_t)row * (G::P + 1), m_lds, scr);
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
+    select_slot<G>(ev, slot, threadIdx.x, act_lds, [&](const typename G::S &st, int lane) {
+        if (obs) {
+            if constexpr (NHWC8) G::write_obs_nhwc8(st, (_Float16 *)obs + (size_t)row * G::CELLS * 8, lane);
+            else G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);
+        }
+    });
+}
+
 // ================================================================================================ root stats
 // MCTS.probs (:308-329) of a tree's root into LDS pr[A]; every lane returns.  cnt = LDS float counts.
 template <class G>

@@ -148,6 +148,17 @@ class DeviceEngine:
         flags = -1 if add_root_noise is None and add_root_temp is None else (int(bool(add_root_noise)) | 2 * int(bool(add_root_temp)))
         _abi.check(self.L.azg_backup(self.h, _stream(), _ptr(policy), _ptr(value), _ptr(row_of_slot), flags))
 
+    def backup_select(self, policy, value, obs, row_of_slot=None, add_root_noise=None, add_root_temp=None):
+        """backup(policy, value) of this simulation + select(obs) of the next one in one launch."""
+        assert policy.is_cuda and policy.dtype == torch.float32 and policy.is_contiguous() and policy.shape[1] == self.A
+        assert value.is_cuda and value.dtype == torch.float32 and value.is_contiguous() and value.shape[1] == self.NV
+        flags = -1 if add_root_noise is None and add_root_temp is None else (int(bool(add_root_noise)) | 2 * int(bool(add_root_temp)))
+        dt = 0
+        if obs is not None:
+            assert obs.is_cuda and obs.is_contiguous()
+            dt = 2 if obs.dim() == 3 else {torch.float32: 0, torch.float16: 1}[obs.dtype]
+        _abi.check(self.L.azg_backup_select(self.h, _stream(), _ptr(policy), _ptr(value), _ptr(row_of_slot), flags, _ptr(obs), dt))
+
     def advance(self, record_history=True):
         _abi.check(self.L.azg_advance(self.h, _stream(), int(bool(record_history))))
 

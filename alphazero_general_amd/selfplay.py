@@ -125,12 +125,12 @@ class SelfPlayRunner:
             torch.cuda.synchronize(e.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
-                for _ in range(sims):
-                    e.select(ln.obs)
-                    if self.warmup:
-                        e.backup(ln.policy, ln.value)
+                e.select(ln.obs)
+                for i in range(sims):                                # backup k and select k + 1 share a launch
+                    p, v = (ln.policy, ln.value) if self.warmup else ln.net.run()
+                    if i + 1 < sims:
+                        e.backup_select(p, v, ln.obs)
                     else:
-                        p, v = ln.net.run()
                         e.backup(p, v)
                 e.advance(record_history=not fast)
             ln.round_graphs[key] = g
@@ -241,10 +241,7 @@ class ArenaRunner:
 
     def step(self):
         if self.device_split:
-            if self._graph is not None:
-                self._graph.replay()
-            else:
-                self._step_device_split()
+            self._step_device_split()
             return
         e = self.engine
         row_of_slot, rpm = e.arena_rows(self.player_to_index)
@@ -268,18 +265,37 @@ class ArenaRunner:
         HipResNet.forward_models([n._hip for n in self.nnets], self.obs, self.policy, self.value, rpm)    # one launch
         e.backup(self.policy, self.value, row_of_slot)
 
+    def _round_device_split(self, sims):
+        """A whole move: the mover of every game -- hence the row <-> game map and the per-model split -- is fixed until
+        advance, so the rows are laid out once; then select, and per simulation ONE tower launch for all models plus one
+        tree launch (backup k + select k + 1); advance."""
+        e = self.engine
+        row_of_slot, rpm = e.arena_rows(self.player_to_index)
+        e.select(self.obs, row_of_slot)
+        nets = [n._hip for n in self.nnets]
+        for i in range(sims):
+            HipResNet.forward_models(nets, self.obs, self.policy, self.value, rpm)
+            if i + 1 < sims:
+                e.backup_select(self.policy, self.value, self.obs, row_of_slot)
+            else:
+                e.backup(self.policy, self.value, row_of_slot)
+        e.advance(record_history=False)
+
     def capture(self):
-        """Capture one simulation step as a hipGraph (device-side split only)."""
+        """Capture one whole round (all simulations of a move + advance) as a hipGraph (device-side split only)."""
         assert self.device_split
         self._step_device_split()                                    # warm: lazy allocations happen outside the capture
         self.engine.reset()                                          # (the warm step is not part of any game)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._step_device_split()
+            self._round_device_split(int(self.args.get('numMCTSSims', 100)))
         self._graph = g
 
     def play_round(self):
+        if self.device_split and self._graph is not None:
+            self._graph.replay()
+            return
         for _ in range(int(self.args.get('numMCTSSims', 100))):
             self.step()
         self.engine.advance(record_history=False)

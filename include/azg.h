@@ -134,6 +134,10 @@ int  azg_arena_rows(azg_engine *e, void *stream, const int32_t *player_to_index_
  * row_of_slot[slot] of policy_dev[rows, A] / value_dev[rows, P+1] (float32 probabilities). */
 int  azg_backup(azg_engine *e, void *stream, const float *policy_dev, const float *value_dev,
                 const int32_t *row_of_slot_dev, int flags);
+/* azg_backup of simulation k followed by azg_select of simulation k + 1 in one launch (the two are adjacent in the loop and
+ * touch the same trees); arguments as for the two calls, identical results. */
+int  azg_backup_select(azg_engine *e, void *stream, const float *policy_dev, const float *value_dev,
+                       const int32_t *row_of_slot_dev, int flags, void *obs_dev, int obs_dtype);
 #define AZG_FLAGS_DEFAULT (-1)   /* use azg_config.add_root_noise / add_root_temp                          */
 #define AZG_FLAG_NOISE 1          /* process_results(..., add_root_noise, add_root_temp) per call (:230)    */
 #define AZG_FLAG_TEMP  2
