@@ -600,8 +600,10 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
     if (game == AZG_GAME_CONNECT4 && channels == 64) return launch_tower<C4::H, C4::W, 4, 64>(s, P);
     static const int psplit = getenv("AZG_TOWER_PSPLIT") ? atoi(getenv("AZG_TOWER_PSPLIT")) : 0;   // measurement knob
     if (game == AZG_GAME_BRANDUBH && channels == 64) {           // two cout groups: split the pixels too at small batches
-        const int bt = forced ? forced : n <= 1024 ? 1 : 2;
-        const int sp = psplit ? psplit : 1;
+        // measured (us per evaluation incl. heads, 256 / 512 / 1024 / 2048 boards): 1 board, no split 39 / 47 / 66 / 107;
+        // 1 board, split 35 / 46 / 80 / 113; 2 boards, split 39 / 43 / 63 / 113
+        const int bt = forced ? forced : n <= 256 ? 1 : 2;
+        const int sp = psplit ? psplit : n <= 1024 ? 2 : 1;
         if (bt == 1 && sp == 2) return launch_tower<BR::H, BR::W, 1, 64, 2>(s, P);
         if (bt == 1) return launch_tower<BR::H, BR::W, 1, 64>(s, P);
         if (sp == 2) return launch_tower<BR::H, BR::W, 2, 64, 2>(s, P);
@@ -610,7 +612,7 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
     if (game == AZG_GAME_BRANDUBH && channels == 128) return launch_tower<BR::H, BR::W, 2, 128>(s, P);
     if (game == AZG_GAME_TRIMOK && channels == 32) {             // one cout group
         const int bt = forced ? forced : n <= 2048 ? 2 : 5;
-        const int sp = psplit ? psplit : 1;
+        const int sp = psplit ? psplit : 2;                      // (256 boards: 26 us unsplit, 23 us split in two)
         if (bt == 2 && sp == 4) return launch_tower<TM::H, TM::W, 2, 32, 4>(s, P);
         if (bt == 2 && sp == 2) return launch_tower<TM::H, TM::W, 2, 32, 2>(s, P);
         if (bt == 2) return launch_tower<TM::H, TM::W, 2, 32>(s, P);
