@@ -51,7 +51,7 @@ def test_arena_runner_device_split_graph_equals_host_split():
     assert sum(wins) + draws == c0['games_played']                   # Arena.play_games contract (Arena.pyx:376)
 
 
-@pytest.mark.parametrize('variant', ['no_graph', 'pipelines2'])
+@pytest.mark.parametrize('variant', ['no_graph', 'pipelines2', 'no_graph_fast_rounds_resets'])
 def test_selfplay_runner_launch_strategy_is_invisible(variant):
     """SelfPlayRunner: hipGraph replay of the network / two stream pipelines give bit-identical samples and results to
     the plain launch sequence (slots are sharded by global id, so the pipelines play the same games)."""
@@ -60,8 +60,10 @@ def test_selfplay_runner_launch_strategy_is_invisible(variant):
     from alphazero_general_amd.selfplay import SelfPlayRunner
     net = _net(3)
     outs = []
-    for kw in (dict(), dict(use_graph=False) if variant == 'no_graph' else dict(pipelines=2)):
-        r = SelfPlayRunner(Game, net, _args(), num_slots=64, seed=9, example_capacity=64 * 43 * 2 * 4, **kw)
+    # fast rounds (a second captured round graph with numFastSims, no history) and periodic tree resets ride along in one variant
+    extra = dict(probFastSim=0.4, numFastSims=5, mctsResetThreshold=3) if variant.endswith('fast_rounds_resets') else {}
+    for kw in (dict(), dict(use_graph=False) if variant.startswith('no_graph') else dict(pipelines=2)):
+        r = SelfPlayRunner(Game, net, _args(**extra), num_slots=64, seed=9, example_capacity=64 * 43 * 2 * 4, **kw)
         for _ in range(30):
             r.play_round()
         obs, pi, z = r.samples()
@@ -69,7 +71,9 @@ def test_selfplay_runner_launch_strategy_is_invisible(variant):
         outs.append((obs.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy(), np.asarray(ws), np.asarray(turns), np.asarray(slot), r.counters()))
     a, b = outs
     assert a[6]['games_played'] == b[6]['games_played'] > 0
-    if variant == 'no_graph':
+    if extra:
+        assert len(set(r.sims_per_round)) == 2                    # both kinds of round happened
+    if variant.startswith('no_graph'):
         for x, y in zip(a[:6], b[:6]):
             assert x.shape == y.shape and (x == y).all()
     else:                                                            # lanes emit in their own order: compare as multisets
@@ -105,3 +109,22 @@ def test_fused_search_kernel_equals_three_kernel_path():
     assert a == b and a['games_played'] > 0
     for x, y in zip(ea.examples(), eb.examples()):
         assert torch.equal(x, y)
+
+
+def test_warmup_runner_round_graph_equals_eager():
+    """warm-up mode (SelfPlayAgent.pyx:48-52,111-114: uniform policy / value, numWarmupSims) through the captured round graph
+    and through plain launches: identical games."""
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    outs = []
+    for use_graph in (True, False):
+        r = SelfPlayRunner(Game, None, _args(numWarmupSims=7), num_slots=48, seed=4, warmup=True, use_graph=use_graph,
+                           example_capacity=48 * 43 * 2 * 4)
+        assert r.round_graph == use_graph
+        for _ in range(25):
+            r.play_round()
+        o, p, z = r.samples()
+        outs.append((o.cpu().numpy(), p.cpu().numpy(), z.cpu().numpy(), r.counters()))
+    assert outs[0][3] == outs[1][3] and outs[0][3]['games_played'] > 0 and outs[0][3]['sims'] == 25 * 7 * 48
+    for x, y in zip(outs[0][:3], outs[1][:3]):
+        assert x.shape == y.shape and (x == y).all()
