@@ -26,7 +26,7 @@ def c4_ref_to_cells(g):
 
 
 # ------------------------------------------------------------------------------------------------ rules
-def gen_c4_rules(n_games=120, seed=1234):
+def gen_c4_rules(n_games=460, seed=1234):                  # >= 10^4 positions
     from alphazero.envs.connect4.connect4 import Game
     rng = np.random.RandomState(seed)
     moves, lens, valids, cells, ws, obs_crc, obs_sample = [], [], [], [], [], [], []
@@ -292,7 +292,7 @@ def br_state(g):
     return np.asarray(g._board._state, dtype=np.int8).reshape(-1), g.player, g.turns, int(g._board._king_captured)
 
 
-def gen_br_rules(n_games=60, seed=4321):
+def gen_br_rules(n_games=170, seed=4321):                  # >= 10^4 positions
     G = br_game_cls()
     rng = np.random.RandomState(seed)
     moves, lens, valid_bits, cells, ws, kc, obs_crc, obs_sample, sym_crc, max_k = [], [], [], [], [], [], [], [], [], 0
@@ -409,8 +409,8 @@ def main():
     if 'br_rules' in which:
         gen_br_rules()
     if 'br_tree' in which:
-        gen_tree(br_game_cls(), ol.GAME_BRANDUBH, 'br', n_roots=24, seed=11, max_prefix=40,
-                 configs=[('default', 1.25, 0.2, False, False, 80), ('noise_temp', 1.25, 0.2, True, True, 50)])
+        gen_tree(br_game_cls(), ol.GAME_BRANDUBH, 'br', n_roots=32, seed=11, max_prefix=40,
+                 configs=[('default', 1.25, 0.2, False, False, 200), ('noise_temp', 1.25, 0.2, True, True, 50)])   # >= 32 roots x 200 sims
     if 'tm_tree' in which or 'tm_agent' in which:
         sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
         from alphazero_general_amd.envs.trimok import Game as TM       # the rules statement; searched by the REFERENCE MCTS

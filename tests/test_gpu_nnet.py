@@ -114,7 +114,7 @@ def test_mfma_tower_vs_reference_golden():
     from test_nnet_cpu import fill_deterministic, G
     from alphazero_general_amd.envs.connect4 import Game
     from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
-    d = np.load(os.path.join(G, 'c4_net.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_net.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     w = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', backend='hip')
     w.nnet.load_state_dict(fill_deterministic(w.nnet.state_dict()))
     w.refresh()

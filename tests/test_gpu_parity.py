@@ -50,7 +50,7 @@ def fake_batch(torch, seed, slots, step, A, NV, dev):
 @pytest.mark.parametrize('cname', ['default', 'c4train', 'noise', 'noise_temp'])
 def test_c4_tree_vs_reference_goldens(torch_mod, cname):
     torch = torch_mod
-    d = np.load(os.path.join(G, 'c4_tree.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_tree.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
     noise, temp, sims = bool(noise), bool(temp), int(sims)
     seed = int(d[cname + '_seed'])
@@ -155,7 +155,7 @@ def run_engine_agent(torch, eng, seed, slot_base, sims, games, prob_fast=0.0, fa
 @pytest.mark.parametrize('cname', list(AGENT_CFGS))
 def test_c4_agent_vs_reference_goldens(torch_mod, cname):
     torch = torch_mod
-    d = np.load(os.path.join(G, 'c4_agent.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
     seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
     eng = engine(B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=4096, sims_hint=sims,
@@ -327,7 +327,7 @@ def test_c4_arena_vs_oracle_live(torch_mod):
     routing is correct too: that prefix is additionally pinned to the reference golden."""
     torch = torch_mod
     from alphazero_general_amd.utils import AGENT_STREAM
-    d = np.load(os.path.join(G, 'c4_arena.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_arena.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games, seed = int(d['arena_B']), int(d['arena_sims']), int(d['arena_games']), int(d['arena_seed'])
     A, NV = 7, 3
     ag = ol.OAgent(C4, B, sims=sims, games_per_iteration=games, seed=seed, is_arena=True, ref_misroute=False)
@@ -435,7 +435,7 @@ def test_br_rules_fuzz(torch_mod):
 @pytest.mark.parametrize('cname', ['default', 'noise_temp'])
 def test_br_tree_vs_reference_goldens(torch_mod, cname):
     torch = torch_mod
-    d = np.load(os.path.join(G, 'br_tree.npz'))
+    d = dict(np.load(os.path.join(G, 'br_tree.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
     noise, temp, sims = bool(noise), bool(temp), int(sims)
     seed = int(d[cname + '_seed'])
@@ -486,7 +486,7 @@ def test_br_tree_vs_reference_goldens(torch_mod, cname):
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
 def test_br_agent_vs_reference_goldens(torch_mod, cname, kw):
     torch = torch_mod
-    d = np.load(os.path.join(G, 'br_agent.npz'))
+    d = dict(np.load(os.path.join(G, 'br_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
     seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
     eng = engine(game=BR, B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=20000, sims_hint=sims, **kw)
@@ -510,7 +510,7 @@ TM = 2
 @pytest.mark.parametrize('cname', ['default', 'noise_temp'])
 def test_tm_tree_vs_reference_goldens(torch_mod, cname):
     torch = torch_mod
-    d = np.load(os.path.join(G, 'tm_tree.npz'))
+    d = dict(np.load(os.path.join(G, 'tm_tree.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
     noise, temp, sims = bool(noise), bool(temp), int(sims)
     seed = int(d[cname + '_seed'])
@@ -549,7 +549,7 @@ def test_tm_tree_vs_reference_goldens(torch_mod, cname):
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
 def test_tm_agent_vs_reference_goldens(torch_mod, cname, kw):
     torch = torch_mod
-    d = np.load(os.path.join(G, 'tm_agent.npz'))
+    d = dict(np.load(os.path.join(G, 'tm_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
     seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
     eng = engine(game=TM, B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=8000, sims_hint=sims, **kw)

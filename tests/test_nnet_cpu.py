@@ -32,7 +32,7 @@ def fill_deterministic(sd):
 def _check(name, args):
     from alphazero_general_amd.envs.connect4 import Game
     from alphazero_general_amd.nnet import FoldedResNet, NNetWrapper
-    d = np.load(os.path.join(G, 'c4_net.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_net.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     w = NNetWrapper(Game, args, device='cpu', fast=False)
     sd = w.nnet.state_dict()
     assert sorted(sd.keys()) == list(d[name + '_keys'])                       # checkpoints interchange key for key

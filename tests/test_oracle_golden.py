@@ -18,7 +18,7 @@ def crc(a):
 
 # ------------------------------------------------------------------------------------------------ rules
 def test_c4_rules_playouts():
-    d = np.load(os.path.join(G, 'c4_rules.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_rules.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     n = len(d['lens'])
     k = 0
     for i in range(n):
@@ -37,7 +37,7 @@ def test_c4_rules_playouts():
 
 def test_c4_reference_test_data():
     """The reference's own test tables (envs/connect4/test_connect4.py:31-39,58-64,99-151) as data."""
-    d = np.load(os.path.join(G, 'c4_rules.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_rules.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     for b, ws, winner in zip(d['end_boards'], d['end_ws'], d['end_winner']):
         g = ol.OGame(C4)
         for i, v in enumerate(b.reshape(-1)):
@@ -127,7 +127,7 @@ TREE_CFGS = ['default', 'c4train', 'noise', 'noise_temp']
 
 @pytest.mark.parametrize('cname', TREE_CFGS)
 def test_c4_tree_vs_reference(cname):
-    d = np.load(os.path.join(G, 'c4_tree.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_tree.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     gi = ol.game_info(C4)
     A, NV = gi.action_size, gi.num_players + 1
     cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
@@ -223,7 +223,7 @@ def run_oracle_agent(game, d, cname, kw):
 
 @pytest.mark.parametrize('cname', list(AGENT_CFGS))
 def test_c4_agent_vs_reference(cname):
-    d = np.load(os.path.join(G, 'c4_agent.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     kw = AGENT_CFGS[cname]
     ag, rec = run_oracle_agent(C4, d, cname, kw)
     assert (np.array(rec['sims']) == d[cname + '_round_sims']).all()
@@ -271,7 +271,7 @@ def run_oracle_arena(game, B, sims, games, seed, ref_misroute, A, NV):
 
 def test_c4_arena_agent_vs_reference():
     """Arena mode incl. the reference's row mis-routing, reproduced by the oracle's ref_misroute switch."""
-    d = np.load(os.path.join(G, 'c4_arena.npz'))
+    d = dict(np.load(os.path.join(G, 'c4_arena.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games, seed = int(d['arena_B']), int(d['arena_sims']), int(d['arena_games']), int(d['arena_seed'])
     ag, rec = run_oracle_arena(C4, B, sims, games, seed, True, 7, 3)
     assert ag.player_to_index() == list(d['arena_player_to_index'])
@@ -290,7 +290,7 @@ BR = ol.GAME_BRANDUBH
 
 
 def test_br_rules_playouts():
-    d = np.load(os.path.join(G, 'br_rules.npz'))
+    d = dict(np.load(os.path.join(G, 'br_rules.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     n = len(d['lens'])
     sym = {int(r[0]): r[1:] for r in d['sym_crc']}
     rng = np.random.RandomState(int(d['sym_seed']))
@@ -323,7 +323,7 @@ def test_br_rules_playouts():
 def test_br_symmetries():
     """Game.symmetries (fastafl.pyx:213-256): 8 (state, pi) pairs; the fixture holds crc(state) ^ crc(pi_k) for a pi that
     is regenerated here from the recorded seed by replaying the generator's RandomState stream."""
-    d = np.load(os.path.join(G, 'br_rules.npz'))
+    d = dict(np.load(os.path.join(G, 'br_rules.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     rng = np.random.RandomState(int(d['sym_seed']))
     sym = {int(r[0]): r[1:] for r in d['sym_crc']}
     n = len(d['lens'])
@@ -351,7 +351,7 @@ def test_br_symmetries():
 
 @pytest.mark.parametrize('cname', ['default', 'noise_temp'])
 def test_br_tree_vs_reference(cname):
-    d = np.load(os.path.join(G, 'br_tree.npz'))
+    d = dict(np.load(os.path.join(G, 'br_tree.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     gi = ol.game_info(BR)
     A, NV = gi.action_size, gi.num_players + 1
     cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
@@ -402,7 +402,7 @@ def test_br_tree_vs_reference(cname):
 
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
 def test_br_agent_vs_reference(cname, kw):
-    d = np.load(os.path.join(G, 'br_agent.npz'))
+    d = dict(np.load(os.path.join(G, 'br_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     ag, rec = run_oracle_agent(BR, d, cname, kw)
     assert (np.array(rec['actions']) == d[cname + '_actions']).all()
     assert (np.array(rec['counts']) == d[cname + '_counts']).all()
@@ -438,7 +438,7 @@ def test_tm_rules_vs_python_statement():
 
 @pytest.mark.parametrize('cname', ['default', 'noise_temp'])
 def test_tm_tree_vs_reference(cname):
-    d = np.load(os.path.join(G, 'tm_tree.npz'))
+    d = dict(np.load(os.path.join(G, 'tm_tree.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     gi = ol.game_info(TM)
     A, NV = gi.action_size, gi.num_players + 1
     cpuct, fpu, noise, temp, sims = d[cname + '_cfg']
@@ -469,7 +469,7 @@ def test_tm_tree_vs_reference(cname):
 
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
 def test_tm_agent_vs_reference(cname, kw):
-    d = np.load(os.path.join(G, 'tm_agent.npz'))
+    d = dict(np.load(os.path.join(G, 'tm_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     ag, rec = run_oracle_agent(TM, d, cname, kw)
     assert (np.array(rec['actions']) == d[cname + '_actions']).all()
     assert (np.array(rec['counts']) == d[cname + '_counts']).all()
