@@ -187,6 +187,7 @@ AGENT_CONFIGS = [
     ('fastmix', 6, 16, 8, dict(probFastSim=0.5, numFastSims=6, symmetricSamples=False)),
     ('reset', 4, 12, 5, dict(mctsResetThreshold=3)),
     ('warmup', 6, 10, 8, dict(numWarmupSims=5)),
+    ('config1', 32, 25, 32, dict()),                 # the shape of BASELINE.json configs[0]: 32 games, 25 sims
 ]
 
 

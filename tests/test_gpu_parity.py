@@ -111,6 +111,7 @@ AGENT_CFGS = {
     'fastmix': dict(symmetric_samples=False),
     'reset': dict(mcts_reset_threshold=3),
     'warmup': dict(),
+    'config1': dict(),
 }
 AGENT_ROUND = {'fastmix': dict(prob_fast=0.5, fast_sims=6), 'warmup': dict(warmup=True, warmup_sims=5)}
 
@@ -158,7 +159,7 @@ def test_c4_agent_vs_reference_goldens(torch_mod, cname):
     d = dict(np.load(os.path.join(G, 'c4_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
     seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
-    eng = engine(B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=4096, sims_hint=sims,
+    eng = engine(B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=16384, sims_hint=sims,
                  **AGENT_CFGS[cname])
     rec = run_engine_agent(torch, eng, seed, slot_base, sims, games, **AGENT_ROUND.get(cname, {}))
     assert (np.array(rec['sims']) == d[cname + '_round_sims']).all()

@@ -186,6 +186,7 @@ AGENT_CFGS = {
     'fastmix': dict(prob_fast=0.5, fast_sims=6, symmetric=False),
     'reset': dict(reset_threshold=3),
     'warmup': dict(warmup_sims=5, is_warmup=True),
+    'config1': dict(),
 }
 
 
