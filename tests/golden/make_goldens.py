@@ -420,10 +420,12 @@ def main():
                  configs=[('default', 1.25, 0.2, False, False, 60), ('noise_temp', 2.0, 0.3, True, True, 40)])
     if 'tm_agent' in which:
         gen_agent(TM, ol.GAME_TRIMOK, 'tm', seed=777,
-                  configs=[('plain', 8, 15, 12, dict()), ('noisy', 6, 10, 8, dict(add_root_noise=True, add_root_temp=True))])
+                  configs=[('plain', 8, 15, 12, dict()), ('noisy', 6, 10, 8, dict(add_root_noise=True, add_root_temp=True)),
+                           ('wide', 32, 50, 40, dict())])
     if 'br_agent' in which:
         gen_agent(br_game_cls(), ol.GAME_BRANDUBH, 'br', seed=321,
-                  configs=[('plain', 6, 12, 4, dict()), ('noisy', 4, 10, 3, dict(add_root_noise=True, add_root_temp=True))])
+                  configs=[('plain', 6, 12, 4, dict()), ('noisy', 4, 10, 3, dict(add_root_noise=True, add_root_temp=True)),
+                           ('wide', 16, 30, 10, dict())])
 
 
 if __name__ == '__main__':

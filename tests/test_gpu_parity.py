@@ -484,7 +484,7 @@ def test_br_tree_vs_reference_goldens(torch_mod, cname):
     eng.close()
 
 
-@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
+@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
 def test_br_agent_vs_reference_goldens(torch_mod, cname, kw):
     torch = torch_mod
     d = dict(np.load(os.path.join(G, 'br_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
@@ -547,7 +547,7 @@ def test_tm_tree_vs_reference_goldens(torch_mod, cname):
     eng.close()
 
 
-@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
+@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
 def test_tm_agent_vs_reference_goldens(torch_mod, cname, kw):
     torch = torch_mod
     d = dict(np.load(os.path.join(G, 'tm_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])

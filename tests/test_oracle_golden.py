@@ -401,7 +401,7 @@ def test_br_tree_vs_reference(cname):
         assert ol.lib().azo_mcts_tape_ctr(m.h) == d[cname + '_ctr'][r]
 
 
-@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
+@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
 def test_br_agent_vs_reference(cname, kw):
     d = dict(np.load(os.path.join(G, 'br_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     ag, rec = run_oracle_agent(BR, d, cname, kw)
@@ -468,7 +468,7 @@ def test_tm_tree_vs_reference(cname):
         assert m.value(False) == d[cname + '_vmax'][r] and m.value(True) == d[cname + '_vavg'][r]
 
 
-@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True))])
+@pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
 def test_tm_agent_vs_reference(cname, kw):
     d = dict(np.load(os.path.join(G, 'tm_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     ag, rec = run_oracle_agent(TM, d, cname, kw)
