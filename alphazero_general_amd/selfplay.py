@@ -33,7 +33,7 @@ class SelfPlayRunner:
     independent and every random draw is keyed by the global slot id, so the split changes no result."""
 
     def __init__(self, game_cls, nnet, args, *, num_slots, seed=0, slot_base=0, device=None, example_capacity=None,
-                 use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None):
+                 use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None, result_capacity=None):
         self.game_cls, self.nnet, self.args = game_cls, nnet, args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -46,6 +46,8 @@ class SelfPlayRunner:
         if example_capacity is None:
             per_game = (gi.max_turns + 1) * (gi.num_symmetries if args.get('symmetricSamples', True) else 1)
             example_capacity = (int(args.get('gamesPerIteration', self.B)) + self.B) * per_game
+        if result_capacity is None:                                  # one record per finished game; a game is at least a few moves
+            result_capacity = example_capacity // max(gi.num_symmetries if args.get('symmetricSamples', True) else 1, 1) // 4 + 4 * self.B + 1024
         self.seed, self.slot_base = int(seed), int(slot_base)
         self._actr = 0
         self.use_graph = bool(use_graph) and not self.warmup and nnet is not None
@@ -62,7 +64,8 @@ class SelfPlayRunner:
                 games_per_iteration=int(args.get('gamesPerIteration', 1 << 30)), start_temp=args.get('startTemp', 1.0),
                 arena_temp=args.get('arenaTemp', 0.25), temp_fn=args.get('temp_scaling_fn', default_temp_scaling),
                 seed=seed, slot_base=self.slot_base + li * Bl, device=device,
-                example_capacity=example_capacity // self.pipelines + 1, sims_hint=sims)
+                example_capacity=example_capacity // self.pipelines + 1, result_capacity=int(result_capacity) // self.pipelines + 1,
+                sims_hint=sims)
             dev = eng.device
             with torch.cuda.device(dev):
                 lane = _Lane(eng, torch.cuda.Stream(device=dev) if self.pipelines > 1 else torch.cuda.current_stream(dev))
@@ -208,7 +211,7 @@ class ArenaRunner:
     correct row <-> game map (the reference's mis-routing, SURVEY.md Q15, is not reproduced).  Returns the
     (wins, draws, winrates) contract of Arena.play_games (:376) via get_game_results semantics (utils.py:34-54)."""
 
-    def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None, use_graph=True):
+    def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None, use_graph=True, result_capacity=None):
         self.game_cls, self.nnets, self.args = game_cls, list(nnets), args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -225,7 +228,9 @@ class ArenaRunner:
         self.engine = DeviceEngine(self.game, self.B, arena=True, cpuct=args.get('cpuct', 1.25),
                                    fpu_reduction=args.get('fpu_reduction', 0.2), arena_temp=args.get('arenaTemp', 0.25),
                                    games_per_iteration=int(args.get('gamesPerIteration', 1 << 30)), seed=seed,
-                                   slot_base=slot_base, device=device, sims_hint=int(args.get('numMCTSSims', 100)))
+                                   slot_base=slot_base, device=device, sims_hint=int(args.get('numMCTSSims', 100)),
+                                   result_capacity=int(result_capacity if result_capacity is not None else
+                                                       min(int(args.get('gamesPerIteration', 1 << 30)), 1 << 20) + 4 * self.B + 1024))
         e = self.engine
         hip = all(getattr(n, '_hip', None) is not None or (n.refresh() and n._hip is not None) for n in self.nnets)
         self.nhwc8 = bool(hip)

@@ -157,7 +157,8 @@ def run_other_workload(a, rank, local_rank, world):
         for sd in (0, 1):                                            # two differently seeded random-init nets
             torch.manual_seed(sd)
             nets.append(NNetWrapper(Game_, getattr(nn_mod, netargs), device=dev, dtype=torch.float16))
-        runner = ArenaRunner(Game_, nets, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank)
+        runner = ArenaRunner(Game_, nets, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
+                             result_capacity=B * (a.steps + a.warmup + 8) // 5 + 2 * B)
         counters = lambda: runner.engine.counters()
     else:
         torch.manual_seed(0)
