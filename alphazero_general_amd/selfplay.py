@@ -139,6 +139,19 @@ class SelfPlayRunner:
             ln.round_graphs[key] = g
         return ln.round_graphs[key]
 
+    def prepare(self):
+        """Capture the round graph(s) now (nothing is executed), so that the first play_round does not pay for it."""
+        if self.round_graph:
+            a = self.args
+            kinds = [(int(a.get('numWarmupSims', 5) if self.warmup else a.get('numMCTSSims', 100)), False)]
+            if float(a.get('probFastSim', 0.0) or 0.0) > 0:
+                kinds.append((int(a.get('numFastSims', 20)), True))
+            for ln in self.lanes:
+                with torch.cuda.stream(ln.stream):
+                    for sims, fast in kinds:
+                        self._round_graph(ln, sims, fast)
+        return self
+
     def play_round(self):
         sims, fast = self._sims_for_round()
         if self.round_graph and not any(getattr(ln.engine, 'profiling', False) for ln in self.lanes):
