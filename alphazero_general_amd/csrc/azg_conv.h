@@ -677,6 +677,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             }
             __syncthreads();                                    // every wave is done reading the image
             AZG_STAMP2(2);
+            int oz = 0;                                         // opaque zero: the store offsets lb + edelta are loop invariants that
+            asm volatile("" : "+s"(oz));                        // LLVM would otherwise precompute, keep live across the main loop and spill
 #pragma unroll
             for (int ps = 0; ps < NSUB; ps++) {
                 half2v v[4];
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
                     a0.u = r0[0]; b0.u = r0[1]; a1.u = r1[0]; b1.u = r1[1];
                     v[0] = a0.h; v[1] = a1.h; v[2] = b0.h; v[3] = b1.h;
                 }
-                const unsigned off = lb[ps] + edelta;
+                const unsigned off = lb[ps] + (edelta + (unsigned)oz);
                 const bool lv = (livemask >> ps) & 1;
                 if (!is_s) {
 #pragma unroll
@@ -730,6 +732,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             // batch issues its 16 weight-fragment loads back to back (branch-free: pixels past the end re-read the last one
             // with a zeroed B fragment), four independent accumulators (one per channel step) avoid a dependent MFMA chain.
             constexpr int NPW = (HW + 3) / 4, JB = 4;
+            // (an opaque zero keeps LLVM from hoisting this block's per-pixel offsets and weight pointers -- loop invariants -- out
+            //  of the tile loop, where they would sit in registers across all the layers and be spilled: 36 MB of stores per launch)
+            int opaque = 0;
+            asm volatile("" : "+s"(opaque));
             floatx4 hacc4[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) hacc4[ks] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
 #pragma unroll
                 for (int j = 0; j < JB; j++) {
                     if (j0 + j < NPW) {
-                        const int p = wave + 4 * (j0 + j), pc = min(p, HW - 1);
+                        const int p = wave + opaque + 4 * (j0 + j), pc = min(p, HW - 1);
                         const int y = pc / W, x = pc - y * W;
                         const unsigned poff = (unsigned)(((y + 1) * GEO::PW + x) * RS);
 #pragma unroll
