@@ -35,9 +35,9 @@ C4_SELECT_BYTES_PER_SIM = 5 * (32 + 7 * 32) + (32 + 7 * 32) + 2 * 80 + 336 + 5 *
 C4_BACKUP_BYTES_PER_SIM = 7 * 4 + 12 + 7 * 4 + 5 * (4 + 16) + 32
 C4_NET_FLOPS_PER_LEAF = 205e6
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
-TOWER_TRAFFIC_BYTES = 107660000  # PMC per launch @2048 boards: (2 x FETCH_SIZE + WRITE_SIZE) KB, rows tower2_r1b of
-                                 # profiles/r01_pmc_summary.csv: 70 MB fetched (the 4.7 MB weight stream per XCD, re-fetched about
-                                 # twice: it exceeds the 4 MB L2) + 36 MB written, all of it register-spill stores (276 B/lane)
+TOWER_TRAFFIC_BYTES = 78000000   # PMC per launch @2048 boards, (2 x FETCH_SIZE + WRITE_SIZE) KB (profiles/r01_pmc_summary.csv):
+                                 # 70 MB fetched at the L2 <-> fabric boundary (the 4.7 MB weight stream per XCD, re-fetched about
+                                 # twice: it exceeds the 4 MB L2; Infinity-Cache hits included) + 8 MB written (52 B/lane of spills)
 
 
 def selfplay_args(games):
