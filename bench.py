@@ -35,9 +35,9 @@ C4_SELECT_BYTES_PER_SIM = 5 * (32 + 7 * 32) + (32 + 7 * 32) + 2 * 80 + 336 + 5 *
 C4_BACKUP_BYTES_PER_SIM = 7 * 4 + 12 + 7 * 4 + 5 * (4 + 16) + 32
 C4_NET_FLOPS_PER_LEAF = 205e6
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
-TOWER_TRAFFIC_BYTES = 78000000   # PMC per launch @2048 boards, (2 x FETCH_SIZE + WRITE_SIZE) KB (profiles/r01_pmc_summary.csv):
-                                 # 70 MB fetched at the L2 <-> fabric boundary (the 4.7 MB weight stream per XCD, re-fetched about
-                                 # twice: it exceeds the 4 MB L2; Infinity-Cache hits included) + 8 MB written (52 B/lane of spills)
+TOWER_TRAFFIC_BYTES = 50850000   # PMC per launch @2048 boards, (2 x FETCH_SIZE + WRITE_SIZE) KB (profiles/r01_pmc_summary.csv, rows
+                                 # tower2_r1c): 43 MB fetched at the L2 <-> fabric boundary = the 4.7 MB weight stream once per XCD
+                                 # (8 x 4.7 = 38 MB; Infinity-Cache hits are counted) + inputs, 6.4 MB written (52 B/lane of spills)
 
 
 def selfplay_args(games):
