@@ -598,7 +598,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             __syncthreads();
             if (tid == 0) *flag = 0;
             if (err) break;
-            const int slot = tile * BOARDS + wave;
+            int slot = tile * BOARDS + wave;
+            asm volatile("" : "+v"(slot));                       // (opaque: keeps the slot's tree addresses from being hoisted out of
+                                                                 //  the simulation loop and spilled across the tower)
+            slot = __builtin_amdgcn_readfirstlane(slot);
             if (slot < sa.ev.B) {
                 select_slot<G>(sa.ev, slot, lane, nullptr, [&](const typename G::S &st, int ln) {
                     if (ln < HW) {                               // leaf observation -> the image rows of board `wave`, channels 8.. zero
@@ -802,7 +805,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             if constexpr (IS_SEARCH) {
                 using G = typename SEARCH::Game;
                 __syncthreads();
-                const int slot = tile * BOARDS + wave;
+                int slot = tile * BOARDS + wave;
+                asm volatile("" : "+v"(slot));
+                slot = __builtin_amdgcn_readfirstlane(slot);
                 const float *pv = reinterpret_cast<const float *>(img + SCRATCH_PV) + wave * 16;
                 if (slot < sa.ev.B) backup_slot<G>(sa.ev, slot, lane, pv, pv + P.A, nullptr, nullptr);
             }

@@ -530,7 +530,7 @@ extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void
 }
 
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
-static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}) {
+static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}, bool init_only = false) {
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     using GEO = TowerGeom<H, W, BOARDS, C>;
     static int16_t *d_map[16] = {nullptr};                                  // per device: pixel -> (subtile, lane) table
@@ -546,6 +546,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
         if constexpr (C == 128)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)GEO::TILE));
     }
+    if (init_only) return AZG_OK;                            // (first-use allocations must not happen inside a stream capture)
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS + (P.rows_per_model ? P.nmodels - 1 : 0);
     static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
@@ -666,11 +667,10 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     if (e->cfg.game != AZG_GAME_CONNECT4 || e->v.arena)
         return fail(AZG_E_UNSUPPORTED, "the fused search kernel is built for connect4 self-play with a 128-channel tower (use azg_select / network / azg_backup)");
-    if (sims == 0) return AZG_OK;
     const int A = e->gi.action_size, NV = e->gi.num_players + 1;
     TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, head_w, head_b, nullptr, nullptr, A, NV, nullptr, nullptr, 0, {}};
     SearchArgs<C4> sa{e->v, sims};
-    return launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa);
+    return launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
 }
 
 extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,

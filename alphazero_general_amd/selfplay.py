@@ -33,7 +33,8 @@ class SelfPlayRunner:
     independent and every random draw is keyed by the global slot id, so the split changes no result."""
 
     def __init__(self, game_cls, nnet, args, *, num_slots, seed=0, slot_base=0, device=None, example_capacity=None,
-                 use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None, result_capacity=None):
+                 use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None, result_capacity=None,
+                 fused_search=False):
         self.game_cls, self.nnet, self.args = game_cls, nnet, args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -82,6 +83,10 @@ class SelfPlayRunner:
         self.engine = self.lanes[0].engine                           # single-lane convenience (tests, smoke)
         self.device = self.engine.device
         self.sims_per_round = []
+        # connect4 + fused 128-channel tower: the whole simulation loop of a move can be ONE persistent launch (azg_search_f16)
+        hip = getattr(nnet, '_hip', None) if nnet is not None else None
+        self.fused_search = bool(fused_search) and self.round_graph and not self.warmup and self.game == 0 and hip is not None \
+            and hip.fused and hip.fused_head
 
     @property
     def obs(self):
@@ -125,17 +130,25 @@ class SelfPlayRunner:
         key = (sims, fast)
         if key not in ln.round_graphs:
             e = ln.engine
+            if self.fused_search:
+                self.nnet._hip.search(e, 0)                          # one-time setup outside the capture
             torch.cuda.synchronize(e.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
-                e.select(ln.obs)
+                if self.fused_search:
+                    self.nnet._hip.search(e, sims)
+                    e.advance(record_history=not fast)
+                    sims = 0
+                else:
+                    e.select(ln.obs)
                 for i in range(sims):                                # backup k and select k + 1 share a launch
                     p, v = (ln.policy, ln.value) if self.warmup else ln.net.run()
                     if i + 1 < sims:
                         e.backup_select(p, v, ln.obs)
                     else:
                         e.backup(p, v)
-                e.advance(record_history=not fast)
+                if not self.fused_search:
+                    e.advance(record_history=not fast)
             ln.round_graphs[key] = g
         return ln.round_graphs[key]
 

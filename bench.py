@@ -30,6 +30,7 @@ from alphazero_general_amd.selfplay import SelfPlayRunner  # noqa: E402
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
 B_PER_GPU, SIMS = 2048, 100
+NN_REPS = 24                                                          # back-to-back tower launches timed by one event pair
 # algorithmic figures (DESIGN.md "Roofline"): bytes one simulation moves through the tree kernels / FLOPs per leaf
 C4_SELECT_BYTES_PER_SIM = 5 * (32 + 7 * 32) + (32 + 7 * 32) + 2 * 80 + 336 + 5 * 4   # D=5 levels read, expand write, states, fp16 obs, path
 C4_BACKUP_BYTES_PER_SIM = 7 * 4 + 12 + 7 * 4 + 5 * (4 + 16) + 32
@@ -200,6 +201,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--pipelines', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fused-search', action='store_true',
+                    help='2 launches per simulation (tower, backup+select) instead of one persistent launch per move (azg_search_f16)')
     a = ap.parse_args()
 
     rank, local_rank, world = D.init_from_env()
@@ -215,7 +218,7 @@ def main():
     games = 1 << 30
     per_game = 43 * 2
     runner = SelfPlayRunner(Game, net, selfplay_args(games), num_slots=B, seed=0, slot_base=D.slot_base(rank, B),
-                            device=local_rank, use_graph=not a.no_graph, pipelines=a.pipelines,
+                            device=local_rank, use_graph=not a.no_graph, pipelines=a.pipelines, fused_search=not a.no_fused_search and a.pipelines == 1,
                             example_capacity=int(B * (a.steps + a.warmup + 8) / 7.0 + 2 * B) * per_game)
     eng = runner.engine
     lanes = runner.lanes
@@ -224,7 +227,7 @@ def main():
         runner.play_round()
     c0 = runner.counters()
     ex0 = [ln.engine.counters()['num_examples'] for ln in lanes]
-    ev_nn = []
+    ev_nn, ev_search = [], []
     D.barrier(); torch.cuda.synchronize()
     t0 = time.time()
     for k in range(a.steps):
@@ -233,14 +236,23 @@ def main():
             if runner.use_graph:                                    # (events around every launch perturb the pipeline)
                 with torch.cuda.stream(lanes[0].stream):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    lanes[0].net.replay()                            # warm launch path, then 8 back-to-back replays
+                    for _ in range(8):                               # warm launch path and clocks (a short burst after a pause
+                        lanes[0].net.replay()                        #  runs at boost clock: 0.24 ms instead of the sustained 0.28)
                     e0.record()
-                    for _ in range(8):
+                    for _ in range(NN_REPS):
                         lanes[0].net.replay()
                     e1.record(); ev_nn.append((e0, e1))
                 torch.cuda.synchronize()
             eng.profile(True)
-        runner.play_round()
+        if runner.fused_search and k == a.steps // 2 + 1:           # HIP events around ONE search launch (= all simulations of a move)
+            with torch.cuda.stream(lanes[0].stream):
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record(); net._hip.search(eng, SIMS); s1.record()
+                eng.advance(True)
+            runner.sims_per_round.append(SIMS); runner._actr += 1    # (probFastSim = 0: the agent-level coin of this round is unused)
+            ev_search.append((s0, s1))
+        else:
+            runner.play_round()
         if k == a.steps // 2:
             prof = eng.profile_read()
             eng.profile(False)
@@ -260,7 +272,7 @@ def main():
     adv_us = prof['advance_ms'] * 1e3 / max(prof['advance_n'], 1)
     Bl = B // a.pipelines                                           # slots per launch
     sel_gbs = C4_SELECT_BYTES_PER_SIM * Bl / (sel_us * 1e-6) / 1e9
-    nn_ms = ev_nn[0][0].elapsed_time(ev_nn[0][1]) / 8 if ev_nn else None
+    nn_ms = ev_nn[0][0].elapsed_time(ev_nn[0][1]) / NN_REPS if ev_nn else None
     tree = {'kernel': 'k_select<C4>', 'bound': 'hbm', 'achieved': round(sel_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(sel_gbs / HBM_PEAK_GBS, 6),
             # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_tree.py):
@@ -279,13 +291,27 @@ def main():
                 'traffic': TOWER_TRAFFIC_BYTES if Bl == 2048 else None}
     else:
         roof = tree
+    if ev_search:
+        # default path: the whole simulation loop of a move is ONE persistent launch (azg_search_f16): tree walk, tower + heads and
+        # backup of every simulation.  Its FLOPs are the network's; the tree phases ride inside the launch time.
+        sms = ev_search[0][0].elapsed_time(ev_search[0][1])
+        stf = C4_NET_FLOPS_PER_LEAF * Bl * SIMS / (sms * 1e-3) / 1e12
+        roof = {'kernel': 'k_tower2<6,7,4,128,1,SearchArgs<C4>> (azg_search_f16: %d x [find_leaf, ResNet 128ch x 8 + heads, backup] '
+                          'on every game, one persistent launch per move)' % SIMS, 'bound': 'mfma', 'achieved': round(stf, 1),
+                'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(stf / MFMA_F16_PEAK_TFLOPS, 4),
+                'avg_launch_us': round(sms * 1e3, 1), 'algorithmic_flops_per_launch': C4_NET_FLOPS_PER_LEAF * Bl * SIMS,
+                'traffic': TOWER_TRAFFIC_BYTES * SIMS if Bl == 2048 else None,
+                # the same tower + heads as its own launch (one evaluation), timed as a burst of NN_REPS launches: after the
+                # lighter search launches the chip boosts, so this runs faster than the same kernel does in a sustained stream
+                # (0.28 ms = 60 % with --no-fused-search, where it is launched 100 times per move)
+                'net_eval_only': roof}
     out = {
         'metric': 'mcts_node_expansions_per_sec', 'value': round(expansions / dt, 1), 'unit': 'expansions/s',
         'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net', 'data': 'synthetic',
         'config': {'workload': 'connect4 self-play, %d games/GPU x %d sims/move, fp16 ResNet 128ch x 8, random-init, noise+temp on'
                                % (B, SIMS), 'games_per_gpu': B, 'sims_per_move': SIMS, 'hipgraph_net': bool(runner.use_graph),
-                   'stream_pipelines': a.pipelines},
+                   'stream_pipelines': a.pipelines, 'fused_search_launch': bool(runner.fused_search)},
         'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(sims / dt, 1),
         'games_finished': games_done, 'samples_gathered': nsamples,
         'roofline': roof, 'tree_roofline': tree,
@@ -294,8 +320,9 @@ def main():
         # context for the MFMA fraction: the best plain fp16 GEMM the vendor library reaches on this very GPU (outside the
         # timed region; SURVEY.md 8d asks for it next to the datasheet peak)
         lib_tf = library_gemm_tflops(dev)
-        out['roofline']['library_gemm_tflops'] = round(lib_tf, 1)
-        out['roofline']['vs_library_gemm'] = round(tf / lib_tf, 3)
+        tgt = out['roofline'].get('net_eval_only', out['roofline'])
+        tgt['library_gemm_tflops'] = round(lib_tf, 1)
+        tgt['vs_library_gemm'] = round(tf / lib_tf, 3)
     if a.gpus == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(net)
     print(json.dumps(out))

@@ -229,7 +229,8 @@ int  azg_resnet_policy_value_multi_f16(void *stream, int game, const void *x_dev
  * (azg_select's code), the leaf observations go straight into the tower's LDS image, the workgroup evaluates them
  * (azg_resnet_policy_value_f16's code) and each wavefront backs its game up (azg_backup's code, engine flags) from the
  * probabilities left in LDS.  Results are identical to `sims` x [azg_select, azg_resnet_policy_value_f16, azg_backup].
- * connect4 self-play engines with a 128-channel tower only (AZG_E_UNSUPPORTED otherwise); parameters as above. */
+ * connect4 self-play engines with a 128-channel tower only (AZG_E_UNSUPPORTED otherwise); parameters as above.
+ * sims == 0 only performs the one-time setup (call it once before capturing the launch in a graph). */
 int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const float *bias_dev, const float *pre_scale_dev,
                     const float *pre_shift_dev, int nblocks, const void *head_w_packed_dev, const float *head_b_dev, int sims);
 

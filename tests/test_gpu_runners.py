@@ -51,7 +51,7 @@ def test_arena_runner_device_split_graph_equals_host_split():
     assert sum(wins) + draws == c0['games_played']                   # Arena.play_games contract (Arena.pyx:376)
 
 
-@pytest.mark.parametrize('variant', ['no_graph', 'pipelines2', 'no_graph_fast_rounds_resets'])
+@pytest.mark.parametrize('variant', ['no_graph', 'pipelines2', 'no_graph_fast_rounds_resets', 'no_graph_vs_fused_search'])
 def test_selfplay_runner_launch_strategy_is_invisible(variant):
     """SelfPlayRunner: hipGraph replay of the network / two stream pipelines give bit-identical samples and results to
     the plain launch sequence (slots are sharded by global id, so the pipelines play the same games)."""
@@ -62,8 +62,10 @@ def test_selfplay_runner_launch_strategy_is_invisible(variant):
     outs = []
     # fast rounds (a second captured round graph with numFastSims, no history) and periodic tree resets ride along in one variant
     extra = dict(probFastSim=0.4, numFastSims=5, mctsResetThreshold=3) if variant.endswith('fast_rounds_resets') else {}
-    for kw in (dict(), dict(use_graph=False) if variant.startswith('no_graph') else dict(pipelines=2)):
+    first = dict(fused_search=True) if variant.endswith('fused_search') else dict()   # one persistent launch per move (azg_search_f16)
+    for kw in (first, dict(use_graph=False) if variant.startswith('no_graph') else dict(pipelines=2)):
         r = SelfPlayRunner(Game, net, _args(**extra), num_slots=64, seed=9, example_capacity=64 * 43 * 2 * 4, **kw)
+        assert r.fused_search == bool(kw.get('fused_search'))
         for _ in range(30):
             r.play_round()
         obs, pi, z = r.samples()
