@@ -30,7 +30,7 @@ from alphazero_general_amd.selfplay import SelfPlayRunner  # noqa: E402
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
 B_PER_GPU, SIMS = 2048, 100
-NN_REPS = 24                                                          # back-to-back tower launches timed by one event pair
+NN_REPS = 8                                                           # back-to-back tower launches timed by one event pair
 # algorithmic figures (DESIGN.md "Roofline"): bytes one simulation moves through the tree kernels / FLOPs per leaf
 C4_SELECT_BYTES_PER_SIM = 5 * (32 + 7 * 32) + (32 + 7 * 32) + 2 * 80 + 336 + 5 * 4   # D=5 levels read, expand write, states, fp16 obs, path
 C4_BACKUP_BYTES_PER_SIM = 7 * 4 + 12 + 7 * 4 + 5 * (4 + 16) + 32
