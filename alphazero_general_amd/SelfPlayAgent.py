@@ -132,6 +132,7 @@ class SelfPlayAgent(mp.Process):
     def run(self):
         try:
             np.random.seed()
+            torch.set_num_threads(1)                                  # forked child: never touch the parent's thread pools
             self._start_worker()
             a = self.args
             while not self.stop_event.is_set() and self.games_played.value < a.gamesPerIteration:
@@ -179,7 +180,9 @@ class SelfPlayAgent(mp.Process):
             order = np.argsort(row_of_slot, kind='stable')               # row -> game, what the reference keeps (:132)
             self.batch_indices = list(order)
         else:
-            self.batch_tensor.copy_(torch.from_numpy(self._obs_h.reshape((self.batch_size,) + shape)))
+            # numpy, not Tensor.copy_: a large copy_ goes to torch's intra-op thread pool, whose threads do not exist in this
+            # forked child (the parent created them) -- it would wait for them forever
+            self.batch_tensor.numpy()[...] = self._obs_h.reshape((self.batch_size,) + shape)
         self.ready_queue.put(self.id)
 
     def processBatch(self):                                            # :137-151

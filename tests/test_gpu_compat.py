@@ -185,3 +185,58 @@ def test_compat_arena_agent():
         except queue.Empty:
             break
     assert n >= games
+
+
+@pytest.mark.timeout(180)
+def test_compat_agent_realistic_batch_with_gpu_net_in_parent():
+    """Coach's real arrangement at a realistic size: the parent has a GPU network AND a live CPU thread pool before it forks
+    the agent, batches are 1024 leaves.  (A Tensor.copy_ of that size in the forked agent used to wait forever for the
+    parent's intra-op threads; small batches never showed it.)"""
+    import time
+    import torch
+    import torch.multiprocessing as mp
+    from alphazero_general_amd.SelfPlayAgent import SelfPlayAgent
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
+    torch.manual_seed(0)
+    net = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0'); net.refresh()
+    (torch.randn(1024, 1024) @ torch.randn(1024, 1024)).sum().item()           # the parent's intra-op pool is up
+    B, sims, games = 1024, 8, 1100
+    args = _args(games, sims, add_root_noise=True, add_root_temp=True, cpuct=4.0, fpu_reduction=0.4)
+    ready_queue, file_queue, result_queue = mp.Queue(), mp.Queue(), mp.Queue()
+    completed, games_played = mp.Value('i', 0), mp.Value('i', 0)
+    stop, pause = mp.Event(), mp.Event()
+    inp, pol, val, ev = torch.zeros([B, 4, 6, 7]).share_memory_(), torch.zeros([B, 7]).share_memory_(), torch.zeros([B, 3]).share_memory_(), mp.Event()
+    ag = SelfPlayAgent(0, Game, ready_queue, ev, inp, pol, val, file_queue, result_queue, completed, games_played, stop, pause, args)
+    ag.daemon = True; ag.start()
+    nsamples, nresults, steps, t0 = 0, 0, 0, time.time()
+    try:
+        while completed.value != 1:
+            assert time.time() - t0 < 150, 'agent did not finish (%d batches served)' % steps
+            for q, which in ((file_queue, 0), (result_queue, 1)):
+                try:
+                    while True:
+                        q.get_nowait()
+                        if which: nresults += 1
+                        else: nsamples += 1
+                except queue.Empty:
+                    pass
+            try:
+                ready_queue.get(timeout=0.2)
+            except queue.Empty:
+                continue
+            p, v = net.process(inp)                                    # Coach.processSelfPlayBatches :337-342
+            pol.copy_(p); val.copy_(v); ev.set(); steps += 1
+    finally:
+        stop.set()
+    time.sleep(0.5)
+    for q, which in ((file_queue, 0), (result_queue, 1)):
+        try:
+            while True:
+                q.get_nowait()
+                if which: nresults += 1
+                else: nsamples += 1
+        except queue.Empty:
+            pass
+    ag.join(30)
+    assert games_played.value == games and nresults >= games and nsamples >= games * 7 * 2 and steps % sims == 0
