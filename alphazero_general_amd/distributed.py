@@ -21,12 +21,16 @@ def init_from_env(backend=None):
     # exercises the same RCCL calls as an 8-GPU one
     if (world > 1 or 'WORLD_SIZE' in os.environ and 'MASTER_ADDR' in os.environ) and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('AZG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
+        if os.environ.get('AZG_SINGLE_DEVICE'):              # test rig: every rank on GPU 0 (needs AZG_DIST_BACKEND=gloo;
+            local_rank = 0                                   #  RCCL refuses two ranks on one device)
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif os.environ.get('AZG_SINGLE_DEVICE'):
+        local_rank = 0
     return rank, local_rank, world
 
 
@@ -46,6 +50,8 @@ def all_gather_examples(obs, pi, z, group=None):
     if not dist.is_initialized():
         return obs, pi, z
     world = dist.get_world_size(group)
+    if dist.get_backend(group) != 'nccl':                    # gloo (CPU tests, single-device rig): gather on the host
+        obs, pi, z = obs.cpu(), pi.cpu(), z.cpu()
     n = torch.tensor([obs.shape[0]], dtype=torch.int64, device=obs.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)

@@ -130,3 +130,30 @@ def test_warmup_runner_round_graph_equals_eager():
     assert outs[0][3] == outs[1][3] and outs[0][3]['games_played'] > 0 and outs[0][3]['sims'] == 25 * 7 * 48
     for x, y in zip(outs[0][:3], outs[1][:3]):
         assert x.shape == y.shape and (x == y).all()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path end to end -- rendezvous, slot sharding by rank, timed loop, all-gather of the example shards,
+    tally all-reduce, max-over-ranks -- with two ranks sharing GPU 0 over gloo (RCCL refuses two ranks on one device; the
+    8-GPU run itself is the driver's)."""
+    import json
+    import os
+    import signal
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AZG_DIST_BACKEND='gloo', AZG_SINGLE_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29613', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '1', '--slots', '256']
+    p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        raise
+    lines = [l for l in out.decode(errors='replace').splitlines() if l.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, out.decode(errors='replace')[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and d['games_finished'] > 0
+    assert d['samples_gathered'] >= d['games_finished'] * 7 * 2          # both ranks' shards arrived
+    assert 'cpu_baseline' not in d                                       # rank 0, N = 1 only
