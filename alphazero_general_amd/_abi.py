@@ -61,6 +61,7 @@ SYMBOLS = {
     'azg_arena_rows': (_i, [_vp, _vp, _i32p, _vp, _vp]),
     'azg_backup': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     'azg_backup_select': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
+    'azg_backup_select_logits': (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i]),
     'azg_advance': (_i, [_vp, _vp, _i]),
     'azg_advance_begin': (_i, [_vp, _vp, _i, _i32p]),
     'azg_advance_commit': (_i, [_vp, _vp, _i32p]),

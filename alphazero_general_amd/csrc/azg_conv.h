@@ -887,34 +887,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, co
 __global__ __launch_bounds__(256) void k_heads_softmax(const float *logits, float *policy, float *value, int boards, int opad, int A, int NV) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= boards) return;
-    const float *lg = logits + (size_t)b * opad;
-    float x[16], m = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int o = lane + 64 * j;
-        x[j] = lg[min(o, A - 1)];
-        if (o >= A) x[j] = -INFINITY;
-        m = fmaxf(m, x[j]);
-    }
-    const float v = lg[A + min(lane, NV - 1)];
-#pragma unroll
-    for (int d = 32; d; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; j++) { x[j] = __expf(x[j] - m); sum += x[j]; }    // exp(-inf) = 0 for the padding
-#pragma unroll
-    for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int j = 0; j < 16; j++) { const int o = lane + 64 * j; if (o < A) policy[(size_t)b * A + o] = x[j] * inv; }
-    float vm = lane < NV ? v : -INFINITY;
-#pragma unroll
-    for (int d = 32; d; d >>= 1) vm = fmaxf(vm, __shfl_xor(vm, d));
-    const float ev = lane < NV ? __expf(v - vm) : 0.f;
-    float vs = ev;
-#pragma unroll
-    for (int d = 32; d; d >>= 1) vs += __shfl_xor(vs, d);
-    if (lane < NV) value[(size_t)b * NV + lane] = ev / vs;
+    heads_softmax_row(logits + (size_t)b * opad, lane, A, NV, policy + (size_t)b * A, value + (size_t)b * NV);
 }
 
 // leaf observation planes [B, C, H, W] (any of the engine's obs dtypes) are written by k_select directly as the stem's

@@ -238,4 +238,36 @@ AZG_DEV float np_sum_wave(const float *m, const SumPlan *plan, float *scr, int l
     return st[0];
 }
 
+// softmax over the A policy logits and the NV value logits of one board by one wavefront (NNetArchitecture.py:112-118,
+// exp(log_softmax)): lane owns logits lane, lane + 64, ... (A <= 1024).  pol / val may be global or LDS.
+AZG_DEV void heads_softmax_row(const float *lg, int lane, int A, int NV, float *pol, float *val) {
+    float x[16], m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int o = lane + 64 * j;
+        x[j] = lg[min(o, A - 1)];
+        if (o >= A) x[j] = -INFINITY;
+        m = fmaxf(m, x[j]);
+    }
+    const float v = lg[A + min(lane, NV - 1)];
+#pragma unroll
+    for (int d = 32; d; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { x[j] = __expf(x[j] - m); sum += x[j]; }    // exp(-inf) = 0 for the padding
+#pragma unroll
+    for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int o = lane + 64 * j; if (o < A) pol[o] = x[j] * inv; }
+    float vm = lane < NV ? v : -INFINITY;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) vm = fmaxf(vm, __shfl_xor(vm, d));
+    const float ev = lane < NV ? __expf(v - vm) : 0.f;
+    float vs = ev;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) vs += __shfl_xor(vs, d);
+    if (lane < NV) val[lane] = ev / vs;
+}
+
 }  // namespace azg

@@ -289,6 +289,24 @@ extern "C" int azg_backup_select(azg_engine *e, void *stream, const float *polic
     return AZG_OK;
 }
 
+extern "C" int azg_backup_select_logits(azg_engine *e, void *stream, const float *logits, int logits_stride, const int32_t *row_of_slot,
+                                        int flags, void *obs, int obs_dtype, int do_select) {
+    if (!e || !logits) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (obs_dtype < 0 || obs_dtype > 2) return fail(AZG_E_INVALID_ARG, "obs_dtype must be 0 (f32), 1 (f16) or 2 (f16 NHWC8)");
+    if (logits_stride < e->gi.action_size + e->gi.num_players + 1 || e->gi.action_size > 1024)
+        return fail(AZG_E_INVALID_ARG, "logits_stride must hold A + P + 1 logits (A <= 1024)");
+    hipStream_t s = (hipStream_t)stream;
+    View v = e->v;
+    if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
+    EvPair p; prof_begin(e, s, 1, p);
+    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select_logits<G, float>), dim3(v.B), dim3(64), 0, s, v, logits, logits_stride, (float *)obs, row_of_slot, do_select)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select_logits<G, _Float16>), dim3(v.B), dim3(64), 0, s, v, logits, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
+    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select_logits<G, _Float16, true>), dim3(v.B), dim3(64), 0, s, v, logits, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
+    prof_end(e, s, 1, p);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
 extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
     if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
     hipStream_t s = (hipStream_t)stream;
@@ -675,13 +693,14 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
 
 extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,
                                           int A, int NV, float *logits_ws, float *policy, float *value) {
-    if (!y || !head_w_packed || !head_b || !logits_ws || !policy || !value) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (!y || !head_w_packed || !head_b || !logits_ws || (!policy != !value)) return fail(AZG_E_INVALID_ARG, "null argument");
     if (boards <= 0 || k <= 0 || (k & 31) || A <= 0 || A > 1024 || NV <= 0 || NV > 64) return fail(AZG_E_INVALID_ARG, "boards > 0, k a multiple of 32, 0 < A <= 1024, 0 < NV <= 64");
     const int osub = (A + NV + 15) / 16, nchunks = (osub + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_heads, dim3(groups * nchunks), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)y, (const half8 *)head_w_packed, head_b, logits_ws,
                        boards, k / 32, osub);
-    hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
+    if (policy)                                              // (NULL: leave the logits for azg_backup_select_logits)
+        hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }

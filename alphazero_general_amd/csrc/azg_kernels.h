@@ -325,6 +325,33 @@ __global__ __launch_bounds__(64) void k_backup_select(View ev, const float *poli
     });
 }
 
+// The same with the softmaxes of the wide heads folded in: the network hands over LOGITS rows (stride `ld`: A policy logits, then
+// P + 1 value logits, as azg_policy_value_heads_f16 leaves them in its workspace) and this wavefront turns its own row into
+// probabilities in LDS -- one launch and one HBM round trip of the probabilities less per simulation.  do_select = 0: backup only.
+template <class G, typename OT, bool NHWC8 = false>
+__global__ __launch_bounds__(64) void k_backup_select_logits(View ev, const float *logits, int ld, OT *obs, const int32_t *row_of_slot,
+                                                             int do_select) {
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
+    __shared__ float m_lds[G::A < 8 ? 8 : G::A];
+    __shared__ float scr[64];
+    __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
+    __shared__ float pi_lds[G::A], v_lds[G::P + 1];
+    const int slot = blockIdx.x;
+    const int row = row_of_slot ? row_of_slot[slot] : slot;
+    heads_softmax_row(logits + (size_t)row * ld, threadIdx.x, G::A, G::P + 1, pi_lds, v_lds);
+    __syncthreads();
+    backup_slot<G>(ev, slot, threadIdx.x, pi_lds, v_lds, m_lds, scr);
+    if (!do_select) return;
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
+    select_slot<G>(ev, slot, threadIdx.x, act_lds, [&](const typename G::S &st, int lane) {
+        if (obs) {
+            if constexpr (NHWC8) G::write_obs_nhwc8(st, (_Float16 *)obs + (size_t)row * G::CELLS * 8, lane);
+            else G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);
+        }
+    });
+}
+
 // ================================================================================================ root stats
 // MCTS.probs (:308-329) of a tree's root into LDS pr[A]; every lane returns.  cnt = LDS float counts.
 template <class G>

@@ -159,6 +159,18 @@ class DeviceEngine:
             dt = 2 if obs.dim() == 3 else {torch.float32: 0, torch.float16: 1}[obs.dtype]
         _abi.check(self.L.azg_backup_select(self.h, _stream(), _ptr(policy), _ptr(value), _ptr(row_of_slot), flags, _ptr(obs), dt))
 
+    def backup_select_logits(self, logits, obs=None, row_of_slot=None, select=True, add_root_noise=None, add_root_temp=None):
+        """backup fed with LOGITS rows [rows, ld >= A + P + 1] (the softmaxes run inside the launch), optionally followed by the
+        next simulation's select(obs) in the same launch."""
+        assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape[1] >= self.A + self.NV
+        flags = -1 if add_root_noise is None and add_root_temp is None else (int(bool(add_root_noise)) | 2 * int(bool(add_root_temp)))
+        dt = 0
+        if obs is not None:
+            assert obs.is_cuda and obs.is_contiguous()
+            dt = 2 if obs.dim() == 3 else {torch.float32: 0, torch.float16: 1}[obs.dtype]
+        _abi.check(self.L.azg_backup_select_logits(self.h, _stream(), _ptr(logits), int(logits.shape[1]), _ptr(row_of_slot), flags,
+                                                   _ptr(obs), dt, int(bool(select))))
+
     def advance(self, record_history=True):
         _abi.check(self.L.azg_advance(self.h, _stream(), int(bool(record_history))))
 

@@ -227,7 +227,13 @@ class HipResNet:
         self._check(self.L.azg_conv3x3_f16(st, self.game, vp(x), vp(w), vp(b), vp(pre[0] if pre else None),
                                            vp(pre[1] if pre else None), vp(res), vp(y), int(boards), int(stem), int(relu)))
 
-    def forward_nhwc8(self, x, key=0):
+    def forward_logits_nhwc8(self, x, key=0):
+        """Wide-head networks only: x [B, H*W, 8] fp16 -> logits [B, OS*16] float32 (A policy logits, then P+1 value logits per
+        row), for DeviceEngine.backup_logits / backup_select_logits, which run the softmaxes inside the tree launch."""
+        assert self.fused and self.wide_head
+        return self.forward_nhwc8(x, key, logits_only=True)
+
+    def forward_nhwc8(self, x, key=0, logits_only=False):
         """x: [B, H*W, 8] fp16 -> (policy [B, A], value [B, P+1]) float32 probabilities.  `key` selects a private set
         of activation buffers (one per captured graph, so that graphs on different streams never share scratch)."""
         B = x.shape[0]
@@ -264,9 +270,12 @@ class HipResNet:
                 mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=self.device)
                 self._bufs[('pvw', B, key)] = (mk(self.A), mk(self.NV), mk(self.head_opad))
             pol, val, ws = self._bufs[('pvw', B, key)]
+            null = C.c_void_p(0)
             self._check(self.L.azg_policy_value_heads_f16(st, vp(s), vp(self.head_w_wide), vp(self.head_b_wide), int(B), self.HW * self.CH,
-                                                          int(self.A), int(self.NV), vp(ws), vp(pol), vp(val)))
-            return pol, val
+                                                          int(self.A), int(self.NV), vp(ws), null if logits_only else vp(pol),
+                                                          null if logits_only else vp(val)))
+            return ws if logits_only else (pol, val)
+        assert not logits_only
         logits = torch.matmul(s.view(B, self.HW * self.CH), self.head_w).float() + self.head_b
         return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
 
@@ -315,6 +324,7 @@ class CapturedNet:
 
     def __init__(self, graph, x, policy, value, run=None):
         self.graph, self.x, self.policy, self.value = graph, x, policy, value
+        self.run_logits = None
         self.run = run                   # the same evaluation as plain launches on the current stream -> (policy, value); lets a
                                          # caller capture it inside a larger graph (selfplay: a whole round of simulations)
 
@@ -413,7 +423,10 @@ class NNetWrapper:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g), torch.no_grad():
             p, v = run()
-        return CapturedNet(g, x, p, v, run)
+        cn = CapturedNet(g, x, p, v, run)
+        if self._hip is not None and self._hip.fused and self._hip.wide_head:
+            cn.run_logits = lambda: self._hip.forward_logits_nhwc8(x, key)   # stops at the logits (softmax inside the tree launch)
+        return cn
 
     @property
     def input_is_nhwc8(self):

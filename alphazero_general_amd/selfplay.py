@@ -141,7 +141,11 @@ class SelfPlayRunner:
                     sims = 0
                 else:
                     e.select(ln.obs)
+                logits_path = not self.warmup and ln.net.run_logits is not None    # wide heads: softmax inside the tree launch
                 for i in range(sims):                                # backup k and select k + 1 share a launch
+                    if logits_path:
+                        e.backup_select_logits(ln.net.run_logits(), ln.obs, select=i + 1 < sims)
+                        continue
                     p, v = (ln.policy, ln.value) if self.warmup else ln.net.run()
                     if i + 1 < sims:
                         e.backup_select(p, v, ln.obs)

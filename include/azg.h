@@ -138,6 +138,11 @@ int  azg_backup(azg_engine *e, void *stream, const float *policy_dev, const floa
  * touch the same trees); arguments as for the two calls, identical results. */
 int  azg_backup_select(azg_engine *e, void *stream, const float *policy_dev, const float *value_dev,
                        const int32_t *row_of_slot_dev, int flags, void *obs_dev, int obs_dtype);
+/* azg_backup (do_select = 0) or azg_backup_select (do_select = 1) fed with LOGITS: row r of logits_dev (stride logits_stride
+ * floats) holds the A policy logits, then the P+1 value logits, of network row r -- the workspace azg_policy_value_heads_f16
+ * fills; the two softmaxes of NNetArchitecture.py:112-118 run inside this launch.  Same results as softmax + azg_backup. */
+int  azg_backup_select_logits(azg_engine *e, void *stream, const float *logits_dev, int logits_stride,
+                              const int32_t *row_of_slot_dev, int flags, void *obs_dev, int obs_dtype, int do_select);
 #define AZG_FLAGS_DEFAULT (-1)   /* use azg_config.add_root_noise / add_root_temp                          */
 #define AZG_FLAG_NOISE 1          /* process_results(..., add_root_noise, add_root_temp) per call (:230)    */
 #define AZG_FLAG_TEMP  2
@@ -237,7 +242,8 @@ int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const
 /* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same
  * [k = H*W*C, A+NV] matrix applied to the final stream y [boards, k] fp16 that azg_resnet_tower_f16 stores, then the
  * two softmaxes.  head_w_packed: fragment order [k/32][OS = ceil((A+NV)/16)][64 lanes][8 halves], lane g*16+i, half j
- * = Wfull[ks*32 + g*8 + j, sub*16 + i] (zero beyond A+NV); head_b: f32[OS*16]; logits_ws: f32[boards * OS*16] scratch. */
+ * = Wfull[ks*32 + g*8 + j, sub*16 + i] (zero beyond A+NV); head_b: f32[OS*16]; logits_ws: f32[boards * OS*16] scratch.
+ * policy_dev = value_dev = NULL: stop at the logits (rows of stride OS*16 in logits_ws, for azg_backup_select_logits). */
 int  azg_policy_value_heads_f16(void *stream, const void *y_dev, const void *head_w_packed_dev, const float *head_b_dev,
                                 int boards, int k, int A, int NV, float *logits_ws_dev, float *policy_dev, float *value_dev);
 

@@ -157,3 +157,31 @@ def test_bench_two_ranks_on_one_gpu():
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and d['games_finished'] > 0
     assert d['samples_gathered'] >= d['games_finished'] * 7 * 2          # both ranks' shards arrived
     assert 'cpu_baseline' not in d                                       # rank 0, N = 1 only
+
+
+@pytest.mark.parametrize('game', ['brandubh', 'trimok'])
+def test_wide_head_runner_logits_path_equals_plain_launches(game):
+    """networks with wide heads (brandubh A = 588, 3-player env A = 25): the captured round hands LOGITS to the tree launch
+    (azg_backup_select_logits: softmax + backup + select in one launch); plain launches run heads -> softmax kernel ->
+    backup -> select.  Same games, same samples."""
+    import importlib
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    import torch
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    torch.manual_seed(17)
+    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    outs = []
+    for use_graph in (True, False):
+        r = SelfPlayRunner(Game, net, _args(numMCTSSims=9, cpuct=1.25, fpu_reduction=0.2), num_slots=40, seed=6, use_graph=use_graph,
+                           example_capacity=40 * 101 * 8 * 2)
+        if use_graph:
+            assert r.lanes[0].net.run_logits is not None
+        for _ in range(14):
+            r.play_round()
+        o, p, z = r.samples()
+        outs.append((o.cpu().numpy(), p.cpu().numpy(), z.cpu().numpy(), r.engine.last_actions().cpu().numpy(), r.counters()))
+    a, b = outs
+    assert a[4] == b[4] and a[4]['sims'] == 14 * 9 * 40
+    for x, y in zip(a[:4], b[:4]):
+        assert x.shape == y.shape and (x == y).all()
