@@ -515,7 +515,6 @@ template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSear
 __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
-    static_assert(PSPLIT == 1 || C < 128, "the fused heads assume one wave per cout group");
     static_assert(!IS_SEARCH || (PSPLIT == 1 && C == 128 && BOARDS == C / 32), "search mode: one wave per game, fused heads");
     TowerParams P = Pin;
     constexpr int NT = C * 2 * PSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
@@ -746,6 +745,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             const unsigned bbase = (unsigned)((GEO::LEAD + (bvalid ? i16 : 0) * GEO::BSTRIDE) * RS + g * 16);
             const half8 *hw = reinterpret_cast<const half8 *>(P.head_w) + lane;
             const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            // (with pixel-split workgroups only the first four waves -- one per cout group -- take part: the same pixel split and
+            //  the same summation order in every tile shape, so a board's probabilities do not depend on the shape)
+            if (wave < 4)
 #pragma unroll
             for (int j0 = 0; j0 < NPW; j0 += JB) {
                 half8 af[JB][4], bf[JB][4];
@@ -778,8 +780,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             AZG_WGSTAMP(6);
             __syncthreads();
             float *red = reinterpret_cast<float *>(img);
+            if (wave < 4) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) red[(wave * 16 + g * 4 + r) * 16 + i16] = hacc[r];
+                for (int r = 0; r < 4; r++) red[(wave * 16 + g * 4 + r) * 16 + i16] = hacc[r];
+            }
             __syncthreads();
             const int nb_here = min(BOARDS, P.boards - tile * BOARDS);
             if (tid < 64) {                                      // lane = (board, output): both softmaxes inside 16-lane groups
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             }
             AZG_WGSTAMP(7);
             __syncthreads();
-            reinterpret_cast<uint4 *>(img)[tid] = make_uint4(0, 0, 0, 0);
+            if (tid < 256) reinterpret_cast<uint4 *>(img)[tid] = make_uint4(0, 0, 0, 0);
             if constexpr (IS_SEARCH) { if (tid < 16) reinterpret_cast<uint4 *>(img + SCRATCH_PV)[tid] = make_uint4(0, 0, 0, 0); }
         }
         __syncthreads();

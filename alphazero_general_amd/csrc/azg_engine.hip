@@ -609,15 +609,16 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
 // the single-tree API, brandubh's 512 games per GPU).  AZG_TOWER_BOARDS overrides the choice (measurement knob).
 static int dispatch_tower(hipStream_t s, int game, int channels, const TowerParams &P) {
     static const int forced = getenv("AZG_TOWER_BOARDS") ? atoi(getenv("AZG_TOWER_BOARDS")) : 0;
+    static const int psplit = getenv("AZG_TOWER_PSPLIT") ? atoi(getenv("AZG_TOWER_PSPLIT")) : 0;   // measurement knob
     const int n = P.boards;
     if (game == AZG_GAME_CONNECT4 && channels == 128) {
         const int bt = forced ? forced : n <= 640 ? 1 : n <= 1280 ? 2 : 4;
+        if (bt == 1 && psplit == 2) return launch_tower<C4::H, C4::W, 1, 128, 2>(s, P);   // 8 waves, 2 + 1 pixel subtiles: measured slower (101 vs 69 us)
         if (bt == 1) return launch_tower<C4::H, C4::W, 1, 128>(s, P);
         if (bt == 2) return launch_tower<C4::H, C4::W, 2, 128>(s, P);
         return launch_tower<C4::H, C4::W, 4, 128>(s, P);
     }
     if (game == AZG_GAME_CONNECT4 && channels == 64) return launch_tower<C4::H, C4::W, 4, 64>(s, P);
-    static const int psplit = getenv("AZG_TOWER_PSPLIT") ? atoi(getenv("AZG_TOWER_PSPLIT")) : 0;   // measurement knob
     if (game == AZG_GAME_BRANDUBH && channels == 64) {           // two cout groups: split the pixels too at small batches
         // measured (us per evaluation incl. heads, 256 / 512 / 1024 / 2048 boards): 1 board, no split 39 / 47 / 66 / 107;
         // 1 board, split 35 / 46 / 80 / 113; 2 boards, split 39 / 43 / 63 / 113
