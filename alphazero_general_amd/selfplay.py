@@ -34,7 +34,7 @@ class SelfPlayRunner:
 
     def __init__(self, game_cls, nnet, args, *, num_slots, seed=0, slot_base=0, device=None, example_capacity=None,
                  use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None, result_capacity=None,
-                 fused_search=False):
+                 fused_search=None):
         self.game_cls, self.nnet, self.args = game_cls, nnet, args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -85,8 +85,8 @@ class SelfPlayRunner:
         self.sims_per_round = []
         # connect4 + fused 128-channel tower: the whole simulation loop of a move can be ONE persistent launch (azg_search_f16)
         hip = getattr(nnet, '_hip', None) if nnet is not None else None
-        self.fused_search = bool(fused_search) and self.round_graph and not self.warmup and self.game == 0 and hip is not None \
-            and hip.fused and hip.fused_head
+        self.fused_search = (fused_search is None or bool(fused_search)) and self.round_graph and not self.warmup and self.game == 0 \
+            and hip is not None and hip.fused and hip.fused_head and hip.CH == 128
 
     @property
     def obs(self):

@@ -218,7 +218,7 @@ def main():
     games = 1 << 30
     per_game = 43 * 2
     runner = SelfPlayRunner(Game, net, selfplay_args(games), num_slots=B, seed=0, slot_base=D.slot_base(rank, B),
-                            device=local_rank, use_graph=not a.no_graph, pipelines=a.pipelines, fused_search=not a.no_fused_search and a.pipelines == 1,
+                            device=local_rank, use_graph=not a.no_graph, pipelines=a.pipelines, fused_search=False if (a.no_fused_search or a.pipelines > 1) else None,
                             example_capacity=int(B * (a.steps + a.warmup + 8) / 7.0 + 2 * B) * per_game)
     eng = runner.engine
     lanes = runner.lanes

@@ -62,10 +62,10 @@ def test_selfplay_runner_launch_strategy_is_invisible(variant):
     outs = []
     # fast rounds (a second captured round graph with numFastSims, no history) and periodic tree resets ride along in one variant
     extra = dict(probFastSim=0.4, numFastSims=5, mctsResetThreshold=3) if variant.endswith('fast_rounds_resets') else {}
-    first = dict(fused_search=True) if variant.endswith('fused_search') else dict()   # one persistent launch per move (azg_search_f16)
+    first = dict(fused_search=True) if variant.endswith('fused_search') else dict(fused_search=False) if variant == 'no_graph' else dict()
     for kw in (first, dict(use_graph=False) if variant.startswith('no_graph') else dict(pipelines=2)):
         r = SelfPlayRunner(Game, net, _args(**extra), num_slots=64, seed=9, example_capacity=64 * 43 * 2 * 4, **kw)
-        assert r.fused_search == bool(kw.get('fused_search'))
+        assert r.fused_search == bool(kw.get('fused_search', kw.get('use_graph', True)))     # on by default when graphs are
         for _ in range(30):
             r.play_round()
         obs, pi, z = r.samples()
