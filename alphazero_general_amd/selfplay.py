@@ -225,6 +225,29 @@ class SelfPlayRunner:
                 ln.stream.synchronize()
         return tuple(torch.cat([o[j] for o in outs]) for j in range(3))
 
+    def save_iteration_samples(self, folder, iteration, first_per_lane=None):
+        """Write the iteration's samples the way Coach.saveIterationSamples does (Coach.py:363-386): three CPU float32 tensors
+        `iteration-NNNN-{data,policy,value}.pkl` (torch.save, highest pickle protocol) that the unchanged Coach.train loads
+        (:444-456).  Returns the number of samples."""
+        import os
+        import pickle
+        data, policy, value = [t.cpu() for t in self.samples(first_per_lane)]
+        os.makedirs(folder, exist_ok=True)
+        stem = os.path.join(folder, 'iteration-%04d' % int(iteration))              # utils.get_iter_file :15-16
+        torch.save(data, stem + '-data.pkl', pickle_protocol=pickle.HIGHEST_PROTOCOL)
+        torch.save(policy, stem + '-policy.pkl', pickle_protocol=pickle.HIGHEST_PROTOCOL)
+        torch.save(value, stem + '-value.pkl', pickle_protocol=pickle.HIGHEST_PROTOCOL)
+        return int(data.shape[0])
+
+    def game_results(self):
+        """(wins per player, draws, average game length) -- utils.get_game_results (:34-54), what Coach.processGameResults
+        logs (Coach.py:388-398) -- over every finished game."""
+        ws, turns, _ = self.results()
+        P = self.game_cls.num_players()
+        wins = [int(ws[:, p].sum()) for p in range(P)] if len(ws) else [0] * P
+        draws = int(ws[:, P].sum()) if len(ws) else 0
+        return wins, draws, (float(turns.sum()) / len(turns) if len(turns) else 0)
+
     def results(self):
         import numpy as np
         rs = [ln.engine.results() for ln in self.lanes]

@@ -185,3 +185,21 @@ def test_wide_head_runner_logits_path_equals_plain_launches(game):
     assert a[4] == b[4] and a[4]['sims'] == 14 * 9 * 40
     for x, y in zip(a[:4], b[:4]):
         assert x.shape == y.shape and (x == y).all()
+
+
+def test_runner_writes_coach_iteration_files(tmp_path):
+    """SelfPlayRunner.save_iteration_samples writes what Coach.saveIterationSamples writes (Coach.py:363-386): three float32 CPU
+    tensors that load with torch.load and line up row by row; game_results is get_game_results (utils.py:34-54)."""
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    r = SelfPlayRunner(Game, _net(5), _args(gamesPerIteration=40), num_slots=32, seed=2)
+    c = r.run()
+    n = r.save_iteration_samples(str(tmp_path / 'run'), 3)
+    # (weights_only=False: what torch.load meant in the reference's torch < 2.5, Coach.py:448-450)
+    d, p, v = [torch.load(str(tmp_path / 'run' / ('iteration-0003-%s.pkl' % k)), weights_only=False) for k in ('data', 'policy', 'value')]
+    assert d.shape == (n, 4, 6, 7) and p.shape == (n, 7) and v.shape == (n, 3) and d.dtype == p.dtype == v.dtype == torch.float32
+    assert not d.is_cuda and n == c['num_examples'] > 0
+    assert torch.allclose(p.sum(1), torch.ones(n), atol=1e-5) and ((v == 0) | (v == 1)).all() and (v.sum(1) == 1).all()
+    wins, draws, avg_len = r.game_results()
+    assert sum(wins) + draws == c['num_results'] >= 40 and 7 <= avg_len <= 42
