@@ -59,6 +59,7 @@ SYMBOLS = {
     'azg_get_tape_counters': (_i, [_vp, _vp, _i, _i, C.POINTER(_u64)]),
     'azg_select': (_i, [_vp, _vp, _vp, _i, _vp]),
     'azg_arena_rows': (_i, [_vp, _vp, _i32p, _vp, _vp]),
+    'azg_arena_rows_seats': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'azg_backup': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     'azg_backup_select': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
     'azg_backup_select_logits': (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i]),

@@ -256,7 +256,15 @@ extern "C" int azg_arena_rows(azg_engine *e, void *stream, const int32_t *p2i_ho
     if (e->gi.num_players > 8) return fail(AZG_E_UNSUPPORTED, "more than 8 players");
     SeatMap seat{};
     for (int i = 0; i < e->gi.num_players; i++) seat.v[i] = p2i_host[i];
-    hipLaunchKernelGGL(k_arena_rows, dim3(1), dim3(64), 0, s, e->v, seat, row_of_slot, rows_per_model);
+    hipLaunchKernelGGL(k_arena_rows, dim3(1), dim3(64), 0, s, e->v, seat, (const uint32_t *)nullptr, row_of_slot, rows_per_model);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_arena_rows_seats(azg_engine *e, void *stream, const uint32_t *seat_of_slot, int32_t *row_of_slot, int32_t *rows_per_model) {
+    if (!e || !seat_of_slot || !row_of_slot || !rows_per_model) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (e->gi.num_players > 8) return fail(AZG_E_UNSUPPORTED, "more than 8 players");
+    hipLaunchKernelGGL(k_arena_rows, dim3(1), dim3(64), 0, (hipStream_t)stream, e->v, SeatMap{}, seat_of_slot, row_of_slot, rows_per_model);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }

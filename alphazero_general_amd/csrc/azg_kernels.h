@@ -594,7 +594,10 @@ __global__ __launch_bounds__(64) void k_reset_max_depth(View ev) {
 // arena rows (SelfPlayAgent.pyx:117-132): rows grouped by model = player_to_index[mover], slot order inside a group
 struct SeatMap { int32_t v[8]; };                            // player_to_index by value: no host copy, graph-capturable
 
-__global__ __launch_bounds__(64) void k_arena_rows(View ev, SeatMap seat, int32_t *row_of_slot, int32_t *rows_per_model) {
+// seat_of_slot (optional): per-slot seat permutation, 4 bits per player (model of player p = (word >> 4p) & 15) -- every
+// concurrent game can have its own seating instead of the one permutation per agent of SelfPlayAgent.pyx:44-47.
+__global__ __launch_bounds__(64) void k_arena_rows(View ev, SeatMap seat, const uint32_t *seat_of_slot, int32_t *row_of_slot,
+                                                   int32_t *rows_per_model) {
     const int lane = threadIdx.x;
     const int32_t *p2i = seat.v;
     int base = 0;
@@ -602,7 +605,11 @@ __global__ __launch_bounds__(64) void k_arena_rows(View ev, SeatMap seat, int32_
         int cntm = 0;
         for (int s0 = 0; s0 < ev.B; s0 += 64) {
             const int s = s0 + lane;
-            const int is = s < ev.B ? (p2i[ev.states[s].player] == mi) : 0;
+            int is = 0;
+            if (s < ev.B) {
+                const int mover = ev.states[s].player;
+                is = (seat_of_slot ? (int)((seat_of_slot[s] >> (4 * mover)) & 15u) : p2i[mover]) == mi;
+            }
             const int r = wave_excl_scan(is, lane);
             if (is) row_of_slot[s] = base + cntm + r;
             cntm += wave_sum_i(is);

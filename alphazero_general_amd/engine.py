@@ -142,6 +142,15 @@ class DeviceEngine:
         _abi.check(self.L.azg_arena_rows(self.h, _stream(), p2i, _ptr(self._row_of_slot), _ptr(self._rows_per_model)))
         return self._row_of_slot, self._rows_per_model
 
+    def arena_rows_seats(self, seat_of_slot):
+        """arena_rows with one seating per slot: seat_of_slot = int32 device tensor [B], 4 bits per player (model of player p)."""
+        if self._row_of_slot is None:
+            self._row_of_slot = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+            self._rows_per_model = torch.zeros(self.P, dtype=torch.int32, device=self.device)
+        assert seat_of_slot.is_cuda and seat_of_slot.dtype == torch.int32 and seat_of_slot.numel() == self.B
+        _abi.check(self.L.azg_arena_rows_seats(self.h, _stream(), _ptr(seat_of_slot), _ptr(self._row_of_slot), _ptr(self._rows_per_model)))
+        return self._row_of_slot, self._rows_per_model
+
     def backup(self, policy, value, row_of_slot=None, add_root_noise=None, add_root_temp=None):
         assert policy.is_cuda and policy.dtype == torch.float32 and policy.is_contiguous() and policy.shape[1] == self.A
         assert value.is_cuda and value.dtype == torch.float32 and value.is_contiguous() and value.shape[1] == self.NV

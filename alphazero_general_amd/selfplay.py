@@ -264,7 +264,8 @@ class ArenaRunner:
     correct row <-> game map (the reference's mis-routing, SURVEY.md Q15, is not reproduced).  Returns the
     (wins, draws, winrates) contract of Arena.play_games (:376) via get_game_results semantics (utils.py:34-54)."""
 
-    def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None, use_graph=True, result_capacity=None):
+    def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None, use_graph=True, result_capacity=None,
+                 seats='agent'):
         self.game_cls, self.nnets, self.args = game_cls, list(nnets), args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -285,6 +286,23 @@ class ArenaRunner:
                                    result_capacity=int(result_capacity if result_capacity is not None else
                                                        min(int(args.get('gamesPerIteration', 1 << 30)), 1 << 20) + 4 * self.B + 1024))
         e = self.engine
+        # seats = 'agent': the one permutation above for every game (the reference, SelfPlayAgent.pyx:44-47);
+        # seats = 'slot': every concurrent game draws its own seating from its slot's stream of the tape, so that
+        # one engine of B games is as balanced as the reference's many agents
+        assert seats in ('agent', 'slot')
+        self.seats = seats
+        self.slot_seats = None
+        if seats == 'slot':
+            perm = []
+            for sl in range(self.B):
+                _abi.lib().azg_tape_shuffle_pos(self.seed ^ 0x5EA7, AGENT_STREAM + self.slot_base + 1 + sl, 0, P, pos)
+                m = [0] * P
+                for i in range(P):
+                    m[pos[i]] = i
+                perm.append(m)
+            self.slot_player_to_index = perm                        # [slot][player] -> model
+            packed = [sum(m[p] << (4 * p) for p in range(P)) for m in perm]
+            self.slot_seats = torch.tensor(packed, dtype=torch.int32, device=e.device)
         hip = all(getattr(n, '_hip', None) is not None or (n.refresh() and n._hip is not None) for n in self.nnets)
         self.nhwc8 = bool(hip)
         self.obs = (torch.zeros((self.B, e.gi.obs_h * e.gi.obs_w, 8), dtype=torch.float16, device=e.device) if self.nhwc8
@@ -297,12 +315,16 @@ class ArenaRunner:
         if self.device_split and use_graph:
             self.capture()
 
+    def _rows(self):
+        e = self.engine
+        return e.arena_rows_seats(self.slot_seats) if self.slot_seats is not None else e.arena_rows(self.player_to_index)
+
     def step(self):
         if self.device_split:
             self._step_device_split()
             return
         e = self.engine
-        row_of_slot, rpm = e.arena_rows(self.player_to_index)
+        row_of_slot, rpm = self._rows()
         e.select(self.obs, row_of_slot)
         counts = rpm.cpu().tolist()                                  # host read of the batch split, once per simulation
         off = 0
@@ -318,7 +340,7 @@ class ArenaRunner:
         """rows -> select -> every model on its own slice (the split stays on the device) -> backup: no host read, so the
         whole simulation step is one hipGraph."""
         e = self.engine
-        row_of_slot, rpm = e.arena_rows(self.player_to_index)
+        row_of_slot, rpm = self._rows()
         e.select(self.obs, row_of_slot)
         HipResNet.forward_models([n._hip for n in self.nnets], self.obs, self.policy, self.value, rpm)    # one launch
         e.backup(self.policy, self.value, row_of_slot)
@@ -328,7 +350,7 @@ class ArenaRunner:
         advance, so the rows are laid out once; then select, and per simulation ONE tower launch for all models plus one
         tree launch (backup k + select k + 1); advance."""
         e = self.engine
-        row_of_slot, rpm = e.arena_rows(self.player_to_index)
+        row_of_slot, rpm = self._rows()
         e.select(self.obs, row_of_slot)
         nets = [n._hip for n in self.nnets]
         for i in range(sims):
@@ -371,12 +393,13 @@ class ArenaRunner:
         ws, turns, slot = self.engine.results()
         P = self.game_cls.num_players()
         wins, draws = [0] * P, 0
-        for w in ws:
+        for w, sl in zip(ws, slot):
+            p2i = self.slot_player_to_index[int(sl)] if self.slot_seats is not None else self.player_to_index
             for p in range(P + 1):
                 if w[p]:
                     if p == P:
                         draws += 1
                     else:
-                        wins[self.player_to_index[p]] += 1
+                        wins[p2i[p]] += 1
         n = max(len(ws), 1)
         return wins, draws, [x / n for x in wins]

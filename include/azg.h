@@ -130,6 +130,10 @@ int  azg_select(azg_engine *e, void *stream, void *obs_dev, int obs_dtype, const
  * rows_per_model_dev[P] (device), to be called before azg_select */
 int  azg_arena_rows(azg_engine *e, void *stream, const int32_t *player_to_index_host, int32_t *row_of_slot_dev,
                     int32_t *rows_per_model_dev);
+/* the same with one seating per SLOT instead of per agent: seat_of_slot_dev[B], 4 bits per player -- the model of player p in
+ * slot s is (seat_of_slot_dev[s] >> 4p) & 15 (every concurrent game draws its own seats) */
+int  azg_arena_rows_seats(azg_engine *e, void *stream, const uint32_t *seat_of_slot_dev, int32_t *row_of_slot_dev,
+                          int32_t *rows_per_model_dev);
 /* SelfPlayAgent.processBatch (:137-151) = MCTS.process_results (:230-289) on every slot with row
  * row_of_slot[slot] of policy_dev[rows, A] / value_dev[rows, P+1] (float32 probabilities). */
 int  azg_backup(azg_engine *e, void *stream, const float *policy_dev, const float *value_dev,

@@ -203,3 +203,31 @@ def test_runner_writes_coach_iteration_files(tmp_path):
     assert torch.allclose(p.sum(1), torch.ones(n), atol=1e-5) and ((v == 0) | (v == 1)).all() and (v.sum(1) == 1).all()
     wins, draws, avg_len = r.game_results()
     assert sum(wins) + draws == c['num_results'] >= 40 and 7 <= avg_len <= 42
+
+
+def test_arena_runner_per_slot_seats():
+    """seats='slot': every concurrent game has its own seating.  The row map the device builds must equal a numpy restatement
+    (model of a game's mover = its slot's permutation), roughly half the games seat model 0 first, graph == eager, and the
+    tallies add up per model."""
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.selfplay import ArenaRunner
+    nets = [_net(0), _net(1)]
+    runs = []
+    for use_graph in (True, False):
+        r = ArenaRunner(Game, nets, _args(), num_slots=96, seed=8, use_graph=use_graph, seats='slot')
+        first = sum(1 for m in r.slot_player_to_index if m[0] == 0)
+        assert 24 <= first <= 72                                      # a fair coin per slot
+        for rnd in range(12):
+            r.play_round()
+            if rnd in (0, 5):
+                row_of_slot, rpm = r._rows()
+                movers = [st[1] for st in r.engine.get_states()]
+                model = np.array([r.slot_player_to_index[s][movers[s]] for s in range(96)])
+                exp = np.zeros(96, np.int64)
+                exp[model == 0] = np.arange((model == 0).sum()); exp[model == 1] = (model == 0).sum() + np.arange((model == 1).sum())
+                assert (row_of_slot.cpu().numpy() == exp).all() and rpm.cpu().tolist() == [(model == 0).sum(), (model == 1).sum()]
+        runs.append((r.engine.last_actions().cpu().numpy().copy(), r.engine.counters(), r.results()))
+    assert (runs[0][0] == runs[1][0]).all() and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    wins, draws, _ = runs[0][2]
+    assert sum(wins) + draws == runs[0][1]['games_played'] > 0
