@@ -144,6 +144,37 @@ def pack_conv_weight(w, ks):
     return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1).to(torch.float16)
 
 
+def _reference_pickle():
+    """A pickle module whose Unpickler resolves the reference's own classes without the reference installed: alphazero.utils.dotdict
+    -> utils.dotdict; anything else that cannot be imported (optimizer / scheduler classes of other torch versions, ...) -> a
+    placeholder, since only 'state_dict' and the architecture keys of 'args' are used."""
+    import pickle
+    import types
+
+    class _Missing:
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, state):
+            pass
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.startswith('alphazero.') and name == 'dotdict':
+                return dotdict
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return _Missing
+
+    mod = types.ModuleType('azg_reference_pickle')
+    for k in dir(pickle):
+        if not k.startswith('__'):
+            setattr(mod, k, getattr(pickle, k))
+    mod.Unpickler = Unpickler
+    return mod
+
+
 class HipResNet:
     """The eval-mode network with its residual tower on the hand-written gfx950 MFMA convolution
     (azg_conv3x3_f16: one launch per conv with the bias / ReLU / pre-activation affine / residual add fused) and the
@@ -435,10 +466,35 @@ class NNetWrapper:
     def replay(self):
         self._graph[0].replay()
 
-    def save_checkpoint(self, path):
-        torch.save({'state_dict': self.nnet.state_dict(), 'args': dict(self.args)}, path)
+    def save_checkpoint(self, folder='checkpoint', filename='checkpoint.pth.tar', make_dirs=True):
+        """NNetWrapper.save_checkpoint (NNetWrapper.py:239-250): {'state_dict', 'args'} under folder/filename (no optimizer /
+        scheduler state: this wrapper only evaluates); the reference's load_checkpoint reads it."""
+        import os
+        import pickle
+        if make_dirs and not os.path.exists(folder):
+            os.makedirs(folder)
+        torch.save({'state_dict': self.nnet.state_dict(), 'args': self.args}, os.path.join(folder, filename),
+                   pickle_protocol=pickle.HIGHEST_PROTOCOL)
 
-    def load_checkpoint(self, path):
-        ck = torch.load(path, map_location=self.device, weights_only=False)
+    def load_checkpoint(self, folder='checkpoint', filename='checkpoint.pth.tar', use_saved_args=True):
+        """NNetWrapper.load_checkpoint (NNetWrapper.py:252-276), also for files the REFERENCE wrote: their pickles name
+        alphazero.utils.dotdict (mapped to this package's dotdict when the reference is not importable); opt_state / sch_state
+        are ignored.  With use_saved_args the network is rebuilt from the saved architecture keys first.  Returns the saved
+        args (or None)."""
+        import os
+        path = os.path.join(folder, filename)
+        if not os.path.exists(path):
+            raise FileNotFoundError('No model in path {}'.format(path))
+        ck = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_reference_pickle())
+        saved = ck.get('args')
+        if use_saved_args and saved is not None:
+            arch = {k: saved[k] for k in DEFAULT_NET_ARGS if k in saved}
+            if any(self.args.get(k) != v for k, v in arch.items()):
+                self.args.update(arch)
+                obs = tuple(self.game_cls.observation_size())
+                self.nnet = ResNet(obs, self.game_cls.action_size(), self.game_cls.num_players() + self.game_cls.has_draw(),
+                                   self.args).to(self.device)
+                self.nnet.eval()
         self.nnet.load_state_dict(ck['state_dict'])
-        self._infer = None
+        self._infer = self._hip = self._graph = None
+        return dotdict(saved) if saved is not None else None

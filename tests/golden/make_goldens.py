@@ -393,6 +393,29 @@ def gen_net():
     print('c4_net: %d boards' % len(obs))
 
 
+def gen_ckpt():
+    """A checkpoint file written by the REFERENCE NNetWrapper.save_checkpoint (alphazero/NNetWrapper.py:239-250) for a tiny
+    net, plus the reference's own process() outputs on fixed boards: pins load_checkpoint compatibility (keys, args, weights)."""
+    import torch
+    import torch.optim as optim
+    from alphazero.NNetWrapper import NNetWrapper
+    from alphazero.envs.connect4.connect4 import Game
+    from alphazero.utils import dotdict
+    torch.manual_seed(1234)
+    args = dotdict(dict(nnet_type='resnet', num_channels=8, depth=2, value_head_channels=2, policy_head_channels=3,
+                        value_dense_layers=[12, 6], policy_dense_layers=[10], lr=1e-2, optimizer=optim.SGD,
+                        optimizer_args=dotdict(dict(momentum=0.9)), scheduler=optim.lr_scheduler.MultiStepLR,
+                        scheduler_args=dotdict(dict(milestones=[10], gamma=0.1)), cuda=False, value_loss_weight=1.5))
+    w = NNetWrapper(Game, args)
+    w.nnet.load_state_dict(fill_deterministic(w.nnet.state_dict()))
+    w.save_checkpoint(folder=OUT, filename='c4_ref_checkpoint.pth.tar')
+    d = np.load(os.path.join(OUT, 'c4_net.npz'))
+    w.nnet.eval()
+    p, v = w.process(torch.from_numpy(d['obs']))
+    np.savez_compressed(os.path.join(OUT, 'c4_ckpt.npz'), obs=d['obs'], policy=p.numpy(), value=v.numpy())
+    print('c4_ckpt: %d bytes' % os.path.getsize(os.path.join(OUT, 'c4_ref_checkpoint.pth.tar')))
+
+
 def main():
     which = sys.argv[1:] or ['c4_rules', 'c4_tree', 'c4_agent', 'c4_arena']
     rh.import_reference()
@@ -407,6 +430,8 @@ def main():
         gen_arena(C4, ol.GAME_CONNECT4, 'c4')
     if 'c4_net' in which:
         gen_net()
+    if 'c4_ckpt' in which:
+        gen_ckpt()
     if 'br_rules' in which:
         gen_br_rules()
     if 'br_tree' in which:

@@ -3,6 +3,7 @@ tests/golden/make_goldens.py with deterministic weights; checkpoint keys and sha
 import os
 
 import numpy as np
+import pytest
 import torch
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -55,3 +56,27 @@ def test_default_net_vs_reference():
 def test_connect4_train_net_vs_reference():
     from alphazero_general_amd.nnet import CONNECT4_NET_ARGS
     _check('c4train', CONNECT4_NET_ARGS)
+
+
+def test_load_checkpoint_written_by_the_reference(tmp_path):
+    """tests/golden/c4_ref_checkpoint.pth.tar was written by the reference's NNetWrapper.save_checkpoint (make_goldens.py
+    c4_ckpt); c4_ckpt.npz holds the reference's own process() outputs.  Loading it here (no reference importable) must rebuild
+    the saved architecture and reproduce those outputs; a save / load round trip through this wrapper must too."""
+    import sys
+    import torch
+    assert not any(m == 'alphazero' or m.startswith('alphazero.') for m in sys.modules), 'the reference must not be importable here'
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import NNetWrapper
+    d = dict(np.load(os.path.join(G, 'c4_ckpt.npz')))
+    w = NNetWrapper(Game, device='cpu', backend='torch')
+    saved = w.load_checkpoint(G, 'c4_ref_checkpoint.pth.tar')
+    assert saved.num_channels == 8 and saved.depth == 2 and w.args.num_channels == 8 and saved.value_loss_weight == 1.5
+    p, v = w.process(torch.from_numpy(d['obs']))
+    assert np.abs(p.numpy() - d['policy']).max() < 1e-6 and np.abs(v.numpy() - d['value']).max() < 1e-6
+    w.save_checkpoint(str(tmp_path), 'again.pth.tar')
+    w2 = NNetWrapper(Game, device='cpu', backend='torch')
+    w2.load_checkpoint(str(tmp_path), 'again.pth.tar')
+    p2, v2 = w2.process(torch.from_numpy(d['obs']))
+    assert torch.equal(p, p2) and torch.equal(v, v2)
+    with pytest.raises(FileNotFoundError):
+        w2.load_checkpoint(str(tmp_path), 'missing.pth.tar')
