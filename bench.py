@@ -41,6 +41,9 @@ TOWER_TRAFFIC_BYTES = 50850000   # PMC per launch @2048 boards, (2 x FETCH_SIZE 
                                  # (8 x 4.7 = 38 MB; Infinity-Cache hits are counted) + inputs, 6.4 MB written (52 B/lane of spills)
 
 
+SEARCH_TRAFFIC_BYTES = 7169000000  # one azg_search_f16 launch, 2048 games x 100 sims
+
+
 def selfplay_args(games):
     return dotdict(cpuct=4.0, fpu_reduction=0.4, root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0,
                    numMCTSSims=SIMS, numFastSims=20, numWarmupSims=5, probFastSim=0.0, gamesPerIteration=games,
@@ -300,7 +303,9 @@ def main():
                           'on every game, one persistent launch per move)' % SIMS, 'bound': 'mfma', 'achieved': round(stf, 1),
                 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(stf / MFMA_F16_PEAK_TFLOPS, 4),
                 'avg_launch_us': round(sms * 1e3, 1), 'algorithmic_flops_per_launch': C4_NET_FLOPS_PER_LEAF * Bl * SIMS,
-                'traffic': TOWER_TRAFFIC_BYTES * SIMS if Bl == 2048 else None,
+                # PMC per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_summary.csv rows search_r1d): 72 MB per simulation
+                # = the tower's 51 MB (weight stream per XCD) + the trees' ~8 MB + ~13 MB of spill traffic
+                'traffic': SEARCH_TRAFFIC_BYTES if (Bl == 2048 and SIMS == 100) else None,
                 # the same tower + heads as its own launch (one evaluation), timed as a burst of NN_REPS launches: after the
                 # lighter search launches the chip boosts, so this runs faster than the same kernel does in a sustained stream
                 # (0.28 ms = 60 % with --no-fused-search, where it is launched 100 times per move)
