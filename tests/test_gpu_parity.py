@@ -641,3 +641,43 @@ def test_whole_games_sample_invariants(torch_mod, game):
         off += n
     assert off == o.shape[0]
     eng.close()
+
+
+def test_abi_argument_validation(torch_mod):
+    """every entry point rejects bad arguments with a status code and a message (azg_last_error) instead of touching the GPU."""
+    import ctypes as C
+    from alphazero_general_amd import _abi
+    L = _abi.lib()
+    eng = engine(B=8, sims_hint=4)
+    h, null = eng.h, C.c_void_p(0)
+    st = C.c_void_p(torch_mod.cuda.current_stream().cuda_stream)
+    pol = torch_mod.zeros((8, 7), device=eng.device); val = torch_mod.zeros((8, 3), device=eng.device)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+
+    def bad(rc, code=_abi.E_INVALID_ARG):
+        assert rc == code, (rc, L.azg_last_error())
+        assert len(L.azg_last_error()) > 0
+
+    bad(L.azg_select(null, st, null, 0, null))
+    bad(L.azg_select(h, st, null, 7, null))                                   # unknown obs dtype
+    bad(L.azg_backup(h, st, null, vp(val), null, -1))
+    bad(L.azg_backup_select(h, st, vp(pol), null, null, -1, null, 0))
+    bad(L.azg_backup_select_logits(h, st, vp(pol), 7, null, -1, null, 0, 1))  # stride < A + P + 1
+    bad(L.azg_set_states(h, st, 6, 5, _abi.states_array(5), 1))               # slot range out of bounds
+    bad(L.azg_resnet_tower_f16(st, 0, null, null, null, null, null, null, 4, 1, 128))
+    bad(L.azg_resnet_tower_f16(st, 0, vp(pol), vp(pol), vp(val), vp(val), vp(val), vp(pol), 4, 1, 96), _abi.E_UNSUPPORTED)   # no 96-channel tower
+    bad(L.azg_resnet_policy_value_f16(st, 1, vp(pol), vp(pol), vp(val), vp(val), vp(val), 4, 1, vp(pol), vp(val), 588, 3, vp(pol), vp(val)),
+        _abi.E_UNSUPPORTED)                                                   # heads too wide to fuse
+    bad(L.azg_policy_value_heads_f16(st, vp(pol), vp(pol), vp(val), 4, 100, 7, 3, vp(pol), vp(pol), vp(val)))   # k not a multiple of 32
+    bad(L.azg_search_f16(null, st, vp(pol), vp(val), vp(val), vp(val), 1, vp(pol), vp(val), 4))
+    br = engine(game=1, B=4, sims_hint=4)
+    bad(L.azg_search_f16(br.h, st, vp(pol), vp(val), vp(val), vp(val), 1, vp(pol), vp(val), 4), _abi.E_UNSUPPORTED)   # connect4 only
+    cfg = _abi.Config(); cfg.abi_version = _abi.ABI_VERSION + 1; cfg.num_slots = 4
+    out = C.c_void_p()
+    bad(L.azg_engine_create(C.byref(cfg), C.byref(out)))                      # ABI version mismatch
+    cfg.abi_version = _abi.ABI_VERSION; cfg.game = 99
+    bad(L.azg_engine_create(C.byref(cfg), C.byref(out)), _abi.E_UNSUPPORTED)  # unknown game
+    # the engines are still healthy
+    eng.select(None); eng.backup(pol + 1.0 / 7, val + 1.0 / 3)
+    assert eng.counters()['sims'] == 8
+    eng.close(); br.close()
