@@ -589,14 +589,18 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
         if constexpr (IS_SEARCH) {
             using G = typename SEARCH::Game;
             static_assert(G::CELLS == HW && G::A < 8, "search mode needs a game whose tree functions use no LDS scratch");
-            // a sticky device error (tree arena full) stops the trees; the decision must be uniform over the workgroup
-            int *flag = reinterpret_cast<int *>(img + SCRATCH_PV + 512);
-            if (tid == 0) *flag = sa.ev.gcount[GC_ERROR];
-            __syncthreads();
-            const int err = *flag;
-            __syncthreads();
-            if (tid == 0) *flag = 0;
-            if (err) break;
+            // a sticky device error (tree arena full) stops the trees; the decision must be uniform over the workgroup.  Looked at
+            // every 16th simulation only (a global load and two barriers): the tree functions themselves never write past a full
+            // arena, they just stop expanding
+            if ((sim & 15) == 0) {
+                int *flag = reinterpret_cast<int *>(img + SCRATCH_PV + 512);
+                if (tid == 0) *flag = sa.ev.gcount[GC_ERROR];
+                __syncthreads();
+                const int err = *flag;
+                __syncthreads();
+                if (tid == 0) *flag = 0;
+                if (err) break;
+            }
             int slot = tile * BOARDS + wave;
             asm volatile("" : "+v"(slot));                       // (opaque: keeps the slot's tree addresses from being hoisted out of
                                                                  //  the simulation loop and spilled across the tower)

@@ -231,3 +231,20 @@ def test_arena_runner_per_slot_seats():
     assert (runs[0][0] == runs[1][0]).all() and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
     wins, draws, _ = runs[0][2]
     assert sum(wins) + draws == runs[0][1]['games_played'] > 0
+
+
+def test_fused_search_kernel_tree_arena_overflow_is_reported():
+    """a tree arena that is too small: the persistent search launch must stop expanding, finish, and leave the sticky device
+    error for the next counter read -- no out-of-bounds write, no hang."""
+    from alphazero_general_amd import _abi
+    from alphazero_general_amd.engine import DeviceEngine
+    net = _net(4); net.refresh()
+    e = DeviceEngine(0, 37, cpuct=4.0, fpu_reduction=0.4, seed=1, sims_hint=4, nodes_per_tree=48)
+    net._hip.search(e, 60)
+    with pytest.raises(_abi.AzgError) as ei:
+        e.counters()
+    assert ei.value.code == _abi.E_TREE_FULL
+    e.close()
+    e2 = DeviceEngine(0, 37, cpuct=4.0, fpu_reduction=0.4, seed=1, sims_hint=60)      # the device is fine afterwards
+    net._hip.search(e2, 60)
+    assert e2.counters()['sims'] == 37 * 60
