@@ -322,6 +322,7 @@ extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
     GAME_SWITCH(e, {
         hipLaunchKernelGGL((k_play<G>), dim3(e->v.B), dim3(64), 0, s, e->v, record_history);
         hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)nullptr);
+        hipLaunchKernelGGL((k_emit_samples<G>), dim3(e->v.B, G::NSYM), dim3(64), 0, s, e->v);
         hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
     });
     prof_end(e, s, 2, p);
@@ -345,6 +346,7 @@ extern "C" int azg_advance_commit(azg_engine *e, void *stream, const int32_t *co
     HIPCHK(hipMemcpyAsync(e->v.fin_counted, counted_host, sizeof(int32_t) * e->v.B, hipMemcpyHostToDevice, s));
     GAME_SWITCH(e, {
         hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)e->v.fin_counted);
+        hipLaunchKernelGGL((k_emit_samples<G>), dim3(e->v.B, G::NSYM), dim3(64), 0, s, e->v);
         hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
     });
     HIPCHK(hipGetLastError());

@@ -534,7 +534,31 @@ __global__ __launch_bounds__(64) void k_finalize(View ev, const int32_t *counted
     }
 }
 
-// Phase 3 (per finished slot): result record, samples x symmetries (:184-196), reset game + trees (:197-200).
+// Phase 3a (per finished, counted slot and symmetry): the samples of that symmetry (:184-196).  One wavefront per (slot,
+// symmetry) -- a finished brandubh game is 100 positions x 8 symmetries x 3.3 KB, too much for the slot's single wave.
+template <class G>
+__global__ __launch_bounds__(64) void k_emit_samples(View ev) {
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
+    constexpr int A = G::A, NV = G::P + 1;
+    const int slot = blockIdx.x, kk = blockIdx.y, lane = threadIdx.x;
+    const int ws = __builtin_amdgcn_readfirstlane(ev.fin_flag[slot]);
+    if (ws == 0 || !ev.fin_counted[slot] || ev.arena || ev.ex_cap <= 0) return;
+    const int nsym = ev.symmetric ? G::NSYM : 1;
+    if (kk >= nsym) return;
+    const int hl = ev.hist_len[slot], soff = ev.fin_soff[slot];
+    for (int hI = 0; hI < hl; hI++) {
+        const int si = soff + hI * nsym + kk;
+        if (si >= ev.ex_cap) continue;
+        typename G::S hs = G::load(&ev.hist_state[(size_t)slot * ev.max_hist + hI], lane);
+        const float *hp = ev.hist_pi + ((size_t)slot * ev.max_hist + hI) * A;
+        typename G::S ss = G::symmetry(hs, kk);
+        G::template write_obs<float>(ss, ev.ex_obs + (size_t)si * G::OBS, lane);
+        for (int a = lane; a < A; a += 64) ev.ex_pi[(size_t)si * A + G::sym_action(a, kk)] = hp[a];
+        if (lane < NV) ev.ex_z[(size_t)si * NV + lane] = (float)((ws >> lane) & 1);
+    }
+}
+
+// Phase 3b (per finished slot): result record, reset game + trees (:197-200).
 template <class G>
 __global__ __launch_bounds__(64) void k_emit(View ev) {
     if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
@@ -547,23 +571,7 @@ __global__ __launch_bounds__(64) void k_emit(View ev) {
         for (int j = 0; j < NV; j++) ev.res_ws[(size_t)ridx * NV + j] = (uint8_t)((ws >> j) & 1);
         ev.res_turns[ridx] = ev.states[slot].turns; ev.res_slot[ridx] = slot;
     }
-    if (!counted) return;
-    if (!ev.arena && ev.ex_cap > 0) {
-        const int nsym = ev.symmetric ? G::NSYM : 1;
-        const int hl = ev.hist_len[slot], soff = ev.fin_soff[slot];
-        for (int hI = 0; hI < hl; hI++) {
-            typename G::S hs = G::load(&ev.hist_state[(size_t)slot * ev.max_hist + hI], lane);
-            const float *hp = ev.hist_pi + ((size_t)slot * ev.max_hist + hI) * A;
-            for (int kk = 0; kk < nsym; kk++) {
-                const int si = soff + hI * nsym + kk;
-                if (si >= ev.ex_cap) continue;
-                typename G::S ss = G::symmetry(hs, kk);
-                G::template write_obs<float>(ss, ev.ex_obs + (size_t)si * G::OBS, lane);
-                for (int a = lane; a < A; a += 64) ev.ex_pi[(size_t)si * A + G::sym_action(a, kk)] = hp[a];
-                if (lane < NV) ev.ex_z[(size_t)si * NV + lane] = (float)((ws >> lane) & 1);
-            }
-        }
-    }
+    (void)counted;
     typename G::S st; G::init(st);
     G::store(st, &ev.states[slot], lane);
     if (lane == 0) ev.hist_len[slot] = 0;
