@@ -470,9 +470,9 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
                                            floatx4 (&acc)[2][NSUB]) {
     // fragment t = (kk, ps) is read PF fragments ahead into a register ring.  Large tiles index the ring by subtile (slot
     // ps % RING: collision-free with PF = 4 for NSUB = 11 at RING = 6, checked case by case; one slot per subtile otherwise);
-    // small tiles (NSUB <= PF, the low-latency shapes for small batches) by fragment number, RING = PF + 1
-    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = 4;
-    constexpr bool TRING = NSUB <= PF;
+    // small tiles (NSUB <= 4, the low-latency shapes for small batches) by fragment number, RING = PF + 1
+    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = NSUB <= 4 ? 6 : 4;     // (small tiles run one wave per SIMD: nothing else
+    constexpr bool TRING = NSUB <= 4;                                             //  hides the LDS latency; measured 78 -> 72 us at 256 boards)
     constexpr int RING = TRING ? PF + 1 : NSUB == 11 ? 6 : NSUB;
     using FO = FragOff<GEO, KS, NSUB>;
     half8 bb[RING];
