@@ -87,6 +87,7 @@ SYMBOLS = {
     'azg_resnet_policy_value_multi_f16': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'azg_search_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     'azg_policy_value_heads_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'azg_tower_layout': (_i, [_i, _i, _i, _vp, _vp, _vp]),
     'azg_profile_enable': (_i, [_vp, _i]),
     'azg_profile_read': (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_int64)]),
     'azg_tape_u64': (_u64, [_u64, _u64, _u64]),

@@ -716,6 +716,27 @@ extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const voi
     return AZG_OK;
 }
 
+// host-side layout tables of the tower (no device needed): the pixel -> (subtile, lane) map and the padded LDS row of every pixel
+template <int H, int W, int BOARDS, int C>
+static int tower_layout_of(int16_t *map, int32_t *qrow, int32_t *info) {
+    using GEO = TowerGeom<H, W, BOARDS, C>;
+    if (map) tower_pixmap<GEO>(map);
+    if (qrow) for (int p = 0; p < GEO::ROWS; p++) qrow[p] = GEO::qrow(p);
+    info[0] = GEO::NSUB; info[1] = GEO::ROWS; info[2] = GEO::RSTRIDE; info[3] = GEO::TROWS; info[4] = GEO::TILE; info[5] = GEO::PW;
+    info[6] = GEO::LEAD; info[7] = GEO::BSTRIDE;
+    return AZG_OK;
+}
+
+extern "C" int azg_tower_layout(int game, int boards_per_tile, int channels, int16_t *pixmap, int32_t *qrow, int32_t *info8) {
+    if (!info8) return fail(AZG_E_INVALID_ARG, "null argument");
+#define AZG_LAYOUT(GM, BT, CH) if (game == GM::ID && boards_per_tile == BT && channels == CH) return tower_layout_of<GM::H, GM::W, BT, CH>(pixmap, qrow, info8)
+    AZG_LAYOUT(C4, 1, 128); AZG_LAYOUT(C4, 2, 128); AZG_LAYOUT(C4, 4, 128); AZG_LAYOUT(C4, 4, 64);
+    AZG_LAYOUT(BR, 1, 64); AZG_LAYOUT(BR, 2, 64); AZG_LAYOUT(BR, 2, 128);
+    AZG_LAYOUT(TM, 2, 32); AZG_LAYOUT(TM, 5, 32);
+#undef AZG_LAYOUT
+    return fail(AZG_E_UNSUPPORTED, "no tower instantiation for this (game, boards per tile, channels)");
+}
+
 extern "C" int azg_profile_enable(azg_engine *e, int on) {
     if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
     prof_drain(e);

@@ -251,6 +251,11 @@ int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const
 int  azg_policy_value_heads_f16(void *stream, const void *y_dev, const void *head_w_packed_dev, const float *head_b_dev,
                                 int boards, int k, int A, int NV, float *logits_ws_dev, float *policy_dev, float *value_dev);
 
+/* Host-side layout tables of one tower instantiation (no device needed; for tests and tooling): pixmap[NSUB*16] = pixel of
+ * (subtile, lane & 15) or -1, qrow[ROWS] = padded LDS row of pixel p, info8 = {NSUB, ROWS, row stride B, tile rows, tile bytes,
+ * padded width, lead rows, board stride}.  pixmap / qrow may be NULL.  AZG_E_UNSUPPORTED for a shape that is not instantiated. */
+int  azg_tower_layout(int game, int boards_per_tile, int channels, int16_t *pixmap, int32_t *qrow, int32_t *info8);
+
 /* ---- timing hooks for bench.py (HIP events on `stream` around the engine's own kernels) -------------------- */
 int  azg_profile_enable(azg_engine *e, int on);
 /* accumulated GPU ms + launch counts per kernel family: select, backup, advance. blocking. */

@@ -67,3 +67,51 @@ def test_no_cpu_fallback(built):
     h = C.c_void_p()
     assert _abi.lib().azg_engine_create(C.byref(cfg), C.byref(h)) == _abi.E_HIP
     assert b'no CPU fallback' in _abi.lib().azg_last_error()
+
+
+@pytest.mark.parametrize('game,bt,ch,H,W', [(0, 1, 128, 6, 7), (0, 2, 128, 6, 7), (0, 4, 128, 6, 7), (0, 4, 64, 6, 7),
+                                            (1, 1, 64, 7, 7), (1, 2, 64, 7, 7), (1, 2, 128, 7, 7), (2, 2, 32, 5, 5), (2, 5, 32, 5, 5)])
+def test_tower_lds_layout_invariants(game, bt, ch, H, W):
+    """The LDS image of the MFMA tower (csrc/azg_conv.h TowerGeom / tower_pixmap), checked on the host for every instantiated
+    shape: every pixel sits in exactly one (subtile, lane); all nine taps of a pixel are in-bounds rows; pad rows never
+    coincide with pixel rows; and the bank-conflict rule DESIGN.md states -- the 8 lanes {0-3,12-15} and the 8 lanes {4-11} of
+    a fragment read rows of pairwise different residue mod 8 (row stride = 2 (mod 4) 16-byte slots) -- holds wherever the
+    residue classes allow it (at most one doubled residue per 8-lane set)."""
+    import ctypes as C
+    import numpy as np
+    from alphazero_general_amd import _abi
+    L = _abi.lib()
+    info = (C.c_int32 * 8)()
+    assert L.azg_tower_layout(game, bt, ch, None, None, info) == 0
+    nsub, rows, rstride, trows, tile, pw, lead, bstride = list(info)
+    assert rows == bt * H * W and nsub == (rows + 15) // 16 and tile == trows * rstride and tile <= 160 * 1024 // (2 if rows > 64 else 1)
+    assert rstride == 2 * ch + 32 and (rstride // 16) % 4 == 2 and pw == W + 2 and bstride % 8 == 2
+    pm = np.zeros(nsub * 16, np.int16); q = np.zeros(rows, np.int32)
+    assert L.azg_tower_layout(game, bt, ch, pm.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), info) == 0
+    live = pm[pm >= 0]
+    assert sorted(live.tolist()) == list(range(rows))                        # a bijection pixels <-> live lanes
+    assert len(set(q.tolist())) == rows                                      # distinct rows
+    for p in range(rows):                                                    # every tap row is inside the image
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                r = q[p] + dy * pw + dx
+                assert 0 <= r < trows
+    pixel_rows = set(q.tolist())
+    for p in range(rows):                                                    # off-board taps land on pad rows, never on a pixel
+        b, pos = divmod(p, H * W); y, x = divmod(pos, W)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                inside = 0 <= y + dy < H and 0 <= x + dx < W
+                r = q[p] + dy * pw + dx
+                if inside:
+                    assert r == q[b * H * W + (y + dy) * W + (x + dx)]
+                else:
+                    assert r not in pixel_rows
+    setA, setB = (0, 1, 2, 3, 12, 13, 14, 15), (4, 5, 6, 7, 8, 9, 10, 11)
+    doubled = 0
+    for s in range(nsub):
+        for lanes in (setA, setB):
+            res = [q[pm[s * 16 + l]] % 8 for l in lanes if pm[s * 16 + l] >= 0]
+            doubled += len(res) - len(set(res))
+    assert doubled <= nsub                                                   # conflict-free up to the leftovers of unequal classes
+    assert L.azg_tower_layout(game, 3, ch, None, None, info) == _abi.E_UNSUPPORTED
