@@ -146,6 +146,23 @@ WORKLOADS = {
 }
 
 
+# algorithmic bytes one simulation moves through the tree kernels (SURVEY.md 8d formula with 32-B node records):
+# D*(32 + k*32) select reads + (32 + k*32) expansion writes + 2*80 states + fp16 obs + D*4 path ; backup: 4*A + 4*(P+1) + 4*k + D*20 + 32
+TREE_BYTES = {'brandubh': (4 * (32 + 40 * 32) + (32 + 40 * 32) + 160 + 49 * 16 + 16, 4 * 588 + 12 + 160 + 80 + 32),
+              'trimok': (4 * (32 + 20 * 32) + (32 + 20 * 32) + 160 + 25 * 16 + 16, 4 * 25 + 16 + 80 + 80 + 32)}
+
+
+def tree_roofline_other(workload, prof, B):
+    if prof is None or workload not in TREE_BYTES or not prof['select_n']:
+        return None
+    sb, bb = TREE_BYTES[workload]
+    sel_us = prof['select_ms'] * 1e3 / prof['select_n']; bak_us = prof['backup_ms'] * 1e3 / max(prof['backup_n'], 1)
+    g = sb * B / (sel_us * 1e-6) / 1e9
+    return {'kernel': 'k_select<%s>' % {'brandubh': 'BR', 'trimok': 'TM'}[workload], 'bound': 'hbm', 'achieved': round(g, 2), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(g / HBM_PEAK_GBS, 6), 'avg_launch_us': round(sel_us, 2), 'algorithmic_bytes_per_launch': sb * B,
+            'backup_us': round(bak_us, 2), 'backup_GBps': round(bb * B / (bak_us * 1e-6) / 1e9, 2), 'traffic': None}
+
+
 def run_other_workload(a, rank, local_rank, world):
     """configs 3-5: not the headline bench line; same timing protocol, reported with their own config.workload."""
     import importlib
@@ -179,8 +196,15 @@ def run_other_workload(a, rank, local_rank, world):
     c0 = counters()
     D.barrier(); torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(a.steps):
+    prof = None
+    eng = getattr(runner, 'engine', None)
+    for k in range(a.steps):
+        timed = a.workload != 'arena' and eng is not None and k == a.steps // 2      # one eagerly launched round with HIP events
+        if timed:
+            torch.cuda.synchronize(); eng.profile(True)
         runner.play_round()
+        if timed:
+            prof = eng.profile_read(); eng.profile(False)
     c1 = counters()
     torch.cuda.synchronize(); D.barrier()
     dt = D.max_over_ranks(time.time() - t0)
@@ -191,7 +215,8 @@ def run_other_workload(a, rank, local_rank, world):
                           'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net',
                           'data': 'synthetic', 'games_per_sec': round(gm / dt, 2), 'simulations_per_sec': round(sm / dt, 1),
-                          'config': {'workload': '%s, %d games/GPU x %d sims/move, net %s' % (a.workload, B, sims, netargs)}}))
+                          'config': {'workload': '%s, %d games/GPU x %d sims/move, net %s' % (a.workload, B, sims, netargs)},
+                          'tree_roofline': tree_roofline_other(a.workload, prof, B)}))
 
 
 def main():
