@@ -134,7 +134,10 @@ def cpu_baseline(net, seconds=12.0):
     return {'value': round(ag.expansions / t_all, 1), 'unit': 'expansions/s', 'cores': 1, 'kind': 'port', 'many_cores': many,
             'sample': 'connect4 %d games x %d sims, %d simulations in %.1f s on one host core, leaves evaluated by the same GPU net '
                       'through host buffers' % (Bc, SIMS, sims_done, t_all),
-            'tree_only_value': round(ag.expansions / t_tree, 1), 'host_cpus': os.cpu_count()}
+            'tree_only_value': round(ag.expansions / t_tree, 1), 'host_cpus': os.cpu_count(),
+            # BASELINE.md section 3 calibration, measured in the build container (same core for both; the reference cannot travel):
+            'vs_reference_cython': 'tree-only, connect4 256 games x 100 sims, one core: C oracle 201.6 k sims/s, reference Cython '
+                                   'MCTS/SelfPlayAgent 8.2 k sims/s -> the port is 24.6x the reference'}
 
 
 WORKLOADS = {
