@@ -104,6 +104,41 @@ def cpu_baseline_threads(net, threads=16, seconds=6.0):
             'sample': '%d oracle agents x %d games x %d sims on %d host cores for %.1f s, one shared GPU net' % (threads, Bc, SIMS, threads, dt)}
 
 
+def cpu_tree_only_threads(threads=64, seconds=4.0):
+    """Tree-only leg on many host cores (BASELINE.md section 3 variant i): warm-up evaluator semantics -- uniform policy and
+    value (SelfPlayAgent.pyx:48-52,111-114) -- so only select / expand / backup / playMoves run; one oracle agent of 256 games
+    per thread, no shared resource."""
+    import threading
+    import oracle_lib as ol
+    Bc = 256
+    threads = max(1, min(threads, (os.cpu_count() or 1) - 2))
+    agents = [ol.OAgent(0, Bc, sims=SIMS, games_per_iteration=1 << 30, seed=200 + i, cpuct=4.0, fpu_reduction=0.4,
+                        add_root_noise=True, add_root_temp=True) for i in range(threads)]
+    pol = np.full((Bc, 7), 1 / 7, np.float32); val = np.full((Bc, 3), 1 / 3, np.float32)
+    stop = time.time() + seconds
+
+    L = ol.lib()
+
+    def work(ag):
+        obs = np.zeros((Bc, ag.O), np.float32); rg = np.zeros(Bc, np.int32); rm = np.zeros(Bc, np.int32)   # (preallocated: the
+        while time.time() < stop:                                    #  threads only meet at the GIL between C calls)
+            ag.begin_round()
+            for s in range(SIMS):
+                L.azo_agent_generate_batch(ag.h, obs, rg, rm)
+                L.azo_agent_process_batch(ag.h, pol, val)
+            ag.play_moves()
+
+    t0 = time.time()
+    ts = [threading.Thread(target=work, args=(ag,)) for ag in agents]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.time() - t0
+    return {'value': round(sum(ag.expansions for ag in agents) / dt, 1), 'unit': 'expansions/s', 'cores': threads,
+            'sample': '%d oracle agents x %d games x %d sims, uniform evaluator, %.1f s' % (threads, Bc, SIMS, dt)}
+
+
 def cpu_baseline(net, seconds=12.0):
     """The CPU path timed beside the GPU number: the C oracle (bit-exact restatement of the reference Cython path,
     oracle/) drives the same workload on ONE host core, leaves evaluated by the same GPU network through host
@@ -131,7 +166,8 @@ def cpu_baseline(net, seconds=12.0):
         t0 = time.time(); ag.play_moves(); dt = time.time() - t0
         t_tree += dt; t_all += dt
     many = cpu_baseline_threads(net)
-    return {'value': round(ag.expansions / t_all, 1), 'unit': 'expansions/s', 'cores': 1, 'kind': 'port', 'many_cores': many,
+    tree_many = cpu_tree_only_threads()
+    return {'value': round(ag.expansions / t_all, 1), 'unit': 'expansions/s', 'cores': 1, 'kind': 'port', 'many_cores': many, 'tree_only_many_cores': tree_many,
             'sample': 'connect4 %d games x %d sims, %d simulations in %.1f s on one host core, leaves evaluated by the same GPU net '
                       'through host buffers' % (Bc, SIMS, sims_done, t_all),
             'tree_only_value': round(ag.expansions / t_tree, 1), 'host_cpus': os.cpu_count(),
