@@ -840,7 +840,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
 // [k-step][subtile][64 lanes][8 halves]) straight from L2 -- no reuse inside a workgroup, so no LDS staging.  With
 // blockIdx = group * nchunks + chunk and 8 chunks, the workgroups sharing a weight chunk sit on one XCD (blockIdx mod 8).
 // The job is L2->CU bandwidth bound: (HEAD_NS*16 + 16) * K * 2 bytes per workgroup.
-constexpr int HEAD_NS = 5, HEAD_WAVES = 8, HEAD_U = 7;
+constexpr int HEAD_NS = 5, HEAD_WAVES = 8, HEAD_U = 4;   // (batches of 2-4 k-steps measured best; 7 is 2-6 % slower)
 
 __global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
                                                           int ksteps, int osub) {
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, co
 #pragma unroll
     for (int s = 0; s < HEAD_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
     // The waves split K (k-steps wave, wave + 8, ...) and work in batches of HEAD_U k-steps: all 6 * HEAD_U fragment loads of a
-    // batch are issued back to back (the job is L2 latency, not MFMA), branch-free: subtiles past the end re-read the last real
+    // batch are issued back to back (the job is L2 latency and bandwidth, not MFMA), branch-free: subtiles past the end re-read the last real
     // one (their accumulators are never stored), k-steps past the end re-read the last one with the A fragment zeroed.
     size_t soff[HEAD_NS];
 #pragma unroll
