@@ -108,7 +108,24 @@ class SelfPlayAgent(mp.Process):
         env = dict(os.environ, AZG_WORKER_KEY=key.hex(),
                    PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
         self._worker = subprocess.Popen([sys.executable, '-m', 'alphazero_general_amd._engine_worker', listener.address], env=env)
-        self._conn = listener.accept()
+        # accept with a liveness check: a worker that dies before connecting (bad PYTHONPATH, exec failure) must not leave the
+        # agent -- and the Coach polling complete_count -- waiting forever
+        listener._listener._socket.settimeout(1.0)
+        deadline = time.time() + float(os.environ.get('AZG_WORKER_START_TIMEOUT', '300'))
+        while True:
+            try:
+                self._conn = listener.accept()
+                break
+            except (TimeoutError, OSError) as ex:
+                if not isinstance(ex, TimeoutError) and 'timed out' not in str(ex):
+                    raise
+                rc = self._worker.poll()
+                if rc is not None:
+                    listener.close()
+                    raise RuntimeError('device engine worker exited with code %s before connecting' % rc)
+                if time.time() > deadline:
+                    self._worker.kill(); listener.close()
+                    raise RuntimeError('device engine worker did not connect in time')
         listener.close()
         self._conn.send(cfg)
         status, out = self._conn.recv()

@@ -81,7 +81,6 @@ SYMBOLS = {
     'azg_read_results': (_i, [_vp, _vp, _i, _i, C.POINTER(C.c_uint8), _i32p, _i32p]),
     'azg_clear_outputs': (_i, [_vp, _vp]),
     'azg_last_actions_dev': (_i, [_vp, C.POINTER(_vp)]),
-    'azg_conv3x3_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'azg_resnet_tower_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'azg_resnet_policy_value_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'azg_resnet_policy_value_multi_f16': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -59,7 +59,11 @@ def engine_worker(conn, cfg):
                 if new > 0:
                     o, p, z = eng.examples(n_ex, new)
                     out = (o.cpu().numpy(), p.cpu().numpy(), z.cpu().numpy())
-                n_ex = c['num_examples']
+                # everything emitted so far has been handed over: rewind the engine's result / example cursors, so that an agent
+                # can finish any number of games (the reference's queues are unbounded; games_cap is 2^30 here, so zeroing the
+                # games counter with them changes nothing)
+                eng.clear_outputs()
+                n_ex = 0
                 conn.send(('ok', out))
             elif cmd == 'close':
                 conn.send(('ok', None))

@@ -1,25 +1,17 @@
-// azg_conv.h -- fused 3x3 convolution for small boards on gfx950 MFMA (the network's hot op).
+// azg_conv.h -- the policy/value ResNet of alphazero/NNetArchitecture.py:36-120 (eval mode) on gfx950 MFMA.
 //
-// Replaces, for the residual tower of alphazero/NNetArchitecture.py:36-120 in eval mode, the MIOpen implicit-GEMM
-// kernel + 4 separate elementwise launches per layer (bias, ReLU, pre-activation BN affine, residual add) that
-// PyTorch issues (profiles/r01_bench_kernel_stats_baseline.csv: 47 us conv + ~38 us elementwise per layer) with ONE
-// launch per convolution:
+// PyTorch issues, per residual-tower layer, a MIOpen implicit-GEMM kernel + 4 elementwise launches (bias, ReLU, pre-activation
+// BN affine, residual add: profiles/r01_bench_kernel_stats_baseline.csv, 47 + ~38 us per layer).  Here the whole tower -- and,
+// for narrow action spaces, both heads and their softmaxes -- is ONE persistent launch (k_tower2) with the activations
+// resident in LDS; wide heads (brandubh: 588 + 3 outputs) run in k_heads.
 //
-//     y = epilogue( conv3x3( prologue(x) ) )       prologue: optional per-channel affine + ReLU (pre-activation BN)
-//                                                  epilogue: + bias, optional + residual, optional ReLU, fp16 store
-//
-// Formulation: Y^T[cout, pixel] = sum over 9 taps of W_tap[cout, cin] . X^T[cin, pixel + shift(tap)]
-//   * activations are NHWC fp16, flattened to rows = board*H*W + y*W + x, 256 B (128 channels) per row;
-//   * one workgroup (4 waves) owns BOARDS whole boards = ROWS pixel rows, staged ONCE in LDS (43 KB for 4 connect4
-//     boards) and re-read by all 9 taps at a row offset of dy*W+dx; taps that fall off the board read a zero row;
-//   * wave w computes couts [32w, 32w+32) for all rows: MFMA v_mfma_f32_16x16x32_f16 with A = weights (16 couts x
-//     32 cin, loaded straight from L2 in a pre-packed fragment layout: each wave needs only its own cout slice, so
-//     LDS sharing would buy nothing) and B = activations (32 cin x 16 pixels, ds_read_b128 from the LDS tile);
-//     D[cout = 4*(lane/16)+r][pixel = lane%16] puts 4 consecutive channels of one pixel in a lane -> 8-byte stores;
-//   * LDS tile layout: row r, 16-byte chunk c lives at r*256 + ((c + 2r) & 15)*16.  For every read group of
-//     ds_read_b128 (8 lanes on rows R+{0..3,12..15} with chunk c, 8 lanes on rows R+{4..11} with chunk c+1) the 16
-//     slots are distinct for ANY row offset R: conflict-free for all 9 taps (an XOR swizzle is not: odd shifts pair up).
-// grid = boards / BOARDS workgroups (512 for 2048 connect4 boards: two resident per CU, one per SIMD pair).
+// Formulation of a convolution: Y^T[cout, pixel] = sum over 9 taps of W_tap[cout, cin] . X^T[cin, pixel + shift(tap)]
+//   * a workgroup owns BOARDS whole boards; its conv input lives in an LDS image (see TowerGeom) that all 9 taps read at
+//     constant offsets; taps that fall off the board hit zero padding;
+//   * wave w computes couts [32w, 32w+32) for all pixels: v_mfma_f32_16x16x32_f16 with A = weights (16 couts x 32 cin,
+//     streamed from L2 in a pre-packed fragment order: each wave needs only its own cout slice, so LDS sharing would buy
+//     nothing) and B = activations (32 cin x 16 pixels, one ds_read_b128 per lane);
+//     D[cout = 4*(lane/16)+r][pixel = lane%16] puts 4 consecutive channels of one pixel in a lane.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,138 +22,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-struct ConvParams {
-    const void *x;          // KS==4: [rows, 128] fp16 ; stem (KS==1): [rows, 8] fp16 (NHWC, channels padded to 8)
-    const void *w;          // packed fragments [9][KS][8][64] x 16 B
-    const float *bias;      // [128]
-    const float *pre_scale; // [128] or null      prologue affine (pre-activation BatchNorm, eval mode)
-    const float *pre_shift; // [128]
-    const void *residual;   // [rows, 128] fp16 or null
-    void *y;                // [rows, 128] fp16
-    int boards;
-};
-
-template <int H, int W, int BOARDS, int KS, bool PRE, bool RES, bool RELU>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvParams P) {
-    constexpr int HW = H * W, ROWS = BOARDS * HW, NSUB = (ROWS + 15) / 16, ZERO_BASE = ROWS * 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
-    const int row0 = blockIdx.x * ROWS;
-    const int rows_here = min(ROWS, P.boards * HW - row0);
-
-    // ---- stage the activation tile in LDS (with the optional pre-activation affine + ReLU) ----
-    if constexpr (KS == 4) {
-        const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0 * 16;
-        const int chunk = tid & 15;
-        float sc[8], sh[8];
-        if constexpr (PRE) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) { sc[j] = P.pre_scale[chunk * 8 + j]; sh[j] = P.pre_shift[chunk * 8 + j]; }
-        }
-        for (int c = tid; c < ROWS * 16; c += 256) {
-            const int row = c >> 4;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < rows_here) v = xg[c];
-            if constexpr (PRE) {
-                half8 h = *reinterpret_cast<half8 *>(&v);
-#pragma unroll
-                for (int j = 0; j < 8; j++) { float f = (float)h[j] * sc[j] + sh[j]; h[j] = (_Float16)(f > 0.f ? f : 0.f); }
-                v = *reinterpret_cast<uint4 *>(&h);
-            }
-            *reinterpret_cast<uint4 *>(smem + row * 256 + ((chunk + 2 * row) & 15) * 16) = v;
-        }
-    } else {
-        const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
-        for (int c = tid; c < ROWS * 4; c += 256) {            // chunks 0..3 of every row: channels 0..31, only 0..7 live
-            const int row = c >> 2, chunk = c & 3;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (chunk == 0 && row < rows_here) v = xg[row];
-            *reinterpret_cast<uint4 *>(smem + row * 256 + ((chunk + 2 * row) & 15) * 16) = v;
-        }
-    }
-    if (tid < 16) *reinterpret_cast<uint4 *>(smem + ZERO_BASE + tid * 16) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-
-    // ---- per-lane pixel coordinates of each 16-row subtile ----
-    int py[NSUB], px[NSUB];
-#pragma unroll
-    for (int ps = 0; ps < NSUB; ps++) {
-        const int p = ps * 16 + i16;
-        const int pos = p % HW;
-        py[ps] = p < ROWS ? pos / W : -100;                     // rows past the tile never pass the bounds test
-        px[ps] = pos % W;
-    }
-
-    floatx4 acc[2][NSUB];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = (floatx4){0.f, 0.f, 0.f, 0.f};
-
-    const half8 *wfrag = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;   // + (tap*KS+ks)*8*64
-    half8 a_cur[2], a_nxt[2];
-    a_cur[0] = wfrag[0]; a_cur[1] = wfrag[64];
-
-#pragma unroll 1
-    for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1, shift = dy * W + dx;
-        int base[NSUB], swz[NSUB];
-#pragma unroll
-        for (int ps = 0; ps < NSUB; ps++) {
-            const int yy = py[ps] + dy, xx = px[ps] + dx;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const int src = ps * 16 + i16 + shift;
-            base[ps] = ok ? src * 256 : ZERO_BASE;
-            swz[ps] = 2 * src + g;
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const int kk = tap * KS + ks;
-            const int kn = kk + 1 < 9 * KS ? kk + 1 : kk;       // prefetch the next weight fragments (L2)
-            a_nxt[0] = wfrag[(size_t)kn * 512]; a_nxt[1] = wfrag[(size_t)kn * 512 + 64];
-#pragma unroll
-            for (int ps = 0; ps < NSUB; ps++) {
-                const half8 b = *reinterpret_cast<const half8 *>(smem + base[ps] + ((swz[ps] + ks * 4) & 15) * 16);
-                acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[0], b, acc[0][ps], 0, 0, 0);
-                acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[1], b, acc[1][ps], 0, 0, 0);
-            }
-            a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
-        }
-    }
-
-    // ---- epilogue: + bias (+ residual) (ReLU) -> fp16, 4 consecutive channels per lane ----
-    _Float16 *yg = reinterpret_cast<_Float16 *>(P.y);
-    const _Float16 *rg = reinterpret_cast<const _Float16 *>(P.residual);
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const int c0 = (2 * wave + m) * 16 + g * 4;
-        const float b0 = P.bias[c0], b1 = P.bias[c0 + 1], b2 = P.bias[c0 + 2], b3 = P.bias[c0 + 3];
-#pragma unroll
-        for (int ps = 0; ps < NSUB; ps++) {
-            const int p = ps * 16 + i16;
-            if (p < rows_here) {
-                const size_t o = (size_t)(row0 + p) * 128 + c0;
-                float v0 = acc[m][ps][0] + b0, v1 = acc[m][ps][1] + b1, v2 = acc[m][ps][2] + b2, v3 = acc[m][ps][3] + b3;
-                if constexpr (RES) {
-                    const half4 r = *reinterpret_cast<const half4 *>(rg + o);
-                    v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
-                }
-                if constexpr (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                half4 out = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                *reinterpret_cast<half4 *>(yg + o) = out;
-            }
-        }
-    }
-}
-
-
 // ================================================================================================ fused tower
-// The whole residual tower in ONE persistent launch: a workgroup keeps the residual stream s of its BOARDS boards in
-// LDS (buf0) for all 1 + 2*nblocks convolutions and ping-pongs the conv input through buf1
-// (t = relu(bn(s)) -> u = relu(conv1(t)+b) -> s' = conv2(u) + s), so activations never touch HBM between the input
-// planes and the final stream: the only per-layer traffic is the weight fragments, shared by all CUs out of L2.
-// 4 waves per workgroup, ONE workgroup per CU (2 x 42 KB tiles), one wave per SIMD with 22 independent accumulators
-// and double-buffered B fragments; grid = min(#tiles, #CUs), each workgroup loops over its tiles.
+// t = relu(bn(s)) -> u = relu(conv1(t)+b) -> s' = conv2(u) + s for every block, activations never leaving the CU between the
+// input planes and the final stream: the only per-layer traffic is the weight fragments, shared by all CUs out of L2.
 struct TowerParams {
     const void *x;            // [boards*H*W, 8] fp16 (NHWC, channels padded to 8) -- the engine's obs_dtype 2
     const void *w;            // packed fragments: stem [9][1][8][64] then per block conv1, conv2 [9][4][8][64], 16 B each
@@ -232,219 +95,6 @@ static void tower_pixmap(int16_t *map /*[NSUB*16]*/) {
 }
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-
-template <class GEO, int KS, int NSUB, int RB>
-__device__ __forceinline__ void conv_main(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[4][2],
-                                          floatx4 (&acc)[2][NSUB]) {
-    constexpr int NSTEP = 9 * KS;
-    half8 bb[2][NSUB];
-#pragma unroll
-    for (int ps = 0; ps < NSUB; ps++)                                        // k-step 0: tap (-1,-1), ks 0
-        bb[0][ps] = *reinterpret_cast<const half8 *>(in + lb[ps] + (GEO::BIAS + (-GEO::PW - 1) * GEO::RSTRIDE));
-#pragma unroll
-    for (int kk = 0; kk < NSTEP; kk++) {
-        const int cur = kk & 1, an = (RB + kk + 3) & 3, ac = (RB + kk) & 3;
-        // weights three k-steps ahead (running straight on into the next layer's fragments), B fragments one ahead
-        a[an][0] = wfrag[(size_t)(kk + 3) * 512]; a[an][1] = wfrag[(size_t)(kk + 3) * 512 + 64];
-        if (kk + 1 < NSTEP) {
-            const int tap = (kk + 1) / KS, ks = (kk + 1) % KS;
-            const int off = GEO::BIAS + ((tap / 3 - 1) * GEO::PW + (tap % 3 - 1)) * GEO::RSTRIDE + ks * 64;
-#pragma unroll
-            for (int ps = 0; ps < NSUB; ps++) bb[cur ^ 1][ps] = *reinterpret_cast<const half8 *>(in + lb[ps] + off);
-        }
-#pragma unroll
-        for (int ps = 0; ps < NSUB; ps++) {
-            acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur][ps], acc[0][ps], 0, 0, 0);
-            acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur][ps], acc[1][ps], 0, 0, 0);
-        }
-        // pin the interleave [2 MFMA | 1 ds_read] x NSUB with the two weight loads up front: left alone hipcc sinks each
-        // ds_read next to its consumer and waits lgkmcnt(0) before every MFMA pair (one wave per SIMD: nothing hides it)
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-#pragma unroll
-        for (int ps = 0; ps < NSUB; ps++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int H, int W, int BOARDS>
-__global__ __launch_bounds__(256, 1) void k_tower(TowerParams P, const int16_t *pixmap) {
-    using GEO = TowerGeom<H, W, BOARDS>;
-    constexpr int HW = GEO::HW, ROWS = GEO::ROWS, NSUB = GEO::NSUB, TILE = GEO::TILE, RS = GEO::RSTRIDE;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *buf0 = smem, *buf1 = smem + TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
-    const int ntiles = (P.boards + BOARDS - 1) / BOARDS;
-    for (int c = tid; c < 2 * TILE / 16; c += 256) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
-    unsigned lb[NSUB], eb[NSUB];                        // fragment-read base / epilogue base of this lane's pixel per subtile
-    bool live[NSUB];
-#pragma unroll
-    for (int ps = 0; ps < NSUB; ps++) {
-        const int p = pixmap[ps * 16 + i16];
-        live[ps] = p >= 0;
-        const int q = p >= 0 ? GEO::qrow(p) : GEO::LEAD;                     // spare lanes read (and discard) pad rows
-        lb[ps] = (unsigned)(TILE + q * RS + g * 16 - GEO::BIAS);             // absolute LDS offset inside buf1 (the conv input)
-        eb[ps] = (unsigned)(q * RS) + (unsigned)(((g & 1) ? (2 * wave + 1) * 16 + (g - 1) * 4 : (2 * wave) * 16 + g * 4) * 2);
-    }
-    const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * wave) * 64 + lane;
-    half8 a[4][2];
-    floatx4 acc[2][NSUB];
-    half2v sreg[NSUB][4];                               // the residual stream of this lane's cells (fp16, 8 channels x NSUB)
-    const int ecol = (g & 1) ? (2 * wave + 1) * 16 + (g - 1) * 4 : (2 * wave) * 16 + g * 4;   // first channel this lane owns in the epilogue
-    __syncthreads();
-
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row0 = tile * ROWS;
-        const int rows_here = min(ROWS, P.boards * HW - row0);
-        // ---- input planes -> buf1: channels 0..7 live, 8..31 zero (the stem reads 32 channels) ----
-        {
-            const uint4 *xg = reinterpret_cast<const uint4 *>(P.x) + (size_t)row0;
-            for (int c = tid; c < ROWS * 4; c += 256) {
-                const int p = c >> 2, chunk = c & 3;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (chunk == 0 && p < rows_here) v = xg[p];
-                *reinterpret_cast<uint4 *>(buf1 + GEO::qrow(p) * RS + chunk * 16) = v;
-            }
-        }
-        const half8 *wt = wl;
-#pragma unroll
-        for (int i = 0; i < 3; i++) { a[i][0] = wt[(size_t)i * 512]; a[i][1] = wt[(size_t)i * 512 + 64]; }
-        __syncthreads();
-#ifdef AZG_TOWER_TIMING
-#define AZG_STAMP(i) do { if (P.dbg && blockIdx.x == 0 && tile == 0 && lane == 0) P.dbg[(layer * 4 + wave) * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define AZG_STAMP(i) do { } while (0)
-#endif
-        for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
-            AZG_STAMP(0);
-            const float *bias = P.bias + (size_t)layer * 128;
-            // layer 0 (stem) and even layers (conv2) produce the residual stream s (kept in REGISTERS: each lane owns the
-            // same (pixel, 4-channel) cells in every layer) and t = relu(affine(s)) -> LDS; odd layers (conv1): u -> LDS
-            const bool is_s = (layer & 1) == 0;
-            const int nb = layer >> 1;
-            const bool has_next = nb < P.nblocks;
-            const half2v zero2 = {(_Float16)0.f, (_Float16)0.f};
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const int c0 = (2 * wave + m) * 16 + g * 4;
-                const floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};      // accumulators start at the bias
-#pragma unroll
-                for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
-            }
-            // Epilogue layout: after a v_permlane16_swap of the two cout-subtiles, a lane with even g holds 8 consecutive
-            // channels of subtile 2w, a lane with odd g 8 consecutive channels of subtile 2w+1 (ecol = first channel), i.e.
-            // ONE 16-byte LDS access per pixel instead of two 8-byte ones (half the LDS instructions, half the conflicts).
-            half2v sc[4], sh[4];                                // next block's pre-activation affine, fetched under the main loop
-#pragma unroll
-            for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
-            if (is_s && has_next) {
-                const float *ps_ = P.pre_scale + (size_t)nb * 128 + ecol, *pt_ = P.pre_shift + (size_t)nb * 128 + ecol;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
-                    sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
-                }
-            }
-            if (layer == 0) { conv_main<GEO, 1, NSUB, 0>(smem, lb, wt, a, acc); wt += (size_t)9 * 512; }
-            else { conv_main<GEO, 4, NSUB, 1>(smem, lb, wt, a, acc); wt += (size_t)36 * 512; }
-            AZG_STAMP(1);
-            __syncthreads();                                    // every wave is done reading buf1
-            AZG_STAMP(2);
-            const bool last = layer == 2 * P.nblocks;
-#pragma unroll
-            for (int ps = 0; ps < NSUB; ps++) {
-                half2v v[4];
-                {
-                    union { half2v h; unsigned u; } a0, a1, b0, b1;
-                    a0.h = (half2v){(_Float16)acc[0][ps][0], (_Float16)acc[0][ps][1]}; a1.h = (half2v){(_Float16)acc[0][ps][2], (_Float16)acc[0][ps][3]};
-                    b0.h = (half2v){(_Float16)acc[1][ps][0], (_Float16)acc[1][ps][1]}; b1.h = (half2v){(_Float16)acc[1][ps][2], (_Float16)acc[1][ps][3]};
-                    auto r0 = __builtin_amdgcn_permlane16_swap(a0.u, b0.u, false, false);   // odd rows of subtile-0 regs <-> even rows of subtile-1 regs
-                    auto r1 = __builtin_amdgcn_permlane16_swap(a1.u, b1.u, false, false);
-                    a0.u = r0[0]; b0.u = r0[1]; a1.u = r1[0]; b1.u = r1[1];
-                    v[0] = a0.h; v[1] = a1.h; v[2] = b0.h; v[3] = b1.h;
-                }
-                const unsigned off = eb[ps];
-                if (!is_s) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] = __builtin_elementwise_max(v[j], zero2);
-                    if (live[ps]) *reinterpret_cast<uint4 *>(buf1 + off) = *reinterpret_cast<uint4 *>(v);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (layer == 0) v[j] = __builtin_elementwise_max(v[j], zero2); else v[j] += sreg[ps][j];
-                        sreg[ps][j] = v[j];
-                    }
-                    if (live[ps]) {
-                        if (last) *reinterpret_cast<uint4 *>(buf0 + off) = *reinterpret_cast<uint4 *>(v);
-                        if (has_next) {
-                            half2v t[4];
-#pragma unroll
-                            for (int j = 0; j < 4; j++) t[j] = __builtin_elementwise_max(v[j] * sc[j] + sh[j], zero2);
-                            *reinterpret_cast<uint4 *>(buf1 + off) = *reinterpret_cast<uint4 *>(t);
-                        }
-                    }
-                }
-            }
-            AZG_STAMP(3);
-            __syncthreads();
-            AZG_STAMP(4);
-        }
-        if (P.head_w == nullptr) {
-            // ---- final residual stream -> HBM (dense rows) ----
-            uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * 16;
-            for (int c = tid; c < rows_here * 16; c += 256) {
-                const int p = c >> 4, chunk = c & 15;
-                yg[c] = *reinterpret_cast<const uint4 *>(buf0 + GEO::qrow(p) * RS + chunk * 16);
-            }
-        } else {
-            // ---- fused heads: the 1x1 convs + BN + flatten + Linear chains of both heads are one linear map of the
-            // final stream (NNetArchitecture.py:88-102,112-118): logits^T[out, board] = sum_k Wfull^T[out, k] s[board, k],
-            // k = (pixel, channel); one MFMA per (pixel, 32-channel step), pixels dealt round-robin to the 4 waves
-            floatx4 hacc = {0.f, 0.f, 0.f, 0.f};
-            const bool bvalid = i16 < BOARDS;
-            const unsigned bbase = (unsigned)((GEO::LEAD + (bvalid ? i16 : 0) * GEO::BSTRIDE) * RS + g * 16);
-            const half8 *hw = reinterpret_cast<const half8 *>(P.head_w) + lane;
-            for (int p = wave; p < HW; p += 4) {
-                const int y = p / W, x = p - y * W;
-                const unsigned poff = (unsigned)(((y + 1) * GEO::PW + x) * RS);
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const half8 af = hw[(size_t)(p * 4 + ks) * 64];
-                    half8 bf = *reinterpret_cast<const half8 *>(buf0 + bbase + poff + ks * 64);
-                    if (!bvalid) bf = (half8){0, 0, 0, 0, 0, 0, 0, 0};
-                    hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, hacc, 0, 0, 0);
-                }
-            }
-            float *red = reinterpret_cast<float *>(buf1);       // [4 waves][16 outs][16 boards]
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 4; r++) red[(wave * 16 + g * 4 + r) * 16 + i16] = hacc[r];
-            __syncthreads();
-            const int nb_here = min(BOARDS, P.boards - tile * BOARDS);
-            if (tid < nb_here) {
-                float lg[16];
-#pragma unroll
-                for (int o = 0; o < 16; o++) lg[o] = red[(0 * 16 + o) * 16 + tid] + red[(1 * 16 + o) * 16 + tid] + red[(2 * 16 + o) * 16 + tid]
-                                                    + red[(3 * 16 + o) * 16 + tid] + P.head_b[o];
-                const int A = P.A, NV = P.NV;
-                float m = lg[0]; for (int o = 1; o < A; o++) m = fmaxf(m, lg[o]);
-                float sum = 0.f; for (int o = 0; o < A; o++) { lg[o] = __expf(lg[o] - m); sum += lg[o]; }
-                float *po = P.policy + (size_t)(tile * BOARDS + tid) * A;
-                for (int o = 0; o < A; o++) po[o] = lg[o] / sum;
-                m = lg[A]; for (int o = 1; o < NV; o++) m = fmaxf(m, lg[A + o]);
-                sum = 0.f; for (int o = 0; o < NV; o++) { lg[A + o] = __expf(lg[A + o] - m); sum += lg[A + o]; }
-                float *vo = P.value + (size_t)(tile * BOARDS + tid) * NV;
-                for (int o = 0; o < NV; o++) vo[o] = lg[A + o] / sum;
-            }
-            __syncthreads();
-            reinterpret_cast<uint4 *>(buf1)[tid] = make_uint4(0, 0, 0, 0);     // the scratch overlapped pad rows: restore the zeros
-        }
-        __syncthreads();
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------ k_tower2
 // Two workgroups per CU.  With the residual stream in registers only ONE LDS image is needed (t / u / final s take

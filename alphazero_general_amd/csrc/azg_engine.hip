@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "azg_kernels.h"
@@ -525,65 +526,33 @@ extern "C" int azg_last_actions_dev(azg_engine *e, int32_t **actions) {
     return AZG_OK;
 }
 
-template <int H, int W, int BOARDS>
-static int launch_conv(hipStream_t s, const ConvParams &P, int stem, int relu) {
-    constexpr int ROWS = BOARDS * H * W;
-    const size_t lds = (size_t)ROWS * 256 + 256;
-    const dim3 grid((P.boards + BOARDS - 1) / BOARDS), block(256);
-    const bool pre = P.pre_scale != nullptr, res = P.residual != nullptr;
-#define AZG_CONV(KS, PRE, RES, RELU) hipLaunchKernelGGL((k_conv3x3<H, W, BOARDS, KS, PRE, RES, RELU>), grid, block, lds, s, P)
-    if (stem) { if (relu) AZG_CONV(1, false, false, true); else AZG_CONV(1, false, false, false); }
-    else if (pre && res && relu) AZG_CONV(4, true, true, true);
-    else if (pre && res) AZG_CONV(4, true, true, false);
-    else if (pre && relu) AZG_CONV(4, true, false, true);
-    else if (pre) AZG_CONV(4, true, false, false);
-    else if (res && relu) AZG_CONV(4, false, true, true);
-    else if (res) AZG_CONV(4, false, true, false);
-    else if (relu) AZG_CONV(4, false, false, true);
-    else AZG_CONV(4, false, false, false);
-#undef AZG_CONV
-    HIPCHK(hipGetLastError());
-    return AZG_OK;
-}
-
-extern "C" int azg_conv3x3_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
-                               const float *pre_shift, const void *residual, void *y, int boards, int stem, int relu) {
-    if (!x || !w || !bias || !y || boards <= 0) return fail(AZG_E_INVALID_ARG, "null argument");
-    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return fail(AZG_E_INVALID_ARG, "pre_scale and pre_shift go together");
-    ConvParams P{x, w, bias, pre_scale, pre_shift, residual, y, boards};
-    switch (game) {
-    case AZG_GAME_CONNECT4: return launch_conv<C4::H, C4::W, 4>((hipStream_t)stream, P, stem, relu);
-    default: return fail(AZG_E_UNSUPPORTED, "no conv geometry for this game");
-    }
-}
-
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
 static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}, bool init_only = false) {
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     using GEO = TowerGeom<H, W, BOARDS, C>;
-    static int16_t *d_map[16] = {nullptr};                                  // per device: pixel -> (subtile, lane) table
+    // per (instantiation, device): the pixel -> (subtile, lane) table, a few hundred bytes that live as long as the process
+    // (the table is a pure function of the template arguments); first use is serialised
+    static int16_t *d_map[16] = {nullptr};
+    static std::mutex d_map_mu;
     int dev = 0, cus = 256;
     HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return fail(AZG_E_INVALID_ARG, "device ordinal out of range");
-    if (!d_map[dev]) {
-        int16_t map[GEO::NSUB * 16];
-        tower_pixmap<GEO>(map);
-        HIPCHK(hipMalloc((void **)&d_map[dev], sizeof(map)));
-        HIPCHK(hipMemcpy(d_map[dev], map, sizeof(map), hipMemcpyHostToDevice));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
-        if constexpr (C == 128)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<H, W, BOARDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)GEO::TILE));
+    {
+        std::lock_guard<std::mutex> lk(d_map_mu);
+        if (!d_map[dev]) {
+            int16_t map[GEO::NSUB * 16];
+            tower_pixmap<GEO>(map);
+            int16_t *d = nullptr;
+            HIPCHK(hipMalloc((void **)&d, sizeof(map)));
+            HIPCHK(hipMemcpy(d, map, sizeof(map), hipMemcpyHostToDevice));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
+            d_map[dev] = d;
+        }
     }
     if (init_only) return AZG_OK;                            // (first-use allocations must not happen inside a stream capture)
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS + (P.rows_per_model ? P.nmodels - 1 : 0);
-    static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
-    if (C == 128 && variant == 1 && !IS_SEARCH) {            // one workgroup per CU, two LDS images, deep prefetch
-        if constexpr (C == 128) {
-            const int grid = ntiles < cus ? ntiles : cus;
-            hipLaunchKernelGGL((k_tower<H, W, BOARDS>), dim3(grid), dim3(256), (size_t)2 * GEO::TILE, s, P, (const int16_t *)d_map[dev]);
-        }
-    } else {                                                 // one LDS image, residual stream in registers, >= 2 workgroups per CU
+    {                                                        // one LDS image, residual stream in registers, >= 2 workgroups per CU
         const int per_cu = (int)(160 * 1024 / GEO::TILE) > 0 ? (int)(160 * 1024 / GEO::TILE) : 1;
         // (search mode: every tile is its own workgroup for the whole launch -- they never synchronise, later ones just start later)
         const int grid = IS_SEARCH || ntiles < per_cu * cus ? ntiles : per_cu * cus;
@@ -680,8 +649,6 @@ extern "C" int azg_resnet_policy_value_multi_f16(void *stream, int game, const v
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     for (int m = 0; m < nmodels; m++)
         if (!w[m] || !bias[m] || !head_w[m] || !head_b[m] || (nblocks > 0 && (!pre_scale[m] || !pre_shift[m]))) return fail(AZG_E_INVALID_ARG, "null model parameter");
-    static const int variant = getenv("AZG_TOWER_VARIANT") ? atoi(getenv("AZG_TOWER_VARIANT")) : 2;
-    if (variant == 1) return fail(AZG_E_UNSUPPORTED, "multi-model launches need the default tower kernel (AZG_TOWER_VARIANT unset)");
     // the grid is sized for max_boards rows plus one partial tile per extra model
     TowerParams P{x, w[0], bias[0], nblocks ? pre_scale[0] : nullptr, nblocks ? pre_shift[0] : nullptr, nullptr, max_boards, nblocks,
                   head_w[0], head_b[0], policy, value, A, NV, nullptr, rows_per_model, nmodels, {}};

@@ -459,6 +459,10 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
     __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
     const int slot = blockIdx.x, lane = threadIdx.x;
     typename G::S st = G::load(&ev.states[slot], lane);
+    if (G::win_bits(st) != 0) {                                              // a finished game that was not counted (:179-183 else
+        if (lane == 0) ev.fin_flag[slot] = 0;                                // branch) keeps its final state and idles: the reference's
+        return;                                                              // agent loop has ended by then (SelfPlayAgent.pyx:79-80)
+    }
     const int tree = ev.arena ? slot * ev.T + st.player : slot;
     const Node *nodes = ev.nodes + (size_t)tree * ev.cap;
     const int root = __builtin_amdgcn_readfirstlane(ev.hdr[tree].root);
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(64) void k_emit(View ev) {
         for (int j = 0; j < NV; j++) ev.res_ws[(size_t)ridx * NV + j] = (uint8_t)((ws >> j) & 1);
         ev.res_turns[ridx] = ev.states[slot].turns; ev.res_slot[ridx] = slot;
     }
-    (void)counted;
+    if (!counted) return;                                                    // :197-200 sit inside the counted branch
     typename G::S st; G::init(st);
     G::store(st, &ev.states[slot], lane);
     if (lane == 0) ev.hist_len[slot] = 0;

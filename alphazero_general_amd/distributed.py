@@ -35,8 +35,11 @@ def init_from_env(backend=None):
 
 
 def shard_games(total_games, rank, world):
-    """Per-rank game quota: ceil(total / world) for every rank (quotas instead of a global atomic)."""
-    return (int(total_games) + world - 1) // world
+    """Per-rank game quota (quotas instead of a global atomic): floor(total / world), the remainder going to the
+    lowest ranks, so that the quotas sum to exactly `total_games` -- the reference counts exactly gamesPerIteration games
+    (SelfPlayAgent.pyx:179-183)."""
+    total_games, world = int(total_games), int(world)
+    return total_games // world + (1 if rank < total_games % world else 0)
 
 
 def slot_base(rank, slots_per_rank):

@@ -144,10 +144,11 @@ def pack_conv_weight(w, ks):
     return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1).to(torch.float16)
 
 
-def _reference_pickle():
-    """A pickle module whose Unpickler resolves the reference's own classes without the reference installed: alphazero.utils.dotdict
-    -> utils.dotdict; anything else that cannot be imported (optimizer / scheduler classes of other torch versions, ...) -> a
-    placeholder, since only 'state_dict' and the architecture keys of 'args' are used."""
+def _reference_pickle(trusted=False):
+    """A pickle module for checkpoints the REFERENCE wrote: alphazero.utils.dotdict -> utils.dotdict.  By default only an
+    allow-list of globals is resolved (tensor rebuild functions, storages, OrderedDict, dotdict); every other global becomes an
+    inert placeholder -- only 'state_dict' and the architecture keys of 'args' are used -- so loading a foreign file cannot run
+    code.  trusted=True resolves every importable global like the reference's own torch.load (NNetWrapper.py:259)."""
     import pickle
     import types
 
@@ -155,13 +156,33 @@ def _reference_pickle():
         def __init__(self, *a, **k):
             pass
 
+        def __call__(self, *a, **k):
+            return self
+
         def __setstate__(self, state):
             pass
 
+    def allowed(module, name):
+        if module == 'collections' and name == 'OrderedDict':
+            return True
+        if module == 'torch._utils' and name.startswith('_rebuild_'):
+            return True
+        if module == 'torch' and (name.endswith('Storage') or name in ('Size', 'device', 'dtype')):
+            return True
+        if module in ('torch.serialization',) and name == '_get_layout':
+            return True
+        if module == 'numpy.core.multiarray' or module == 'numpy._core.multiarray':
+            return name in ('scalar', '_reconstruct')
+        if module == 'numpy' and name in ('dtype', 'ndarray'):
+            return True
+        return False
+
     class Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
-            if module.startswith('alphazero.') and name == 'dotdict':
+            if module.startswith('alphazero') and name == 'dotdict':
                 return dotdict
+            if not trusted and not allowed(module, name):
+                return _Missing
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError):
@@ -176,11 +197,11 @@ def _reference_pickle():
 
 
 class HipResNet:
-    """The eval-mode network with its residual tower on the hand-written gfx950 MFMA convolution
-    (azg_conv3x3_f16: one launch per conv with the bias / ReLU / pre-activation affine / residual add fused) and the
-    two heads -- 1x1 conv + BN + flatten + Linear chain, all linear in the reference (NNetArchitecture.py:88-102,
-    112-118) -- collapsed into ONE [H*W*128, A + P+1] GEMM followed by the two softmaxes.
-    Activations are NHWC fp16 rows [B*H*W, 128]; the input is the engine's obs_dtype 2 format [B, H*W, 8]."""
+    """The eval-mode network on the hand-written gfx950 MFMA kernels of csrc/azg_conv.h: the residual tower is one persistent
+    launch (azg_resnet_tower_f16) and the two heads -- 1x1 conv + BN + flatten + Linear chain, all linear in the reference
+    (NNetArchitecture.py:88-102,112-118) -- are collapsed into ONE [H*W*C, A + P+1] GEMM followed by the two softmaxes: fused
+    behind the tower in the same launch when A + P+1 <= 16 at 128 channels (azg_resnet_policy_value_f16), else in the wide-head
+    kernel (azg_policy_value_heads_f16).  The input is the engine's obs_dtype 2 format [B, H*W, 8] fp16."""
 
     def __init__(self, folded: FoldedResNet, game_id, device):
         from . import _abi
@@ -209,7 +230,6 @@ class HipResNet:
             nb = len(self.blocks)
             self.tower_ps = torch.stack([b['ps'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, CH), **f32)
             self.tower_pt = torch.stack([b['pt'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, CH), **f32)
-            self.fused = True
             # heads: logits[b, o] = sum_{pos,k} s[b,pos,k] * Wfull[pos*128+k, o] + bfull[o]
             hw, hb = folded.head_w.float().reshape(-1, CH), folded.head_b.float()            # [vc+pc, CH], [vc+pc]
             vc = folded.vc
@@ -219,7 +239,6 @@ class HipResNet:
             fv = torch.einsum('ocp,ck->pko', Wv.reshape(NV, vc, HW), hw[:vc])                 # [HW, 128, NV]
             fp = torch.einsum('ocp,ck->pko', Wp.reshape(A, -1, HW), hw[vc:])                  # [HW, 128, A]
             self.A, self.NV = A, NV
-            self.head_w = torch.cat([fp, fv], dim=2).reshape(HW * CH, A + NV).to(self.device, torch.float16).contiguous()
             bfv = bv + torch.einsum('ocp,c->o', Wv.reshape(NV, vc, HW), hb[:vc])
             bfp = bp + torch.einsum('ocp,c->o', Wp.reshape(A, -1, HW), hb[vc:])
             self.head_b = torch.cat([bfp, bfv]).to(**f32).contiguous()
@@ -232,89 +251,78 @@ class HipResNet:
                                        .to(self.device, torch.float16).contiguous()
                 self.head_b16 = torch.zeros(16, **f32)
                 self.head_b16[:A + NV] = self.head_b
-            else:                                                # own launch (azg_policy_value_heads_f16): [k/32][OS][64 lanes][8]
-                OS, KS = (A + NV + 15) // 16, HW * CH // 32
-                wf = torch.zeros((HW * CH, OS * 16), dtype=torch.float32, device=fp.device)
-                wf[:, :A + NV] = torch.cat([fp, fv], dim=2).reshape(HW * CH, A + NV)
-                # [k = ks*32 + g*8 + j, out = sub*16 + i] -> [ks][sub][g][i][j]
-                self.head_w_wide = wf.reshape(KS, 4, 8, OS, 16).permute(0, 3, 1, 4, 2).contiguous().reshape(-1) \
-                                     .to(self.device, torch.float16).contiguous()
-                self.head_b_wide = torch.zeros(OS * 16, **f32)
-                self.head_b_wide[:A + NV] = self.head_b
-                self.head_opad = OS * 16
-            self.wide_head = not self.fused_head
+            # the wide-head kernel's layout (azg_policy_value_heads_f16): [k/32][OS][64 lanes][8]
+            OS, KS = (A + NV + 15) // 16, HW * CH // 32
+            wf = torch.zeros((HW * CH, OS * 16), dtype=torch.float32, device=fp.device)
+            wf[:, :A + NV] = torch.cat([fp, fv], dim=2).reshape(HW * CH, A + NV)
+            # [k = ks*32 + g*8 + j, out = sub*16 + i] -> [ks][sub][g][i][j]
+            self.head_w_wide = wf.reshape(KS, 4, 8, OS, 16).permute(0, 3, 1, 4, 2).contiguous().reshape(-1) \
+                                 .to(self.device, torch.float16).contiguous()
+            self.head_b_wide = torch.zeros(OS * 16, **f32)
+            self.head_b_wide[:A + NV] = self.head_b
+            self.head_opad = OS * 16
         self._bufs = {}
 
-    def _buffers(self, B, key=0):
-        if (B, key) not in self._bufs:
-            mk = lambda: torch.empty((B * self.HW, self.CH), dtype=torch.float16, device=self.device)
-            self._bufs[(B, key)] = (mk(), mk(), mk())
-        return self._bufs[(B, key)]
+    @property
+    def wide_head(self):
+        """heads in their own launch (the wide-head kernel) instead of fused behind the tower."""
+        return not self.fused_head
 
-    def _conv(self, x, w, b, y, boards, *, pre=None, res=None, stem=False, relu=True):
-        import ctypes as C
-        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        self._check(self.L.azg_conv3x3_f16(st, self.game, vp(x), vp(w), vp(b), vp(pre[0] if pre else None),
-                                           vp(pre[1] if pre else None), vp(res), vp(y), int(boards), int(stem), int(relu)))
+    def _scratch(self, kind, key, B, make):
+        """Scratch tensors of a (kind, key) user, allocated once at the largest row count seen and handed out as views [:B]:
+        a caller whose batch size changes every call (the arena's host-split path) keeps ONE set instead of one per size.
+        A captured graph uses a fixed B under its own key, so its addresses never move."""
+        ent = self._bufs.get((kind, key))
+        if ent is None or ent[0] < B:
+            ent = (B, make(B))
+            self._bufs[(kind, key)] = ent
+        return ent[1]
+
+    def _buffers(self, B, key=0):
+        mk = lambda n: (torch.empty((n * self.HW, self.CH), dtype=torch.float16, device=self.device),)
+        return self._scratch('act', key, B, mk)[0][:B * self.HW]
 
     def forward_logits_nhwc8(self, x, key=0):
         """Wide-head networks only: x [B, H*W, 8] fp16 -> logits [B, OS*16] float32 (A policy logits, then P+1 value logits per
         row), for DeviceEngine.backup_logits / backup_select_logits, which run the softmaxes inside the tree launch."""
-        assert self.fused and self.wide_head
+        assert self.wide_head
         return self.forward_nhwc8(x, key, logits_only=True)
 
     def forward_nhwc8(self, x, key=0, logits_only=False):
         """x: [B, H*W, 8] fp16 -> (policy [B, A], value [B, P+1]) float32 probabilities.  `key` selects a private set
         of activation buffers (one per captured graph, so that graphs on different streams never share scratch)."""
         B = x.shape[0]
-        s, u, t = self._buffers(B, key)
-        if self.fused and self.fused_head:                       # tower + heads + softmax in ONE launch
+        if self.fused_head and not logits_only:                  # tower + heads + softmax in ONE launch
             import ctypes as C
             vp = lambda q: C.c_void_p(q.data_ptr())
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if ('pv', B, key) not in self._bufs:
-                self._bufs[('pv', B, key)] = (torch.empty((B, self.A), dtype=torch.float32, device=self.device),
-                                              torch.empty((B, self.NV), dtype=torch.float32, device=self.device))
-            pol, val = self._bufs[('pv', B, key)]
+            pol, val = [t[:B] for t in self._scratch('pv', key, B, lambda n: (
+                torch.empty((n, self.A), dtype=torch.float32, device=self.device),
+                torch.empty((n, self.NV), dtype=torch.float32, device=self.device)))]
             self._check(self.L.azg_resnet_policy_value_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
                                                            vp(self.tower_pt), int(B), len(self.blocks), vp(self.head_w_packed),
                                                            vp(self.head_b16), int(self.A), int(self.NV), vp(pol), vp(val)))
             return pol, val
-        if self.fused:                                           # one persistent launch, activations resident in LDS
-            import ctypes as C
-            vp = lambda q: C.c_void_p(q.data_ptr())
-            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self._check(self.L.azg_resnet_tower_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
-                                                    vp(self.tower_pt), vp(s), int(B), len(self.blocks), int(self.CH)))
-        else:                                                    # one launch per convolution
-            self._conv(x, self.stem_w, self.stem_b, s, B, stem=True, relu=True)
-            for blk in self.blocks:
-                self._conv(s, blk['w1'], blk['b1'], u, B, pre=(blk['ps'], blk['pt']), relu=True)
-                self._conv(u, blk['w2'], self.zero_b, t, B, res=s, relu=False)
-                s, t = t, s
-        if self.wide_head:                                       # heads GEMM + both softmaxes: two launches
-            import ctypes as C
-            vp = lambda q: C.c_void_p(q.data_ptr())
-            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if ('pvw', B, key) not in self._bufs:
-                mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=self.device)
-                self._bufs[('pvw', B, key)] = (mk(self.A), mk(self.NV), mk(self.head_opad))
-            pol, val, ws = self._bufs[('pvw', B, key)]
-            null = C.c_void_p(0)
-            self._check(self.L.azg_policy_value_heads_f16(st, vp(s), vp(self.head_w_wide), vp(self.head_b_wide), int(B), self.HW * self.CH,
-                                                          int(self.A), int(self.NV), vp(ws), null if logits_only else vp(pol),
-                                                          null if logits_only else vp(val)))
-            return ws if logits_only else (pol, val)
-        assert not logits_only
-        logits = torch.matmul(s.view(B, self.HW * self.CH), self.head_w).float() + self.head_b
-        return F.softmax(logits[:, :self.A], dim=1), F.softmax(logits[:, self.A:], dim=1)
+        s = self._buffers(B, key)
+        import ctypes as C                                       # tower: one persistent launch, activations resident in LDS
+        vp = lambda q: C.c_void_p(q.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.L.azg_resnet_tower_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
+                                                vp(self.tower_pt), vp(s), int(B), len(self.blocks), int(self.CH)))
+        # heads GEMM + both softmaxes: two launches (or one, stopping at the logits)
+        pol, val, ws = [t[:B] for t in self._scratch('pvw', key, B, lambda n: tuple(
+            torch.empty((n, w), dtype=torch.float32, device=self.device) for w in (self.A, self.NV, self.head_opad)))]
+        null = C.c_void_p(0)
+        self._check(self.L.azg_policy_value_heads_f16(st, vp(s), vp(self.head_w_wide), vp(self.head_b_wide), int(B), self.HW * self.CH,
+                                                      int(self.A), int(self.NV), vp(ws), null if logits_only else vp(pol),
+                                                      null if logits_only else vp(val)))
+        return ws if logits_only else (pol, val)
 
     def search(self, engine, sims):
         """`sims` whole simulations (select -> this network -> backup) on every slot of `engine` in one persistent launch
         (azg_search_f16): the trees, the leaf batch and the probabilities never leave the GPU's LDS/HBM and nothing is
         launched per simulation.  connect4 self-play with the fused 128-channel tower + heads only."""
-        if not (self.fused and self.fused_head):
+        if not self.fused_head:
             raise NotImplementedError('the fused search kernel needs the fused tower + heads (128 channels, A + NV <= 16)')
         import ctypes as C
         vp = lambda q: C.c_void_p(q.data_ptr())
@@ -330,7 +338,7 @@ class HipResNet:
         import ctypes as C
         n0 = nets[0]
         for n in nets:
-            if not (n.fused and n.fused_head):
+            if not n.fused_head:
                 raise NotImplementedError('multi-model launches need the fused tower + heads kernel (128 channels, A + NV <= 16)')
             assert (n.game, n.CH, len(n.blocks), n.A, n.NV) == (n0.game, n0.CH, len(n0.blocks), n0.A, n0.NV)
         arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -455,7 +463,7 @@ class NNetWrapper:
         with torch.cuda.graph(g), torch.no_grad():
             p, v = run()
         cn = CapturedNet(g, x, p, v, run)
-        if self._hip is not None and self._hip.fused and self._hip.wide_head:
+        if self._hip is not None and self._hip.wide_head:
             cn.run_logits = lambda: self._hip.forward_logits_nhwc8(x, key)   # stops at the logits (softmax inside the tree launch)
         return cn
 
@@ -476,16 +484,21 @@ class NNetWrapper:
         torch.save({'state_dict': self.nnet.state_dict(), 'args': self.args}, os.path.join(folder, filename),
                    pickle_protocol=pickle.HIGHEST_PROTOCOL)
 
-    def load_checkpoint(self, folder='checkpoint', filename='checkpoint.pth.tar', use_saved_args=True):
+    def load_checkpoint(self, folder='checkpoint', filename='checkpoint.pth.tar', use_saved_args=True, trusted=False):
         """NNetWrapper.load_checkpoint (NNetWrapper.py:252-276), also for files the REFERENCE wrote: their pickles name
         alphazero.utils.dotdict (mapped to this package's dotdict when the reference is not importable); opt_state / sch_state
         are ignored.  With use_saved_args the network is rebuilt from the saved architecture keys first.  Returns the saved
-        args (or None)."""
+        args (or None).  The file is read with torch's weights_only loader when it can be, else with an allow-list unpickler
+        (unknown globals become placeholders); trusted=True unpickles everything, like the reference does."""
         import os
         path = os.path.join(folder, filename)
         if not os.path.exists(path):
             raise FileNotFoundError('No model in path {}'.format(path))
-        ck = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_reference_pickle())
+        try:
+            with torch.serialization.safe_globals([dotdict]):
+                ck = torch.load(path, map_location='cpu', weights_only=True)
+        except Exception:
+            ck = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_reference_pickle(trusted))
         saved = ck.get('args')
         if use_saved_args and saved is not None:
             arch = {k: saved[k] for k in DEFAULT_NET_ARGS if k in saved}

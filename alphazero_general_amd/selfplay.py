@@ -55,14 +55,19 @@ class SelfPlayRunner:
         # whole-round graphs need a capturable evaluation: the captured net's launch sequence, or warm-up's constants
         self.round_graph = (self.use_graph or (self.warmup and bool(use_graph))) if round_graph is None else bool(round_graph)
         self.lanes = []
+        from .distributed import shard_games
+        total_games = int(args.get('gamesPerIteration', 1 << 30))
         for li in range(self.pipelines):
+            # the games cap is split into per-lane quotas that sum to exactly gamesPerIteration (a lane that has filled its
+            # quota idles its finished slots, like the reference's agents once games_played reaches the cap)
+            quota = total_games if total_games >= (1 << 30) else shard_games(total_games, li, self.pipelines)
             eng = DeviceEngine(
                 self.game, Bl, cpuct=args.get('cpuct', 1.25), fpu_reduction=args.get('fpu_reduction', 0.2),
                 root_noise_frac=args.get('root_noise_frac', 0.1), root_policy_temp=args.get('root_policy_temp', 1.1),
                 min_discount=args.get('min_discount', 1.0), add_root_noise=args.get('add_root_noise', True),
                 add_root_temp=args.get('add_root_temp', True), symmetric_samples=args.get('symmetricSamples', True),
                 mcts_reset_threshold=args.get('mctsResetThreshold', 0) or 0,
-                games_per_iteration=int(args.get('gamesPerIteration', 1 << 30)), start_temp=args.get('startTemp', 1.0),
+                games_per_iteration=quota, start_temp=args.get('startTemp', 1.0),
                 arena_temp=args.get('arenaTemp', 0.25), temp_fn=args.get('temp_scaling_fn', default_temp_scaling),
                 seed=seed, slot_base=self.slot_base + li * Bl, device=device,
                 example_capacity=example_capacity // self.pipelines + 1, result_capacity=int(result_capacity) // self.pipelines + 1,
@@ -86,7 +91,7 @@ class SelfPlayRunner:
         # connect4 + fused 128-channel tower: the whole simulation loop of a move can be ONE persistent launch (azg_search_f16)
         hip = getattr(nnet, '_hip', None) if nnet is not None else None
         self.fused_search = (fused_search is None or bool(fused_search)) and self.round_graph and not self.warmup and self.game == 0 \
-            and hip is not None and hip.fused and hip.fused_head and hip.CH == 128
+            and hip is not None and hip.fused_head and hip.CH == 128
 
     @property
     def obs(self):
@@ -310,7 +315,7 @@ class ArenaRunner:
         self.policy = torch.zeros((self.B, e.A), dtype=torch.float32, device=e.device)
         self.value = torch.zeros((self.B, e.NV), dtype=torch.float32, device=e.device)
         # fused tower + heads on every model: the per-model batch split never leaves the device
-        self.device_split = bool(hip) and all(n._hip.fused and n._hip.fused_head for n in self.nnets)
+        self.device_split = bool(hip) and all(n._hip.fused_head for n in self.nnets)
         self._graph = None
         if self.device_split and use_graph:
             self.capture()

@@ -258,6 +258,17 @@ def run_other_workload(a, rank, local_rank, world):
                           'tree_roofline': tree_roofline_other(a.workload, prof, B)}))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL), same
+    arguments; rank 0 of the child job prints the JSON line.  Returns the job's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -272,9 +283,14 @@ def main():
                     help='2 launches per simulation (tower, backup+select) instead of one persistent launch per move (azg_search_f16)')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(a.gpus)                                    # one rank per GPU under torch.distributed.run
     rank, local_rank, world = D.init_from_env()
-    assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    assert world == a.gpus, '--gpus %d but %d rank(s) were launched (torch.distributed.run --nproc-per-node must equal --gpus)' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (there is no CPU fallback)'
+    if not os.environ.get('AZG_SINGLE_DEVICE'):
+        assert torch.cuda.device_count() >= world, '%d ranks but only %d visible GPU(s)' % (world, torch.cuda.device_count())
+    a.gpus = world                                                    # n_gpus in the output = the ranks actually initialised
     torch.cuda.set_device(local_rank)
     if a.workload != 'connect4':
         return run_other_workload(a, rank, local_rank, world)
@@ -399,6 +415,7 @@ def main():
 
 if __name__ == '__main__':
     try:
-        main()
+        rc = main()
     finally:
         D.shutdown()
+    sys.exit(rc or 0)

@@ -124,7 +124,7 @@ int  azg_get_tape_counters(azg_engine *e, void *stream, int first, int count, ui
 /* SelfPlayAgent.generateBatch (:103-135) = MCTS.find_leaf (:208-228) on every slot + leaf observation
  * (GameState.observation) written as row `row_of_slot[slot]` (NULL: row = slot) of the dense NN input
  * obs_dev[rows, C, H, W]; obs_dtype 0 = float32, 1 = float16 (both NCHW like the
- * reference), 2 = float16 NHWC with channels padded to 8: obs_dev[rows, H*W, 8], the input format of azg_conv3x3_f16. */
+ * reference), 2 = float16 NHWC with channels padded to 8: obs_dev[rows, H*W, 8], the input format of azg_resnet_tower_f16. */
 int  azg_select(azg_engine *e, void *stream, void *obs_dev, int obs_dtype, const int32_t *row_of_slot_dev);
 /* arena helper (:117-132): rows grouped by model index = player_to_index[mover]; writes row_of_slot_dev[B] and
  * rows_per_model_dev[P] (device), to be called before azg_select */
@@ -194,15 +194,10 @@ int  azg_clear_outputs(azg_engine *e, void *stream);      /* new iteration: game
 /* per-slot action chosen by the last azg_advance (device [B]) */
 int  azg_last_actions_dev(azg_engine *e, int32_t **actions_dev);
 
-/* ---- network hot op: fused 3x3 convolution on MFMA (csrc/azg_conv.h) ----------------------------------------
- * One residual-tower convolution of alphazero/NNetArchitecture.py:36-120 (eval mode, BatchNorm folded) per call:
- *   y = [relu]( conv3x3( [relu(x * pre_scale + pre_shift)] ) + bias [+ residual] ),  128 output channels, fp16 NHWC.
- * x: [boards*H*W, 128] fp16 rows (stem = 0) or [boards*H*W, 8] fp16 rows (stem = 1, the engine's obs_dtype 2);
- * w_packed: MFMA fragment order [9 taps][KS][8][64 lanes][8 halves] (KS = 4, stem: 1), see nnet.pack_conv_weight;
- * bias/pre_scale/pre_shift: f32 [128] (pre_* may be NULL); residual: like y or NULL.  Board geometry from `game`. */
-int  azg_conv3x3_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
-                     const float *pre_scale_dev, const float *pre_shift_dev, const void *residual_dev, void *y_dev,
-                     int boards, int stem, int relu);
+/* ---- network hot op: the policy/value ResNet on MFMA (csrc/azg_conv.h) --------------------------------------
+ * alphazero/NNetArchitecture.py:36-120 in eval mode, BatchNorm folded.  Activations are fp16 NHWC rows; x: [boards*H*W, 8]
+ * fp16 rows (the engine's obs_dtype 2); w_packed: MFMA fragment order [9 taps][KS][C/16][64 lanes][8 halves] per convolution
+ * (KS = C/32, stem: 1), see nnet.pack_conv_weight; bias / pre_scale / pre_shift: f32 [C].  Board geometry from `game`. */
 
 /* The whole residual tower (stem + 2*nblocks convolutions) in ONE persistent launch with activations resident in
  * LDS (csrc/azg_conv.h k_tower2), `channels` = 64 or 128 wide (C below).  x: [boards*H*W, 8] fp16; w_packed: stem fragments

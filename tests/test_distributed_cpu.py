@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
     r, lr, w = D.init_from_env(backend='gloo')
     assert (r, w) == (rank, world)
     B = 6
-    games = D.shard_games(9, rank, world) + rank            # unequal quotas -> unequal shard lengths
+    games = D.shard_games(9, rank, world) + 2 * rank        # unequal quotas (5, 6) -> unequal shard lengths
     ag = _play(B, D.slot_base(rank, B), 5, games)
     obs, pi, z = [torch.from_numpy(x) for x in ag.samples()]
     gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
@@ -90,3 +90,13 @@ def test_sharding_invariance_oracle():
             big.process_batch(pol, val); small.process_batch(pol[6:].copy(), val[6:].copy())
         big.play_moves(); small.play_moves()
         assert (big.last_actions()[6:] == small.last_actions()).all()
+
+
+def test_game_quotas_sum_exactly():
+    """per-rank / per-lane quotas sum to exactly gamesPerIteration (the reference counts exactly that many games,
+    SelfPlayAgent.pyx:179-183), differ by at most one, and the remainder goes to the lowest ranks."""
+    from alphazero_general_amd import distributed as D
+    for total in (0, 1, 7, 8, 9, 100, 4096, 4099):
+        for world in (1, 2, 3, 4, 8):
+            q = [D.shard_games(total, r, world) for r in range(world)]
+            assert sum(q) == total and max(q) - min(q) <= 1 and q == sorted(q, reverse=True)

@@ -80,3 +80,27 @@ def test_load_checkpoint_written_by_the_reference(tmp_path):
     assert torch.equal(p, p2) and torch.equal(v, v2)
     with pytest.raises(FileNotFoundError):
         w2.load_checkpoint(str(tmp_path), 'missing.pth.tar')
+
+
+def test_load_checkpoint_does_not_execute_foreign_globals(tmp_path):
+    """A checkpoint whose pickle names an arbitrary callable (here os.system via __reduce__) must not run it: the default loader
+    resolves only an allow-list of globals and turns everything else into inert placeholders; the weights still load."""
+    import pickle
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import NNetWrapper, DEFAULT_NET_ARGS
+    marker = tmp_path / 'pwned'
+
+    class Evil:
+        def __reduce__(self):
+            import os as _os
+            return (_os.system, ('touch %s' % marker,))
+
+    w = NNetWrapper(Game, device='cpu', backend='torch')
+    torch.save({'state_dict': w.nnet.state_dict(), 'args': dict(DEFAULT_NET_ARGS), 'opt_state': Evil()},
+               str(tmp_path / 'evil.pth.tar'), pickle_protocol=pickle.HIGHEST_PROTOCOL)
+    w2 = NNetWrapper(Game, device='cpu', backend='torch')
+    w2.load_checkpoint(str(tmp_path), 'evil.pth.tar')
+    assert not marker.exists()
+    for k, v in w.nnet.state_dict().items():
+        assert torch.equal(v, w2.nnet.state_dict()[k])
