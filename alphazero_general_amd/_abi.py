@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libazg_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 GAME_CONNECT4, GAME_BRANDUBH, GAME_TRIMOK = 0, 1, 2
 E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_TREE_FULL, E_EXAMPLES_FULL, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
@@ -33,7 +33,7 @@ class Config(C.Structure):
                 ('add_root_noise', C.c_int32), ('add_root_temp', C.c_int32), ('symmetric_samples', C.c_int32),
                 ('mcts_reset_threshold', C.c_int32), ('games_per_iteration', C.c_int32),
                 ('start_temp', C.c_float), ('arena_temp', C.c_float), ('temp_table_len', C.c_int32),
-                ('temp_table', C.POINTER(C.c_float)), ('tape_seed', C.c_uint64), ('slot_base', C.c_uint64)]
+                ('sims_per_move', C.c_int32), ('temp_table', C.POINTER(C.c_float)), ('tape_seed', C.c_uint64), ('slot_base', C.c_uint64)]
 
 
 class Counters(C.Structure):

@@ -4,7 +4,7 @@
 //   Node      32-byte record, one per tree node; the k children of a node are k consecutive records in list order
 //             (the reference's shuffled Node._children, alphazero/MCTS.pyx:76-79), so one wavefront reads a whole
 //             child block with two coalesced dwordx4 loads per lane.
-//   TreeHdr   per tree: root index, arena cursor, leaf of the last find_leaf, depth bookkeeping.
+//   TreeHdr   per tree, one 64-byte line: the root node itself, arena cursor, leaf record of the last find_leaf.
 // Arithmetic follows the C that Cython generates from MCTS.pyx; this file must be compiled with
 // -ffp-contract=off (no FMA contraction) -- bit-exact visit counts depend on it.
 #pragma once
@@ -33,15 +33,27 @@ struct __attribute__((aligned(32))) Node {
 };
 static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 
-struct __attribute__((aligned(32))) TreeHdr {
-    int32_t root;          // MCTS._root
-    int32_t alloc;         // arena cursor (next free node index)
-    int32_t cur;           // MCTS._curnode after find_leaf
-    int32_t depth;         // MCTS.depth
-    int32_t max_depth;     // MCTS.max_depth
-    int32_t expanded;      // last find_leaf took the n == 0 branch
-    int32_t pad[2];
+// Per tree, 64 bytes = one cache line that every kernel reads with ONE load: the ROOT node itself (MCTS._root lives here, not in
+// the node store: update_root copies the chosen child in), the arena cursor, and the record of the last find_leaf, so that
+// process_results needs no dependent load to learn what the leaf was.
+struct __attribute__((aligned(64))) TreeHdr {
+    Node     root;         // MCTS._root
+    int32_t  base;         // offset of the live semi-space inside this tree's node store: 0 or cap (see k_compact)
+    int32_t  alloc;        // arena cursor (next free node index in the live space)
+    int32_t  depth;        // MCTS.depth
+    int32_t  max_depth;    // MCTS.max_depth
+    int32_t  leaf;         // MCTS._curnode after find_leaf: node index, LEAF_IS_ROOT = the root
+    int32_t  leaf_fc;      // its child block
+    uint32_t leaf_info;    // nchild | e << 16 | player << 24
+    int32_t  expanded;     // last find_leaf took the n == 0 branch
 };
+static_assert(sizeof(TreeHdr) == 64, "TreeHdr must be one 64-byte line");
+enum { LEAF_IS_ROOT = -1 };
+
+// One level of the last find_leaf path, 16 bytes: the chosen node, who moved into it, and a snapshot of its (n, q) taken when
+// best_child had the child block in registers -- nothing else touches a tree between find_leaf and process_results, so the
+// backup is pure stores.
+struct __attribute__((aligned(16))) PathEnt { uint32_t idx_mover; int32_t n; float q; uint32_t pad; };
 
 struct SumPlan {           // numpy float32 pairwise-sum structure for a length-n array (see np_sum_wave)
     int32_t n, nleaves, nprog, pad;
@@ -51,9 +63,9 @@ struct SumPlan {           // numpy float32 pairwise-sum structure for a length-
 
 // Engine view passed by value to every kernel.
 struct View {
-    Node     *nodes;       // [trees][cap]
+    Node     *nodes;       // [trees][2][cap]: two semi-spaces per tree, hdr.base selects the live one
     TreeHdr  *hdr;         // [trees]
-    uint32_t *path;        // [trees][maxd]  (node index | mover << 28) for X_1..X_depth
+    PathEnt  *path;        // [trees][maxd]  X_1..X_depth of the last find_leaf
     azg_state *states;     // [B] root states
     azg_state *leaf_states;// [B]
     uint64_t *tape_ctr;    // [B]
@@ -71,7 +83,7 @@ struct View {
     float    *ex_obs, *ex_pi, *ex_z;  // examples
     uint8_t  *res_ws; int32_t *res_turns, *res_slot;
     const float *temp_table; const SumPlan *plan;
-    int32_t B, T, cap, maxd, arena, ex_cap, res_cap, temp_len;
+    int32_t B, T, cap, maxd, arena, ex_cap, res_cap, temp_len, compact_reserve;
     int32_t add_noise, add_temp, symmetric, reset_thr, games_cap, max_hist;
     float cpuct, fpu_reduction, noise_frac, root_temp, arena_temp;
     uint64_t seed, slot_base;

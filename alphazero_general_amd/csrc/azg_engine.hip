@@ -128,8 +128,15 @@ extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
     View &v = e->v;
     memset(&v, 0, sizeof(v));
     v.B = cfg->num_slots; v.arena = cfg->arena ? 1 : 0; v.T = v.arena ? gi.num_players : 1;
-    v.cap = cfg->nodes_per_tree > 0 ? cfg->nodes_per_tree : gi.max_turns * 100 * gi.max_children + 64;
-    if (v.cap >= (1 << 28)) { delete e; return fail(AZG_E_INVALID_ARG, "nodes_per_tree must be < 2^28"); }
+    // node store: two semi-spaces of `cap` nodes per tree (k_compact).  A move adds at most sims_per_move * max_children nodes to
+    // the live space; the default capacity holds four such moves, and the space is compacted after a move once fewer than one
+    // move's worth of free nodes is left
+    const int sims = cfg->sims_per_move > 0 ? cfg->sims_per_move : 100;
+    const long long per_move = (long long)sims * gi.max_children;
+    const long long cap = cfg->nodes_per_tree > 0 ? cfg->nodes_per_tree : 4 * per_move + 64;
+    if (cap >= (1 << 28)) { delete e; return fail(AZG_E_INVALID_ARG, "nodes_per_tree must be < 2^28"); }
+    v.cap = (int)cap;
+    v.compact_reserve = (int)(per_move < cap / 2 ? per_move : cap / 2);
     v.maxd = gi.max_turns + 2; v.max_hist = gi.max_turns + 1;
     v.ex_cap = cfg->example_capacity; v.res_cap = cfg->result_capacity > 0 ? cfg->result_capacity : 4 * v.B + 1024;
     v.add_noise = (cfg->add_root_noise && !v.arena) ? 1 : 0; v.add_temp = (cfg->add_root_temp && !v.arena) ? 1 : 0;
@@ -139,7 +146,7 @@ extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
     v.seed = cfg->tape_seed; v.slot_base = cfg->slot_base;
     const size_t trees = (size_t)v.B * v.T;
     const int A = gi.action_size, NV = gi.num_players + 1, O = gi.obs_c * gi.obs_h * gi.obs_w;
-    DALLOC(v.nodes, trees * (size_t)v.cap);
+    DALLOC(v.nodes, trees * 2 * (size_t)v.cap);
     DALLOC(v.hdr, trees);
     DALLOC(v.path, trees * (size_t)v.maxd);
     DALLOC(v.states, v.B); DALLOC(v.leaf_states, v.B);
@@ -325,6 +332,7 @@ extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
         hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)nullptr);
         hipLaunchKernelGGL((k_emit_samples<G>), dim3(e->v.B, G::NSYM), dim3(64), 0, s, e->v);
         hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
+        hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0);
     });
     prof_end(e, s, 2, p);
     HIPCHK(hipGetLastError());
@@ -349,6 +357,7 @@ extern "C" int azg_advance_commit(azg_engine *e, void *stream, const int32_t *co
         hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)e->v.fin_counted);
         hipLaunchKernelGGL((k_emit_samples<G>), dim3(e->v.B, G::NSYM), dim3(64), 0, s, e->v);
         hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
+        hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0);
     });
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -380,6 +389,7 @@ extern "C" int azg_update_root(azg_engine *e, void *stream, int slot, int action
     int r = check_range(e, slot, 1); if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     GAME_SWITCH(e, hipLaunchKernelGGL((k_update_root<G>), dim3(1), dim3(64), 0, s, e->v, slot, action, e->d_ok));
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0));
     int32_t ok = 0;
     HIPCHK(hipMemcpyAsync(&ok, e->d_ok, sizeof(ok), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -389,16 +399,22 @@ extern "C" int azg_update_root(azg_engine *e, void *stream, int slot, int action
 
 static int tree_of(azg_engine *e, int slot, int tree) { return slot * e->v.T + tree; }
 
+// node `node` of a tree (AZG_NODE_ROOT = the root, which lives in the header) and the base of the tree's live semi-space
+static int fetch_node(azg_engine *e, int t, int node, TreeHdr &h, Node &nd, Node *&base) {
+    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
+    base = e->v.nodes + (size_t)t * 2 * e->v.cap + h.base;
+    if (node < 0) { nd = h.root; return AZG_OK; }
+    if (node >= h.alloc) return fail(AZG_E_INVALID_ARG, "node index out of range");
+    HIPCHK(hipMemcpy(&nd, base + node, sizeof(Node), hipMemcpyDeviceToHost));
+    return AZG_OK;
+}
+
 extern "C" int azg_root_children(azg_engine *e, void *stream, int slot, int tree, int max_k, int32_t *a, int32_t *n, float *q, float *p, float *vv) {
     int r = check_range(e, slot, 1); if (r) return r;
     if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
-    hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipStreamSynchronize(s));
-    const int t = tree_of(e, slot, tree);
-    TreeHdr h; Node root;
-    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
-    Node *base = e->v.nodes + (size_t)t * e->v.cap;
-    HIPCHK(hipMemcpy(&root, base + h.root, sizeof(Node), hipMemcpyDeviceToHost));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    TreeHdr h; Node root; Node *base;
+    r = fetch_node(e, tree_of(e, slot, tree), -1, h, root, base); if (r) return r;
     int k = root.nchild;
     if (k > max_k) return fail(AZG_E_INVALID_ARG, "max_k too small");
     if (k == 0) return 0;
@@ -412,13 +428,8 @@ extern "C" int azg_node_children(azg_engine *e, void *stream, int slot, int tree
     int r = check_range(e, slot, 1); if (r) return r;
     if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    const int t = tree_of(e, slot, tree);
-    TreeHdr h; Node nd;
-    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
-    if (node < 0) node = h.root;
-    if (node >= h.alloc) return fail(AZG_E_INVALID_ARG, "node index out of range");
-    Node *base = e->v.nodes + (size_t)t * e->v.cap;
-    HIPCHK(hipMemcpy(&nd, base + node, sizeof(Node), hipMemcpyDeviceToHost));
+    TreeHdr h; Node nd; Node *base;
+    r = fetch_node(e, tree_of(e, slot, tree), node, h, nd, base); if (r) return r;
     int k = nd.nchild;
     if (k > max_k) return fail(AZG_E_INVALID_ARG, "max_k too small");
     if (k == 0) return 0;
@@ -439,10 +450,9 @@ extern "C" int azg_tree_info(azg_engine *e, void *stream, int slot, int tree, in
     int r = check_range(e, slot, 1); if (r) return r;
     if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    const int t = tree_of(e, slot, tree);
-    TreeHdr h; Node root;
-    HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&root, e->v.nodes + (size_t)t * e->v.cap + h.root, sizeof(Node), hipMemcpyDeviceToHost));
+    TreeHdr h;
+    HIPCHK(hipMemcpy(&h, e->v.hdr + tree_of(e, slot, tree), sizeof(h), hipMemcpyDeviceToHost));
+    const Node &root = h.root;
     out8[0] = root.n; memcpy(&out8[1], &root.q, 4); memcpy(&out8[2], &root.v, 4);
     out8[3] = root.player; out8[4] = root.e; out8[5] = h.depth; out8[6] = h.max_depth; out8[7] = h.alloc;
     return AZG_OK;
@@ -456,11 +466,12 @@ extern "C" int azg_last_path(azg_engine *e, void *stream, int slot, int tree, in
     TreeHdr h;
     HIPCHK(hipMemcpy(&h, e->v.hdr + t, sizeof(h), hipMemcpyDeviceToHost));
     if (h.depth > max_len) return fail(AZG_E_INVALID_ARG, "max_len too small");
-    std::vector<uint32_t> path((size_t)(h.depth > 0 ? h.depth : 1));
-    if (h.depth > 0) HIPCHK(hipMemcpy(path.data(), e->v.path + (size_t)t * e->v.maxd, sizeof(uint32_t) * h.depth, hipMemcpyDeviceToHost));
+    std::vector<PathEnt> path((size_t)(h.depth > 0 ? h.depth : 1));
+    if (h.depth > 0) HIPCHK(hipMemcpy(path.data(), e->v.path + (size_t)t * e->v.maxd, sizeof(PathEnt) * h.depth, hipMemcpyDeviceToHost));
+    const Node *base = e->v.nodes + (size_t)t * 2 * e->v.cap + h.base;
     for (int d = 0; d < h.depth; d++) {
         Node nd;
-        HIPCHK(hipMemcpy(&nd, e->v.nodes + (size_t)t * e->v.cap + (path[d] & 0x0FFFFFFFu), sizeof(Node), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&nd, base + (path[d].idx_mover & 0x0FFFFFFFu), sizeof(Node), hipMemcpyDeviceToHost));
         actions[d] = nd.a;
     }
     return h.depth;

@@ -126,7 +126,7 @@ struct C4 {
 struct BR {
     static constexpr int ID = AZG_GAME_BRANDUBH;
     static constexpr int A = 588, H = 7, W = 7, CELLS = 49, P = 2, HAS_DRAW = 1, MAX_TURNS = 100, NSYM = 8;
-    static constexpr int OBS_C = 5, OBS = OBS_C * CELLS, MAXK = 128;
+    static constexpr int OBS_C = 5, OBS = OBS_C * CELLS, MAXK = 96;      // 8 attackers x 12 destinations bounds the move list
     static constexpr uint64_t ALL = (1ULL << 49) - 1;
     static constexpr uint64_t COL0 = 0x0040810204081ULL, COL6 = COL0 << 6;
     struct S { int cell; int player, turns, kc; };

@@ -28,32 +28,49 @@ AZG_DEV void load_node(const Node *p, uint4 &lo, uint4 &hi) {
 }
 AZG_DEV void raise_error(const View &ev, int code) { atomicCAS(&ev.gcount[GC_ERROR], 0, code); }
 
+// a tree header in registers: one 64-byte line, every lane loads it (same address: one request, broadcast)
+struct HdrR {
+    NodeR root; int base, alloc, depth, max_depth, leaf, leaf_fc, leaf_k, leaf_e, leaf_player, expanded;
+};
+AZG_DEV void load_hdr(const TreeHdr *h, HdrR &r) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(h);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    unpack(a, b, r.root);
+    r.base = __builtin_amdgcn_readfirstlane((int)c.x); r.alloc = __builtin_amdgcn_readfirstlane((int)c.y);
+    r.depth = __builtin_amdgcn_readfirstlane((int)c.z); r.max_depth = __builtin_amdgcn_readfirstlane((int)c.w);
+    r.leaf = __builtin_amdgcn_readfirstlane((int)d.x); r.leaf_fc = __builtin_amdgcn_readfirstlane((int)d.y);
+    const unsigned li = (unsigned)__builtin_amdgcn_readfirstlane((int)d.z);
+    r.leaf_k = li & 0xFFFF; r.leaf_e = (li >> 16) & 0xFF; r.leaf_player = li >> 24;
+    r.expanded = __builtin_amdgcn_readfirstlane((int)d.w);
+}
+// the live semi-space of a tree's node store
+AZG_DEV Node *tree_nodes(const View &ev, int tree, int base) { return ev.nodes + (size_t)tree * 2 * ev.cap + base; }
+
 AZG_DEV void init_tree(const View &ev, int tree, int lane) {           // MCTS.__init__/reset (:133-160)
     if (lane == 0) {
-        uint4 *q = reinterpret_cast<uint4 *>(ev.nodes + (size_t)tree * ev.cap);
-        q[0] = make_uint4(0, 0, 0, 0);
+        uint4 *q = reinterpret_cast<uint4 *>(ev.hdr + tree);
+        q[0] = make_uint4(0, 0, 0, 0);                                   // root: n = 0, q = p = v = 0
         q[1] = pack_hi(-1, 0xFFFF, 0, 0, 0);
-        TreeHdr *h = ev.hdr + tree;
-        h->root = 0; h->alloc = 1; h->cur = 0; h->depth = 0; h->max_depth = 0; h->expanded = 0;
+        q[2] = make_uint4(0, 0, 0, 0);                                   // base, alloc, depth, max_depth
+        q[3] = make_uint4((unsigned)LEAF_IS_ROOT, (unsigned)-1, 0, 0);
     }
 }
 
-// Node.add_children (:76-79) for node `idx` of a tree: k stubs, list order = ascending (tape key, index).
-// my_a[c] = action of child index c*64+lane (ascending action order).  Returns first_child (or -1 on overflow).
-template <class G>
-AZG_DEV int add_children(const View &ev, int slot, Node *nodes, TreeHdr *h, int k, const int (&my_a)[(G::MAXK + 63) / 64], int lane) {
-    constexpr int NCH = (G::MAXK + 63) / 64;
-    int fc = __builtin_amdgcn_readfirstlane(h->alloc);
+// Node.add_children (:76-79): k stubs appended to the tree's live space, list order = ascending (tape key, index).
+// my_a[c] = action of child index c*64+lane (ascending action order), NC = chunks of 64 children actually in use.  `alloc` is the
+// arena cursor held by the caller; returns first_child (or -1 on overflow) and advances `alloc`; the caller stores it.
+template <class G, int NC>
+AZG_DEV int add_children(const View &ev, int slot, Node *nodes, int &alloc, int k, const int (&my_a)[(G::MAXK + 63) / 64], uint64_t &ctr, int lane) {
+    const int fc = alloc;
     if (fc + k > ev.cap) { if (lane == 0) raise_error(ev, AZG_E_TREE_FULL); return -1; }
-    uint64_t ctr = ev.tape_ctr[slot];
-    uint64_t key[NCH];
+    uint64_t key[NC];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) key[c] = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr + (uint64_t)(c * 64 + lane));
+    for (int c = 0; c < NC; c++) key[c] = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr + (uint64_t)(c * 64 + lane));
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
+    for (int c = 0; c < NC; c++) {
         int i = c * 64 + lane, pos = 0;
 #pragma unroll
-        for (int c2 = 0; c2 < NCH; c2++) {
+        for (int c2 = 0; c2 < NC; c2++) {
             int lim = min(64, k - c2 * 64);
             for (int j = 0; j < lim; j++) {
                 uint64_t kj = rl(key[c2], j);
@@ -67,88 +84,119 @@ AZG_DEV int add_children(const View &ev, int slot, Node *nodes, TreeHdr *h, int 
             q[1] = pack_hi(-1, my_a[c], 0, 0, 0);
         }
     }
-    if (lane == 0) {
-        h->alloc = fc + k;
-        ev.tape_ctr[slot] = ctr + (uint64_t)k;          // (no global high-water atomic here: 2048 waves on one word cost ~20 us)
-    }
+    alloc = fc + k;
+    ctr += (uint64_t)k;                                     // (no global high-water atomic here: 2048 waves on one word cost ~20 us)
     return fc;
+}
+template <class G>
+AZG_DEV int add_children_any(const View &ev, int slot, Node *nodes, int &alloc, int k, const int (&my_a)[(G::MAXK + 63) / 64], uint64_t &ctr, int lane) {
+    constexpr int NCH = (G::MAXK + 63) / 64;
+    if constexpr (NCH > 1) { if (k > 64) return add_children<G, NCH>(ev, slot, nodes, alloc, k, my_a, ctr, lane); }
+    return add_children<G, 1>(ev, slot, nodes, alloc, k, my_a, ctr, lane);
 }
 
 // ================================================================================================ select
-// One wavefront runs find_leaf for one slot; `sink(st, lane)` receives the leaf state (it writes the observation wherever the
-// network reads it: the dense batch in HBM for k_select, straight into the tower's LDS image for the fused search kernel).
+// Node.best_child (:86-104) over the k children at nodes[fc ..]: lane i holds child i (+ 64 per further chunk).  Returns the
+// list index of the first maximal child and its record in `sel`.
+template <class G, int NC>
+AZG_DEV int best_child(const View &ev, const Node *nodes, int fc, int k, const NodeR &cn, int lane, NodeR &sel) {
+    uint4 lo[NC], hi[NC];
+    double seen = 0.0;                                                       // :91 python sum() in double, list order
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        int i = c * 64 + lane;
+        if (i < k) load_node(nodes + fc + i, lo[c], hi[c]);
+        else { lo[c] = make_uint4(0, 0, 0, 0); hi[c] = make_uint4(0, 0, 0, 0); }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        int i = c * 64 + lane;
+        uint64_t vis = __ballot(i < k && (int)lo[c].x > 0);
+        while (vis) { int b = __ffsll((unsigned long long)vis) - 1; seen += (double)rl(__uint_as_float(lo[c].z), b); vis &= vis - 1; }
+    }
+    const float seen_f = (float)seen;
+    const float fpu = (float)((double)cn.v - ((double)ev.fpu_reduction * sqrt((double)seen_f)));   // :92
+    // :94 (float)sqrt((double)n): a correctly rounded f32 sqrt of the (exactly representable) count gives the same
+    // float -- rounding a 53-bit sqrt to 24 bits is innocuous double rounding (53 >= 2*24 + 2)
+    const float sqn = cn.n < (1 << 24) ? sqrtf((float)cn.n) : (float)sqrt((double)cn.n);
+    const float cpuct = ev.cpuct;
+    float best = -INFINITY; int bi = 0;
+    sel = cn;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        int i = c * 64 + lane;
+        int ni = (int)lo[c].x;
+        float t = ni == 0 ? fpu : __uint_as_float(lo[c].y);
+        float u = t + (((cpuct * __uint_as_float(lo[c].z)) * sqn) / ((float)(1 + ni)));               // :87
+        if (i >= k) u = -INFINITY;
+        constexpr int RW = G::MAXK <= 8 ? 8 : G::MAXK <= 16 ? 16 : G::MAXK <= 32 ? 32 : 64;
+        float m = RW == 64 ? wave_max(u) : wave_max_n<RW>(u);
+        if (m > best) {                                                      // strict '>' : first max wins (:100)
+            uint64_t bal = __ballot(i < k && u == m);
+            int b = __ffsll((unsigned long long)bal) - 1;
+            best = m; bi = c * 64 + b;
+            uint4 slo, shi;
+            slo.x = rl(lo[c].x, b); slo.y = rl(lo[c].y, b); slo.z = rl(lo[c].z, b); slo.w = rl(lo[c].w, b);
+            shi.x = rl(hi[c].x, b); shi.y = rl(hi[c].y, b); shi.z = rl(hi[c].z, b); shi.w = 0;
+            unpack(slo, shi, sel);
+        }
+    }
+    return bi;
+}
+
+// One wavefront runs find_leaf (:208-228) for one slot; `sink(st, lane)` receives the leaf state (it writes the observation wherever
+// the network reads it: the dense batch in HBM for k_select, straight into the tower's LDS image for the fused search kernel).
+// Dependent-load chain: header (the root is in it) -> one child block per level.
 template <class G, class Sink>
 AZG_DEV void select_slot(const View &ev, int slot, int lane, int *act_lds, Sink &&sink) {
     constexpr int NCH = (G::MAXK + 63) / 64;
-    typename G::S st = G::load(&ev.states[slot], lane);
-    const int tree = ev.arena ? slot * ev.T + st.player : slot;
-    Node *nodes = ev.nodes + (size_t)tree * ev.cap;
+    int tree = slot;                                                         // (self-play: the header load does not wait for the state)
+    if (ev.arena) tree = slot * ev.T + __builtin_amdgcn_readfirstlane(ev.states[slot].player);
     TreeHdr *h = ev.hdr + tree;
-    uint32_t *path = ev.path + (size_t)tree * ev.maxd;
-    int cur = __builtin_amdgcn_readfirstlane(h->root);
-    NodeR cn;
-    { uint4 lo, hi; load_node(nodes + cur, lo, hi); unpack(lo, hi, cn); }
+    HdrR hr; load_hdr(h, hr);
+    uint64_t ctr = ev.tape_ctr[slot];
+    typename G::S st = G::load(&ev.states[slot], lane);
+    Node *nodes = tree_nodes(ev, tree, hr.base);
+    PathEnt *path = ev.path + (size_t)tree * ev.maxd;
+    int cur = LEAF_IS_ROOT;
+    NodeR cn = hr.root;
     int depth = 0;
-    const float cpuct = ev.cpuct;
     while (cn.n > 0 && cn.e == 0 && depth < ev.maxd) {                       // MCTS.pyx:213
         const int k = cn.nchild, fc = cn.fc;
         if (k == 0 || fc < 0) { if (lane == 0) raise_error(ev, AZG_E_TREE_FULL); break; }
-        uint4 lo[NCH], hi[NCH];
-        double seen = 0.0;                                                   // :91 python sum() in double, list order
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            int i = c * 64 + lane;
-            if (i < k) load_node(nodes + fc + i, lo[c], hi[c]);
-            else { lo[c] = make_uint4(0, 0, 0, 0); hi[c] = make_uint4(0, 0, 0, 0); }
-            uint64_t vis = __ballot(i < k && (int)lo[c].x > 0);
-            while (vis) { int b = __ffsll((unsigned long long)vis) - 1; seen += (double)rl(__uint_as_float(lo[c].z), b); vis &= vis - 1; }
-        }
-        const float seen_f = (float)seen;
-        const float fpu = (float)((double)cn.v - ((double)ev.fpu_reduction * sqrt((double)seen_f)));   // :92
-        // :94 (float)sqrt((double)n): a correctly rounded f32 sqrt of the (exactly representable) count gives the same
-        // float -- rounding a 53-bit sqrt to 24 bits is innocuous double rounding (53 >= 2*24 + 2)
-        const float sqn = cn.n < (1 << 24) ? sqrtf((float)cn.n) : (float)sqrt((double)cn.n);
-        float best = -INFINITY; int bi = 0; NodeR sel = cn;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            int i = c * 64 + lane;
-            int ni = (int)lo[c].x;
-            float t = ni == 0 ? fpu : __uint_as_float(lo[c].y);
-            float u = t + (((cpuct * __uint_as_float(lo[c].z)) * sqn) / ((float)(1 + ni)));               // :87
-            if (i >= k) u = -INFINITY;
-            constexpr int RW = G::MAXK <= 8 ? 8 : G::MAXK <= 16 ? 16 : G::MAXK <= 32 ? 32 : 64;
-            float m = RW == 64 ? wave_max(u) : wave_max_n<RW>(u);
-            if (m > best) {                                                  // strict '>' : first max wins (:100)
-                uint64_t bal = __ballot(i < k && u == m);
-                int b = __ffsll((unsigned long long)bal) - 1;
-                best = m; bi = c * 64 + b;
-                uint4 slo, shi;
-                slo.x = rl(lo[c].x, b); slo.y = rl(lo[c].y, b); slo.z = rl(lo[c].z, b); slo.w = rl(lo[c].w, b);
-                shi.x = rl(hi[c].x, b); shi.y = rl(hi[c].y, b); shi.z = rl(hi[c].z, b); shi.w = 0;
-                unpack(slo, shi, sel);
-            }
-        }
+        NodeR sel; int bi;
+        if constexpr (NCH > 1) { bi = k > 64 ? best_child<G, NCH>(ev, nodes, fc, k, cn, lane, sel) : best_child<G, 1>(ev, nodes, fc, k, cn, lane, sel); }
+        else bi = best_child<G, 1>(ev, nodes, fc, k, cn, lane, sel);
         cur = fc + bi;
-        if (lane == 0) path[depth] = (uint32_t)cur | ((uint32_t)cn.player << 28);
+        if (lane == 0) {                                                     // the path entry carries the child's (n, q) for the backup
+            uint4 ent = make_uint4((uint32_t)cur | ((uint32_t)cn.player << 28), (uint32_t)sel.n, __float_as_uint(sel.q), 0u);
+            *reinterpret_cast<uint4 *>(path + depth) = ent;
+        }
         cn = sel;
         G::play(st, cn.a);                                                   // :216
         depth++;
     }
     int expanded = 0;
+    int alloc = hr.alloc;
     if (cn.n == 0) {                                                         // :223-226 expand
         const int e = G::win_bits(st);
         int my_a[NCH];
         const int k = G::valid_list(st, lane, act_lds, my_a);
-        int fc = add_children<G>(ev, slot, nodes, h, k, my_a, lane);
+        const int fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane);
+        cn.fc = fc; cn.nchild = fc < 0 ? 0 : k; cn.player = st.player; cn.e = e;
         if (lane == 0) {
-            uint4 *q = reinterpret_cast<uint4 *>(nodes + cur);
-            q[1] = pack_hi(fc, cn.a, fc < 0 ? 0 : k, st.player, e);
+            ev.tape_ctr[slot] = ctr;
+            const uint4 hi = pack_hi(cn.fc, cn.a, cn.nchild, cn.player, cn.e);
+            if (cur == LEAF_IS_ROOT) reinterpret_cast<uint4 *>(h)[1] = hi;
+            else reinterpret_cast<uint4 *>(nodes + cur)[1] = hi;
         }
         expanded = 1;
     }
     if (lane == 0) {
-        h->cur = cur; h->depth = depth; h->expanded = expanded;
-        if (depth > h->max_depth) h->max_depth = depth;                      // :219-221
+        const int md = depth > hr.max_depth ? depth : hr.max_depth;         // :219-221
+        uint4 *q = reinterpret_cast<uint4 *>(h);
+        q[2] = make_uint4((unsigned)hr.base, (unsigned)alloc, (unsigned)depth, (unsigned)md);
+        q[3] = make_uint4((unsigned)cur, (unsigned)cn.fc, (unsigned)cn.nchild | ((unsigned)cn.e << 16) | ((unsigned)cn.player << 24), (unsigned)expanded);
         ev.slot_exp[slot] += expanded;
     }
     G::store(st, &ev.leaf_states[slot], lane);
@@ -170,128 +218,135 @@ __global__ __launch_bounds__(64) void k_select(View ev, OT *obs, const int32_t *
 }
 
 // ================================================================================================ backup
-// One wavefront runs process_results for one slot with its policy row pi[A] and value row vrow[P+1] (HBM or LDS).
-// m_lds [max(A, 8)] and scr [64] are wave-private scratch (only used when A >= 8).
+// np.sum of the masked policy (:245,252) in numpy's order: cp[c] = value of child c*64+lane, ca[c] its action.
+template <class G, int NC>
+AZG_DEV float masked_sum(const View &ev, const int (&ca)[NC], const float (&cp)[NC], float *m_lds, float *scr, int lane, bool first) {
+    constexpr int A = G::A;
+    if constexpr (A < 8) {
+        float s = 0.f;                                                       // n < 8: sequential in action order
+        for (int a = 0; a < A; a++) {
+            uint64_t bal = __ballot(ca[0] == a);
+            if (bal) s += rl(cp[0], __ffsll((unsigned long long)bal) - 1);
+        }
+        return s;
+    } else {
+        if (first) { for (int a = lane; a < A; a += 64) m_lds[a] = 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; c++) if (ca[c] >= 0) m_lds[ca[c]] = cp[c];
+        __syncthreads();
+        return np_sum_wave(m_lds, ev.plan, scr, lane);
+    }
+}
+
+// update_policy (:81-84) of the freshly expanded leaf from the network's policy row: mask + renormalise (:239-245), root
+// temperature (:249-252) and Dirichlet noise (:197-206) at the root.
+template <class G, int NC>
+AZG_DEV void leaf_policy(const View &ev, int slot, Node *nodes, int fc, int k, bool at_root, const float *pi, float *m_lds, float *scr, int lane) {
+    int ca[NC]; float cp[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        int i = c * 64 + lane;
+        ca[c] = i < k ? (int)nodes[fc + i].a : -1;
+        cp[c] = i < k ? pi[ca[c]] : 0.f;                                     // pi * valids: valid entries keep pi[a]
+    }
+    const float s = masked_sum<G, NC>(ev, ca, cp, m_lds, scr, lane, true);
+#pragma unroll
+    for (int c = 0; c < NC; c++) cp[c] = cp[c] / s;                          // :245
+    if (at_root && ev.add_temp) {                                            // :249-252 root temperature
+        const double ex = 1.0 / (double)ev.root_temp;
+#pragma unroll
+        for (int c = 0; c < NC; c++) cp[c] = np_pow_f32(cp[c], ex);
+        const float s2 = masked_sum<G, NC>(ev, ca, cp, m_lds, scr, lane, false);
+#pragma unroll
+        for (int c = 0; c < NC; c++) cp[c] = cp[c] / s2;
+    }
+    if (at_root && ev.add_noise) {                                           // :197-206 Dirichlet noise (tape)
+        const uint64_t ctr = ev.tape_ctr[slot];
+        const uint64_t key = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr);
+        const double alpha = 10.83 / (double)k;
+        double g[NC]; double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            int i = c * 64 + lane;
+            g[c] = 0.0;
+            if (i < k) { SubStream ss = { key, (uint64_t)i, 0 }; g[c] = ss_gamma(ss, alpha); }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) { int lim = min(64, k - c * 64); for (int j = 0; j < lim; j++) acc += rl(g[c], j); }
+        const double inv = 1.0 / acc;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float nz = (float)(g[c] * inv);
+            cp[c] = (float)(((double)cp[c] * (1.0 - (double)ev.noise_frac)) + (double)(ev.noise_frac * nz));
+        }
+        if (lane == 0) ev.tape_ctr[slot] = ctr + 1;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) { int i = c * 64 + lane; if (i < k) nodes[fc + i].p = cp[c]; }      // update_policy :81-84
+}
+
+// One wavefront runs process_results (:230-289) for one slot with its policy row pi[A] and value row vrow[P+1] (HBM or LDS).
+// m_lds [max(A, 8)] and scr [64] are wave-private scratch (only used when A >= 8).  The header's leaf record and the (n, q)
+// snapshots in the path make this one level of loads (header, path, rows -- all independent; then the leaf's child actions).
 template <class G>
 AZG_DEV void backup_slot(const View &ev, int slot, int lane, const float *pi, const float *vrow, float *m_lds, float *scr) {
     constexpr int NCH = (G::MAXK + 63) / 64;
-    constexpr int A = G::A, P = G::P, NV = P + 1, NE = P + G::HAS_DRAW;
-    const int mover0 = __builtin_amdgcn_readfirstlane(ev.states[slot].player);
-    const int tree = ev.arena ? slot * ev.T + mover0 : slot;
-    Node *nodes = ev.nodes + (size_t)tree * ev.cap;
+    constexpr int P = G::P, NV = P + 1, NE = P + G::HAS_DRAW;
+    int tree = slot;
+    if (ev.arena) tree = slot * ev.T + __builtin_amdgcn_readfirstlane(ev.states[slot].player);
     TreeHdr *h = ev.hdr + tree;
-    const uint32_t *path = ev.path + (size_t)tree * ev.maxd;
-    const int cur = __builtin_amdgcn_readfirstlane(h->cur), depth = __builtin_amdgcn_readfirstlane(h->depth);
-    const int root = __builtin_amdgcn_readfirstlane(h->root);
-    NodeR cn;
-    { uint4 lo, hi; load_node(nodes + cur, lo, hi); unpack(lo, hi, cn); }
+    HdrR hr; load_hdr(h, hr);
+    const PathEnt *path = ev.path + (size_t)tree * ev.maxd;
+    const int depth = hr.depth;
+    uint4 ent[(G::MAX_TURNS + 2 + 63) / 64];                                 // the path, one level per lane
+#pragma unroll
+    for (int j0 = 0, c = 0; j0 < G::MAX_TURNS + 2; j0 += 64, c++)
+        ent[c] = j0 + lane < depth ? *reinterpret_cast<const uint4 *>(path + j0 + lane) : make_uint4(0, 0, 0, 0);
+    Node *nodes = tree_nodes(ev, tree, hr.base);
     float val[NV > NE ? NV : NE];
     int vsize;
-    if (cn.e) {                                                              // :234-235 terminal: value = float32(e)
+    if (hr.leaf_e) {                                                         // :234-235 terminal: value = float32(e)
 #pragma unroll
-        for (int j = 0; j < NE; j++) val[j] = (float)((cn.e >> j) & 1);
+        for (int j = 0; j < NE; j++) val[j] = (float)((hr.leaf_e >> j) & 1);
         vsize = NE;
     } else {
 #pragma unroll
         for (int j = 0; j < NV; j++) val[j] = vrow[j];
         vsize = NV;
-        // ---- mask + renormalise the policy over the node's children (:239-245) ----
-        const int k = cn.nchild, fc = cn.fc;
-        int ca[NCH]; float cp[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            int i = c * 64 + lane;
-            ca[c] = i < k ? (int)nodes[fc + i].a : -1;
-            cp[c] = i < k ? pi[ca[c]] : 0.f;                                 // pi * valids: valid entries keep pi[a]
+        const int k = hr.leaf_k, fc = hr.leaf_fc;
+        const bool at_root = hr.leaf == LEAF_IS_ROOT;
+        if (fc >= 0) {
+            if constexpr (NCH > 1) {
+                if (k > 64) leaf_policy<G, NCH>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
+                else leaf_policy<G, 1>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
+            } else leaf_policy<G, 1>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
         }
-        float s;
-        const bool at_root = cur == root;
-        const bool use_temp = at_root && ev.add_temp;
-        if constexpr (A < 8) {
-            s = 0.f;                                                         // np.sum, n < 8: sequential in action order
-            for (int a = 0; a < A; a++) {
-                uint64_t bal = __ballot(ca[0] == a);
-                if (bal) s += rl(cp[0], __ffsll((unsigned long long)bal) - 1);
-            }
-        } else {
-            for (int a = lane; a < A; a += 64) m_lds[a] = 0.f;
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < NCH; c++) if (ca[c] >= 0) m_lds[ca[c]] = cp[c];
-            __syncthreads();
-            s = np_sum_wave(m_lds, ev.plan, scr, lane);
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; c++) cp[c] = cp[c] / s;                     // :245
-        if (use_temp) {                                                      // :249-252 root temperature
-            const double ex = 1.0 / (double)ev.root_temp;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) cp[c] = np_pow_f32(cp[c], ex);
-            float s2;
-            if constexpr (A < 8) {
-                s2 = 0.f;
-                for (int a = 0; a < A; a++) {
-                    uint64_t bal = __ballot(ca[0] == a);
-                    if (bal) s2 += rl(cp[0], __ffsll((unsigned long long)bal) - 1);
-                }
-            } else {
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < NCH; c++) if (ca[c] >= 0) m_lds[ca[c]] = cp[c];
-                __syncthreads();
-                s2 = np_sum_wave(m_lds, ev.plan, scr, lane);
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; c++) cp[c] = cp[c] / s2;
-        }
-        if (at_root && ev.add_noise) {                                       // :197-206 Dirichlet noise (tape)
-            const uint64_t ctr = ev.tape_ctr[slot];
-            const uint64_t key = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr);
-            const double alpha = 10.83 / (double)k;
-            double g[NCH]; double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                int i = c * 64 + lane;
-                g[c] = 0.0;
-                if (i < k) { SubStream ss = { key, (uint64_t)i, 0 }; g[c] = ss_gamma(ss, alpha); }
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; c++) { int lim = min(64, k - c * 64); for (int j = 0; j < lim; j++) acc += rl(g[c], j); }
-            const double inv = 1.0 / acc;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                float nz = (float)(g[c] * inv);
-                cp[c] = (float)(((double)cp[c] * (1.0 - (double)ev.noise_frac)) + (double)(ev.noise_frac * nz));
-            }
-            if (lane == 0) ev.tape_ctr[slot] = ctr + 1;
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; c++) { int i = c * 64 + lane; if (i < k) nodes[fc + i].p = cp[c]; }      // update_policy :81-84
     }
     // ---- backup along the path (:265-287): X_j = path[j-1] node, mover = player of X_{j-1}; all levels independent
     const float draw_share = vsize > P ? (val[P] / ((float)P)) : 0.f;
-    for (int j0 = 0; j0 < depth; j0 += 64) {
-        int j = j0 + lane;
+#pragma unroll
+    for (int j0 = 0, c = 0; j0 < G::MAX_TURNS + 2; j0 += 64, c++) {
+        const int j = j0 + lane;
         if (j < depth) {
-            uint32_t ent = path[j];
-            int idx = (int)(ent & 0x0FFFFFFFu), mover = (int)(ent >> 28);
+            const int idx = (int)(ent[c].x & 0x0FFFFFFFu), mover = (int)(ent[c].x >> 28);
             float vm = val[0];
 #pragma unroll
             for (int pp = 1; pp < P; pp++) if (mover == pp) vm = val[pp];
-            float v = vsize > P ? vm + draw_share : vm;                      // _get_value :291-295
+            const float v = vsize > P ? vm + draw_share : vm;                // _get_value :291-295
+            const int n = (int)ent[c].y; const float q = __uint_as_float(ent[c].z);
             Node *x = nodes + idx;
-            int n = x->n; float q = x->q;
-            x->q = (((q * (float)n) + (v * 1.0f)) / ((float)(n + 1)));       // :282 (discount == 1)
+            const float qn = (((q * (float)n) + (v * 1.0f)) / ((float)(n + 1)));      // :282 (discount == 1)
+            *reinterpret_cast<uint2 *>(x) = make_uint2((unsigned)(n + 1), __float_as_uint(qn));
             if (n == 0) {                                                    // :283-284 (only the leaf can have n == 0)
                 float vo = val[0];
 #pragma unroll
-                for (int pp = 1; pp < P; pp++) if (cn.player == pp) vo = val[pp];
+                for (int pp = 1; pp < P; pp++) if (hr.leaf_player == pp) vo = val[pp];
                 x->v = vsize > P ? vo + draw_share : vo;
             }
-            x->n = n + 1;
         }
     }
-    if (lane == 0) { nodes[root].n += 1; ev.slot_sims[slot] += 1; }          // :289
+    if (lane == 0) { h->root.n = hr.root.n + 1; ev.slot_sims[slot] += 1; }   // :289
 }
 
 template <class G>
@@ -388,9 +443,9 @@ __global__ __launch_bounds__(64) void k_root_stats(View ev, int what, float temp
     const int slot = blockIdx.x, lane = threadIdx.x;
     const int mover0 = __builtin_amdgcn_readfirstlane(ev.states[slot].player);
     const int tree = ev.arena ? slot * ev.T + mover0 : slot;
-    const Node *nodes = ev.nodes + (size_t)tree * ev.cap;
-    const int root = ev.hdr[tree].root;
-    const int fc = nodes[root].first_child, k = nodes[root].nchild;
+    HdrR hr; load_hdr(ev.hdr + tree, hr);
+    const Node *nodes = tree_nodes(ev, tree, hr.base);
+    const int fc = hr.root.fc, k = hr.root.nchild;
     if (what == 0) {
         for (int a = lane; a < A; a += 64) counts[(size_t)slot * A + a] = 0;
         __syncthreads();
@@ -411,21 +466,23 @@ __global__ __launch_bounds__(64) void k_root_stats(View ev, int what, float temp
     }
 }
 
-// MCTS.update_root (:185-195) for one tree; returns false if the action is not a child.
+// MCTS.update_root (:185-195) for one tree: the chosen child's record is copied into the header (it becomes the root; its own
+// slot in the parent's child block is garbage from then on); returns false if the action is not a child.
 template <class G>
 AZG_DEV bool update_root(const View &ev, int slot, int tree, const typename G::S &st, int action, int *act_lds, int lane) {
     constexpr int NCH = (G::MAXK + 63) / 64;
-    Node *nodes = ev.nodes + (size_t)tree * ev.cap;
     TreeHdr *h = ev.hdr + tree;
-    const int root = __builtin_amdgcn_readfirstlane(h->root);
-    int fc = __builtin_amdgcn_readfirstlane(nodes[root].first_child);
-    int k = __builtin_amdgcn_readfirstlane((int)nodes[root].nchild);
+    HdrR hr; load_hdr(h, hr);
+    Node *nodes = tree_nodes(ev, tree, hr.base);
+    int fc = hr.root.fc, k = hr.root.nchild;
     if (k == 0) {                                                            // :186-187 unexpanded root: add + shuffle
         int my_a[NCH];
         k = G::valid_list(st, lane, act_lds, my_a);
-        fc = add_children<G>(ev, slot, nodes, h, k, my_a, lane);
+        uint64_t ctr = ev.tape_ctr[slot];
+        int alloc = hr.alloc;
+        fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane);
         if (fc < 0) return false;
-        if (lane == 0) { nodes[root].first_child = fc; nodes[root].nchild = (uint16_t)k; }
+        if (lane == 0) { ev.tape_ctr[slot] = ctr; h->alloc = alloc; }
         __syncthreads();
     }
     int found = -1;
@@ -435,7 +492,8 @@ AZG_DEV bool update_root(const View &ev, int slot, int tree, const typename G::S
         if (bal) { found = i0 + __ffsll((unsigned long long)bal) - 1; break; }
     }
     if (found < 0) return false;
-    if (lane == 0) h->root = fc + found;
+    uint4 lo, hi; load_node(nodes + fc + found, lo, hi);
+    if (lane == 0) { uint4 *q = reinterpret_cast<uint4 *>(h); q[0] = lo; q[1] = hi; }
     return true;
 }
 
@@ -447,6 +505,51 @@ __global__ __launch_bounds__(64) void k_update_root(View ev, int slot, int actio
     bool good = true;
     for (int t = 0; t < ev.T; t++) good = update_root<G>(ev, slot, slot * ev.T + t, st, action, act_lds, lane) && good;
     if (lane == 0) *ok = good ? 1 : 0;
+}
+
+// Node reclamation.  The reference drops the siblings of the played move with Python's GC (MCTS.update_root :185-195 rebinds
+// _root).  Here a tree's node store is two semi-spaces of `cap` nodes; when, after a move, fewer than `compact_reserve` free
+// nodes are left in the live space, the subtree under the root (which sits in the header) is copied breadth-first into the
+// other space -- child blocks stay contiguous and keep their list order, so no result changes -- and the spaces swap roles.
+// One wavefront per tree; 64 nodes of the copy frontier per step (their child blocks are sized with a wave scan).
+template <class G>
+__global__ __launch_bounds__(64) void k_compact(View ev, int force) {
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
+    const int tree = blockIdx.x, lane = threadIdx.x;
+    TreeHdr *h = ev.hdr + tree;
+    HdrR hr; load_hdr(h, hr);
+    if (!force && hr.alloc + ev.compact_reserve <= ev.cap) return;
+    const Node *from = tree_nodes(ev, tree, hr.base);
+    const int nbase = hr.base ? 0 : ev.cap;
+    Node *to = tree_nodes(ev, tree, nbase);
+    int nalloc = 0;
+    if (hr.root.fc >= 0 && hr.root.nchild > 0) {                             // the root's child block -> to[0 .. k)
+        const int k = hr.root.nchild;
+        for (int i = lane; i < k; i += 64) { uint4 lo, hi; load_node(from + hr.root.fc + i, lo, hi); uint4 *q = reinterpret_cast<uint4 *>(to + i); q[0] = lo; q[1] = hi; }
+        nalloc = k;
+    }
+    __syncthreads();
+    for (int scan = 0; scan < nalloc; scan += 64) {                          // nodes to[scan ..] still carry from-space child pointers
+        const int i = scan + lane;
+        int ofc = -1, kk = 0;
+        if (i < nalloc) { const uint4 hi = reinterpret_cast<const uint4 *>(to + i)[1]; ofc = (int)hi.x; kk = ofc >= 0 ? (int)(hi.y >> 16) : 0; }
+        const int off = wave_excl_scan(kk, lane), total = wave_sum_i(kk);
+        const int nfc = nalloc + off;
+        if (kk > 0) reinterpret_cast<int32_t *>(to + i)[4] = nfc;            // first_child now points into to-space
+        uint64_t todo = __ballot(kk > 0);
+        while (todo) {                                                       // copy the frontier's child blocks, one parent at a time
+            const int b = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
+            const int sfc = rl(ofc, b), sk = rl(kk, b), dfc = rl(nfc, b);
+            for (int j = lane; j < sk; j += 64) { uint4 lo, hi; load_node(from + sfc + j, lo, hi); uint4 *q = reinterpret_cast<uint4 *>(to + dfc + j); q[0] = lo; q[1] = hi; }
+        }
+        nalloc += total;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (hr.root.fc >= 0 && hr.root.nchild > 0) h->root.first_child = 0;
+        h->base = nbase; h->alloc = nalloc;
+        h->leaf = LEAF_IS_ROOT; h->leaf_fc = -1; h->depth = 0;               // the last find_leaf's indices are void now
+    }
 }
 
 // ================================================================================================ advance
@@ -464,10 +567,9 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
         return;                                                              // agent loop has ended by then (SelfPlayAgent.pyx:79-80)
     }
     const int tree = ev.arena ? slot * ev.T + st.player : slot;
-    const Node *nodes = ev.nodes + (size_t)tree * ev.cap;
-    const int root = __builtin_amdgcn_readfirstlane(ev.hdr[tree].root);
-    const int fc = __builtin_amdgcn_readfirstlane(nodes[root].first_child);
-    const int k = __builtin_amdgcn_readfirstlane((int)nodes[root].nchild);
+    HdrR hr; load_hdr(ev.hdr + tree, hr);
+    const Node *nodes = tree_nodes(ev, tree, hr.base);
+    const int fc = hr.root.fc, k = hr.root.nchild;
     float temp;
     if (ev.arena) temp = ev.arena_temp;                                      // :158
     else { int t = st.turns < ev.temp_len ? st.turns : ev.temp_len - 1; temp = ev.temp_table[t]; }   // :156-157
@@ -591,7 +693,7 @@ __global__ __launch_bounds__(64) void k_reset(View ev, int first, int count, int
     for (int t = 0; t < ev.T; t++) init_tree(ev, slot * ev.T + t, lane);
 }
 
-// high-water mark of the tree arenas, computed when the counters are read
+// high-water mark of the tree arenas (live semi-space), computed when the counters are read
 __global__ __launch_bounds__(256) void k_max_nodes(View ev) {
     int m = 0;
     for (int t = threadIdx.x; t < ev.B * ev.T; t += 256) m = max(m, ev.hdr[t].alloc);

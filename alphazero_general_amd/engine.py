@@ -39,10 +39,10 @@ class DeviceEngine:
         self.O = gi.obs_c * gi.obs_h * gi.obs_w
         self._tt = (np.ascontiguousarray(temp_table_override, np.float32) if temp_table_override is not None
                     else temp_table(temp_fn, start_temp, gi.max_turns))
-        if nodes_per_tree <= 0:
-            # every simulation expands at most one node (<= max_children stubs); trees are kept for a whole game
-            nodes_per_tree = gi.max_turns * max(int(sims_hint), 1) * gi.max_children + 64
         cfg = _abi.Config()
+        # nodes_per_tree = 0: the library sizes the two node semi-spaces of a tree from sims_per_move (every simulation expands
+        # at most one node = max_children stubs; dead siblings are reclaimed by compaction after a move)
+        cfg.sims_per_move = max(int(sims_hint), 1)
         cfg.abi_version, cfg.game, cfg.device, cfg.num_slots = _abi.ABI_VERSION, game, self.device.index, self.B
         cfg.arena, cfg.nodes_per_tree = int(arena), int(nodes_per_tree)
         cfg.example_capacity, cfg.result_capacity = int(example_capacity), int(result_capacity)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AZG_ABI_VERSION 1
+#define AZG_ABI_VERSION 2
 
 typedef enum azg_status {
     AZG_OK = 0,
@@ -74,7 +74,7 @@ typedef struct azg_config {
     int32_t  device;            /* HIP device ordinal */
     int32_t  num_slots;         /* B: concurrent games (batch_tensor.shape[0], SelfPlayAgent.pyx:23-26) */
     int32_t  arena;             /* 1: one tree per player per game (SelfPlayAgent.pyx:60-73)      */
-    int32_t  nodes_per_tree;    /* node-arena capacity per tree; 0 = default for the game         */
+    int32_t  nodes_per_tree;    /* capacity of each of a tree's two node semi-spaces; 0 = 4 * sims_per_move * max_children + 64 */
     int32_t  example_capacity;  /* max (obs, pi, z) samples held; 0 = no sample recording         */
     int32_t  result_capacity;   /* max finished-game records held                                  */
     float    cpuct, fpu_reduction, root_noise_frac, root_policy_temp, min_discount;   /* MCTS.pyx:134-138 */
@@ -84,6 +84,8 @@ typedef struct azg_config {
     int32_t  games_per_iteration;                  /* args.gamesPerIteration :179-183                  */
     float    start_temp, arena_temp;               /* args.startTemp :58, args.arenaTemp :158          */
     int32_t  temp_table_len;                       /* temp used for the move at turn t, i.e.           */
+    int32_t  sims_per_move;                        /* max(numMCTSSims, numFastSims, numWarmupSims): sizes the node store and the
+                                                    * free-node reserve below which a tree is compacted after a move; 0 = 100 */
     const float *temp_table;                       /*   args.temp_scaling_fn iterated (:156-157); host */
     uint64_t tape_seed;                            /* random tape                          */
     uint64_t slot_base;                            /* global id of slot 0 (multi-GPU sharding)         */
