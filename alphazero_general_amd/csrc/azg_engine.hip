@@ -129,11 +129,12 @@ extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
     memset(&v, 0, sizeof(v));
     v.B = cfg->num_slots; v.arena = cfg->arena ? 1 : 0; v.T = v.arena ? gi.num_players : 1;
     // node store: two semi-spaces of `cap` nodes per tree (k_compact).  A move adds at most sims_per_move * max_children nodes to
-    // the live space; the default capacity holds four such moves, and the space is compacted after a move once fewer than one
-    // move's worth of free nodes is left
+    // the live space; the default capacity holds eight such moves (the subtree kept across moves is typically one to two moves'
+    // worth; the worst case, a game that never drops a sibling, needs max_turns), and the space is compacted after a move once
+    // fewer than one move's worth of free nodes is left.  Overflow is loud: the sticky AZG_E_TREE_FULL
     const int sims = cfg->sims_per_move > 0 ? cfg->sims_per_move : 100;
     const long long per_move = (long long)sims * gi.max_children;
-    const long long cap = cfg->nodes_per_tree > 0 ? cfg->nodes_per_tree : 4 * per_move + 64;
+    const long long cap = cfg->nodes_per_tree > 0 ? cfg->nodes_per_tree : 8 * per_move + 64;
     if (cap >= (1 << 28)) { delete e; return fail(AZG_E_INVALID_ARG, "nodes_per_tree must be < 2^28"); }
     v.cap = (int)cap;
     v.compact_reserve = (int)(per_move < cap / 2 ? per_move : cap / 2);

@@ -529,10 +529,11 @@ __global__ __launch_bounds__(64) void k_compact(View ev, int force) {
         nalloc = k;
     }
     __syncthreads();
-    for (int scan = 0; scan < nalloc; scan += 64) {                          // nodes to[scan ..] still carry from-space child pointers
-        const int i = scan + lane;
+    for (int scan = 0; scan < nalloc;) {                                     // nodes to[scan .. nalloc) still carry from-space child pointers
+        const int end = min(scan + 64, nalloc), i = scan + lane;
+        scan = end;
         int ofc = -1, kk = 0;
-        if (i < nalloc) { const uint4 hi = reinterpret_cast<const uint4 *>(to + i)[1]; ofc = (int)hi.x; kk = ofc >= 0 ? (int)(hi.y >> 16) : 0; }
+        if (i < end) { const uint4 hi = reinterpret_cast<const uint4 *>(to + i)[1]; ofc = (int)hi.x; kk = ofc >= 0 ? (int)(hi.y >> 16) : 0; }
         const int off = wave_excl_scan(kk, lane), total = wave_sum_i(kk);
         const int nfc = nalloc + off;
         if (kk > 0) reinterpret_cast<int32_t *>(to + i)[4] = nfc;            // first_child now points into to-space

@@ -74,7 +74,7 @@ typedef struct azg_config {
     int32_t  device;            /* HIP device ordinal */
     int32_t  num_slots;         /* B: concurrent games (batch_tensor.shape[0], SelfPlayAgent.pyx:23-26) */
     int32_t  arena;             /* 1: one tree per player per game (SelfPlayAgent.pyx:60-73)      */
-    int32_t  nodes_per_tree;    /* capacity of each of a tree's two node semi-spaces; 0 = 4 * sims_per_move * max_children + 64 */
+    int32_t  nodes_per_tree;    /* capacity of each of a tree's two node semi-spaces; 0 = 8 * sims_per_move * max_children + 64 */
     int32_t  example_capacity;  /* max (obs, pi, z) samples held; 0 = no sample recording         */
     int32_t  result_capacity;   /* max finished-game records held                                  */
     float    cpuct, fpu_reduction, root_noise_frac, root_policy_temp, min_discount;   /* MCTS.pyx:134-138 */
