@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libazg_hip.so')
+LIB_PATH = os.environ.get('AZG_LIB_PATH') or os.path.join(HERE, 'lib', 'libazg_hip.so')   # (override: measurement builds)
 ABI_VERSION = 2
 
 GAME_CONNECT4, GAME_BRANDUBH, GAME_TRIMOK = 0, 1, 2

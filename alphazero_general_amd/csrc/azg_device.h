@@ -87,7 +87,16 @@ struct View {
     int32_t add_noise, add_temp, symmetric, reset_thr, games_cap, max_hist;
     float cpuct, fpu_reduction, noise_frac, root_temp, arena_temp;
     uint64_t seed, slot_base;
+    unsigned long long *dbg;   // AZG_TREE_TIMING builds only: s_memtime stamps [B][16] of the last simulation of every slot
 };
+
+// phase stamps of the tree kernels (measurement builds: hipcc -DAZG_TREE_TIMING; tools/time_tree.py reads them)
+#ifdef AZG_TREE_TIMING
+#define AZG_TSTAMP(ev, slot, lane, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if ((ev).dbg && (lane) == 0) (ev).dbg[(size_t)(slot) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZG_TSTAMP(ev, slot, lane, i) do { } while (0)
+#endif
 
 enum { GC_GAMES = 0, GC_RESULTS = 1, GC_EXAMPLES = 2, GC_ERROR = 3, GC_MAXNODES = 4 };
 
@@ -196,6 +205,11 @@ AZG_DEV int wave_sum_i(int m) {
     for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
     return m;
 }
+// Ordering point between the lanes of ONE wavefront (every tree function is one wave working on wave-private LDS and on its own
+// tree in HBM): earlier LDS / global accesses of the wave have completed before later ones start.  No s_barrier: the functions
+// can be called by several waves of a workgroup independently (the two-wave tree launch, the persistent search kernel).
+AZG_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
 // exclusive prefix sum over lanes (int)
 AZG_DEV int wave_excl_scan(int x, int lane) {
     int s = x;
@@ -240,19 +254,19 @@ AZG_DEV float np_sum_wave(const float *m, const SumPlan *plan, float *scr, int l
         for (int i = lim; i < len; i++) res += m[off + i];
         if (l < nl && j == 0) scr[l] = res;
     }
-    __syncthreads();
+    wave_sync();
     float st[8]; int sp = 0, li = 0;
     for (int i = 0; i < plan->nprog; i++) {
         if (plan->prog[i] == 0) st[sp++] = scr[li++];
         else { st[sp - 2] = st[sp - 2] + st[sp - 1]; sp--; }
     }
-    __syncthreads();
+    wave_sync();
     return st[0];
 }
 
-// softmax over the A policy logits and the NV value logits of one board by one wavefront (NNetArchitecture.py:112-118,
-// exp(log_softmax)): lane owns logits lane, lane + 64, ... (A <= 1024).  pol / val may be global or LDS.
-AZG_DEV void heads_softmax_row(const float *lg, int lane, int A, int NV, float *pol, float *val) {
+// softmax over the A policy logits of one board by one wavefront (NNetArchitecture.py:112-118, exp(log_softmax)): lane owns logits
+// lane, lane + 64, ... (A <= 1024).  pol may be global or LDS.
+AZG_DEV void policy_softmax_row(const float *lg, int lane, int A, float *pol) {
     float x[16], m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -261,7 +275,6 @@ AZG_DEV void heads_softmax_row(const float *lg, int lane, int A, int NV, float *
         if (o >= A) x[j] = -INFINITY;
         m = fmaxf(m, x[j]);
     }
-    const float v = lg[A + min(lane, NV - 1)];
 #pragma unroll
     for (int d = 32; d; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     float sum = 0.f;
@@ -272,6 +285,10 @@ AZG_DEV void heads_softmax_row(const float *lg, int lane, int A, int NV, float *
     const float inv = 1.f / sum;
 #pragma unroll
     for (int j = 0; j < 16; j++) { const int o = lane + 64 * j; if (o < A) pol[o] = x[j] * inv; }
+}
+// the same for the NV <= 64 value logits lg[0 .. NV): lane j < NV returns probability j (other lanes 0)
+AZG_DEV float value_softmax(const float *lg, int lane, int NV) {
+    const float v = lg[min(lane, NV - 1)];
     float vm = lane < NV ? v : -INFINITY;
 #pragma unroll
     for (int d = 32; d; d >>= 1) vm = fmaxf(vm, __shfl_xor(vm, d));
@@ -279,7 +296,12 @@ AZG_DEV void heads_softmax_row(const float *lg, int lane, int A, int NV, float *
     float vs = ev;
 #pragma unroll
     for (int d = 32; d; d >>= 1) vs += __shfl_xor(vs, d);
-    if (lane < NV) val[lane] = ev / vs;
+    return ev / vs;
+}
+AZG_DEV void heads_softmax_row(const float *lg, int lane, int A, int NV, float *pol, float *val) {
+    policy_softmax_row(lg, lane, A, pol);
+    const float pv = value_softmax(lg + A, lane, NV);
+    if (lane < NV) val[lane] = pv;
 }
 
 }  // namespace azg

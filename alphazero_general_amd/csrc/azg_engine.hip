@@ -174,6 +174,9 @@ extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
     HIPCHK(hipMemcpy(d_plan, &plan, sizeof(plan), hipMemcpyHostToDevice));
     v.plan = d_plan;
     DALLOC(e->d_p2i, 8); DALLOC(e->d_ok, 4);
+#ifdef AZG_TREE_TIMING
+    DALLOC(v.dbg, (size_t)v.B * 16);
+#endif
     *out = e;
     int r = azg_engine_reset(e, nullptr);
     if (r != AZG_OK) { azg_engine_destroy(e); *out = nullptr; return r; }
@@ -298,9 +301,10 @@ extern "C" int azg_backup_select(azg_engine *e, void *stream, const float *polic
     View v = e->v;
     if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
-    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select<G, float>), dim3(v.B), dim3(64), 0, s, v, policy, value, (float *)obs, row_of_slot)); }
-    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select<G, _Float16>), dim3(v.B), dim3(64), 0, s, v, policy, value, (_Float16 *)obs, row_of_slot)); }
-    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select<G, _Float16, true>), dim3(v.B), dim3(64), 0, s, v, policy, value, (_Float16 *)obs, row_of_slot)); }
+    const int A = e->gi.action_size;
+    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, float, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (float *)obs, row_of_slot, 1)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
+    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, true, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -316,9 +320,10 @@ extern "C" int azg_backup_select_logits(azg_engine *e, void *stream, const float
     View v = e->v;
     if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
-    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select_logits<G, float>), dim3(v.B), dim3(64), 0, s, v, logits, logits_stride, (float *)obs, row_of_slot, do_select)); }
-    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select_logits<G, _Float16>), dim3(v.B), dim3(64), 0, s, v, logits, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
-    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select_logits<G, _Float16, true>), dim3(v.B), dim3(64), 0, s, v, logits, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
+    const float *nov = nullptr;
+    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, float, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (float *)obs, row_of_slot, do_select)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
+    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, true, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -715,6 +720,15 @@ extern "C" int azg_tower_layout(int game, int boards_per_tile, int channels, int
 #undef AZG_LAYOUT
     return fail(AZG_E_UNSUPPORTED, "no tower instantiation for this (game, boards per tile, channels)");
 }
+
+#ifdef AZG_TREE_TIMING
+// measurement builds only (not part of include/azg.h): the s_memtime stamps [B][16] of every slot's last simulation
+extern "C" int azg_debug_tree_timing(azg_engine *e, unsigned long long *host) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host, e->v.dbg, sizeof(unsigned long long) * 16 * (size_t)e->v.B, hipMemcpyDeviceToHost));
+    return AZG_OK;
+}
+#endif
 
 extern "C" int azg_profile_enable(azg_engine *e, int on) {
     if (!e) return fail(AZG_E_INVALID_ARG, "null engine");

@@ -262,10 +262,10 @@ struct BR {
         const int cnt = __popc(mv);
         const int off = wave_excl_scan(cnt, lane);
         const int k = wave_sum_i(cnt);
-        __syncthreads();
+        wave_sync();
         int j = 0;
         for (unsigned m = mv; m; m &= m - 1) { if (off + j < MAXK) act_lds[off + j] = 12 * lane + (__ffs(m) - 1); j++; }
-        __syncthreads();
+        wave_sync();
         my_a[0] = lane < k ? act_lds[lane] : -1;
         my_a[1] = 64 + lane < k ? act_lds[64 + lane] : -1;
         return k < MAXK ? k : MAXK;

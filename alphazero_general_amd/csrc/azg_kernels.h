@@ -144,30 +144,31 @@ AZG_DEV int best_child(const View &ev, const Node *nodes, int fc, int k, const N
     return bi;
 }
 
-// One wavefront runs find_leaf (:208-228) for one slot; `sink(st, lane)` receives the leaf state (it writes the observation wherever
-// the network reads it: the dense batch in HBM for k_select, straight into the tower's LDS image for the fused search kernel).
+// One wavefront runs find_leaf (:208-228) for one tree whose header is already in registers; `sink(st, lane)` receives the leaf
+// state (it writes the observation wherever the network reads it: the dense batch in HBM for k_select, straight into the tower's
+// LDS image for the fused search kernel).  `gate(node)` is called before the child block of `node` is read (the two-wave launch
+// waits there for the priors the other wave is still writing); it returns true if the slot's tape counter must be re-read.
 // Dependent-load chain: header (the root is in it) -> one child block per level.
-template <class G, class Sink>
-AZG_DEV void select_slot(const View &ev, int slot, int lane, int *act_lds, Sink &&sink) {
+struct NoGate { AZG_DEV bool operator()(int) const { return false; } };
+template <class G, class Sink, class Gate>
+AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typename G::S st, uint64_t ctr, int lane, int *act_lds,
+                         Sink &&sink, Gate &&gate) {
     constexpr int NCH = (G::MAXK + 63) / 64;
-    int tree = slot;                                                         // (self-play: the header load does not wait for the state)
-    if (ev.arena) tree = slot * ev.T + __builtin_amdgcn_readfirstlane(ev.states[slot].player);
     TreeHdr *h = ev.hdr + tree;
-    HdrR hr; load_hdr(h, hr);
-    uint64_t ctr = ev.tape_ctr[slot];
-    typename G::S st = G::load(&ev.states[slot], lane);
     Node *nodes = tree_nodes(ev, tree, hr.base);
     PathEnt *path = ev.path + (size_t)tree * ev.maxd;
     int cur = LEAF_IS_ROOT;
     NodeR cn = hr.root;
     int depth = 0;
+    AZG_TSTAMP(ev, slot, lane, 4);
     while (cn.n > 0 && cn.e == 0 && depth < ev.maxd) {                       // MCTS.pyx:213
         const int k = cn.nchild, fc = cn.fc;
         if (k == 0 || fc < 0) { if (lane == 0) raise_error(ev, AZG_E_TREE_FULL); break; }
+        if (gate(cur)) ctr = ev.tape_ctr[slot];
         NodeR sel; int bi;
         if constexpr (NCH > 1) { bi = k > 64 ? best_child<G, NCH>(ev, nodes, fc, k, cn, lane, sel) : best_child<G, 1>(ev, nodes, fc, k, cn, lane, sel); }
         else bi = best_child<G, 1>(ev, nodes, fc, k, cn, lane, sel);
-        cur = fc + bi;
+        cur = __builtin_amdgcn_readfirstlane(fc + bi);
         if (lane == 0) {                                                     // the path entry carries the child's (n, q) for the backup
             uint4 ent = make_uint4((uint32_t)cur | ((uint32_t)cn.player << 28), (uint32_t)sel.n, __float_as_uint(sel.q), 0u);
             *reinterpret_cast<uint4 *>(path + depth) = ent;
@@ -178,6 +179,10 @@ AZG_DEV void select_slot(const View &ev, int slot, int lane, int *act_lds, Sink 
     }
     int expanded = 0;
     int alloc = hr.alloc;
+    AZG_TSTAMP(ev, slot, lane, 5);
+#ifdef AZG_TREE_TIMING
+    if (ev.dbg && lane == 0) ev.dbg[(size_t)slot * 16 + 15] = (unsigned long long)depth;
+#endif
     if (cn.n == 0) {                                                         // :223-226 expand
         const int e = G::win_bits(st);
         int my_a[NCH];
@@ -199,8 +204,24 @@ AZG_DEV void select_slot(const View &ev, int slot, int lane, int *act_lds, Sink 
         q[3] = make_uint4((unsigned)cur, (unsigned)cn.fc, (unsigned)cn.nchild | ((unsigned)cn.e << 16) | ((unsigned)cn.player << 24), (unsigned)expanded);
         ev.slot_exp[slot] += expanded;
     }
+    AZG_TSTAMP(ev, slot, lane, 6);
     G::store(st, &ev.leaf_states[slot], lane);
     sink(st, lane);
+    AZG_TSTAMP(ev, slot, lane, 7);
+}
+
+AZG_DEV int tree_of_slot(const View &ev, int slot) {                         // (self-play: the header load does not wait for the state)
+    int tree = slot;
+    if (ev.arena) tree = slot * ev.T + __builtin_amdgcn_readfirstlane(ev.states[slot].player);
+    return tree;
+}
+
+template <class G, class Sink>
+AZG_DEV void select_slot(const View &ev, int slot, int lane, int *act_lds, Sink &&sink) {
+    const int tree = tree_of_slot(ev, slot);
+    HdrR hr; load_hdr(ev.hdr + tree, hr);
+    const uint64_t ctr = ev.tape_ctr[slot];
+    select_tree<G>(ev, slot, tree, hr, G::load(&ev.states[slot], lane), ctr, lane, act_lds, sink, NoGate{});
 }
 
 template <class G, typename OT, bool NHWC8 = false>
@@ -231,10 +252,10 @@ AZG_DEV float masked_sum(const View &ev, const int (&ca)[NC], const float (&cp)[
         return s;
     } else {
         if (first) { for (int a = lane; a < A; a += 64) m_lds[a] = 0.f; }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int c = 0; c < NC; c++) if (ca[c] >= 0) m_lds[ca[c]] = cp[c];
-        __syncthreads();
+        wave_sync();
         return np_sum_wave(m_lds, ev.plan, scr, lane);
     }
 }
@@ -286,24 +307,32 @@ AZG_DEV void leaf_policy(const View &ev, int slot, Node *nodes, int fc, int k, b
     for (int c = 0; c < NC; c++) { int i = c * 64 + lane; if (i < k) nodes[fc + i].p = cp[c]; }      // update_policy :81-84
 }
 
-// One wavefront runs process_results (:230-289) for one slot with its policy row pi[A] and value row vrow[P+1] (HBM or LDS).
-// m_lds [max(A, 8)] and scr [64] are wave-private scratch (only used when A >= 8).  The header's leaf record and the (n, q)
-// snapshots in the path make this one level of loads (header, path, rows -- all independent; then the leaf's child actions).
+// process_results (:230-289) in two independent parts (they touch disjoint memory): the POLICY part writes the priors of the
+// freshly expanded leaf's children, the PATH part the running means along the path and the root count.  The header's leaf
+// record and the (n, q) snapshots in the path make each one level of loads.
 template <class G>
-AZG_DEV void backup_slot(const View &ev, int slot, int lane, const float *pi, const float *vrow, float *m_lds, float *scr) {
+AZG_DEV void backup_policy(const View &ev, int slot, const HdrR &hr, Node *nodes, const float *pi, float *m_lds, float *scr, int lane) {
     constexpr int NCH = (G::MAXK + 63) / 64;
+    if (hr.leaf_e || hr.leaf_fc < 0) return;                                 // :234-235 terminal: no policy update
+    const int k = hr.leaf_k, fc = hr.leaf_fc;
+    const bool at_root = hr.leaf == LEAF_IS_ROOT;
+    if constexpr (NCH > 1) {
+        if (k > 64) leaf_policy<G, NCH>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
+        else leaf_policy<G, 1>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
+    } else leaf_policy<G, 1>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
+}
+
+// vrow: the value row (P + 1 probabilities); returns the header as it stands after the backup (root.n + 1)
+template <class G>
+AZG_DEV void backup_path(const View &ev, int slot, int tree, HdrR &hr, Node *nodes, const float (&vrow)[G::P + 1], int lane) {
     constexpr int P = G::P, NV = P + 1, NE = P + G::HAS_DRAW;
-    int tree = slot;
-    if (ev.arena) tree = slot * ev.T + __builtin_amdgcn_readfirstlane(ev.states[slot].player);
     TreeHdr *h = ev.hdr + tree;
-    HdrR hr; load_hdr(h, hr);
     const PathEnt *path = ev.path + (size_t)tree * ev.maxd;
     const int depth = hr.depth;
     uint4 ent[(G::MAX_TURNS + 2 + 63) / 64];                                 // the path, one level per lane
 #pragma unroll
     for (int j0 = 0, c = 0; j0 < G::MAX_TURNS + 2; j0 += 64, c++)
         ent[c] = j0 + lane < depth ? *reinterpret_cast<const uint4 *>(path + j0 + lane) : make_uint4(0, 0, 0, 0);
-    Node *nodes = tree_nodes(ev, tree, hr.base);
     float val[NV > NE ? NV : NE];
     int vsize;
     if (hr.leaf_e) {                                                         // :234-235 terminal: value = float32(e)
@@ -314,14 +343,6 @@ AZG_DEV void backup_slot(const View &ev, int slot, int lane, const float *pi, co
 #pragma unroll
         for (int j = 0; j < NV; j++) val[j] = vrow[j];
         vsize = NV;
-        const int k = hr.leaf_k, fc = hr.leaf_fc;
-        const bool at_root = hr.leaf == LEAF_IS_ROOT;
-        if (fc >= 0) {
-            if constexpr (NCH > 1) {
-                if (k > 64) leaf_policy<G, NCH>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
-                else leaf_policy<G, 1>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
-            } else leaf_policy<G, 1>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
-        }
     }
     // ---- backup along the path (:265-287): X_j = path[j-1] node, mover = player of X_{j-1}; all levels independent
     const float draw_share = vsize > P ? (val[P] / ((float)P)) : 0.f;
@@ -346,7 +367,25 @@ AZG_DEV void backup_slot(const View &ev, int slot, int lane, const float *pi, co
             }
         }
     }
-    if (lane == 0) { h->root.n = hr.root.n + 1; ev.slot_sims[slot] += 1; }   // :289
+    hr.root.n += 1;
+    if (lane == 0) { h->root.n = hr.root.n; ev.slot_sims[slot] += 1; }       // :289
+}
+
+// One wavefront runs all of process_results for one slot with its policy row pi[A] and value row vrow[P+1] (HBM or LDS).
+// m_lds [max(A, 8)] and scr [64] are wave-private scratch (only used when A >= 8).
+template <class G>
+AZG_DEV void backup_slot(const View &ev, int slot, int lane, const float *pi, const float *vrow, float *m_lds, float *scr) {
+    const int tree = tree_of_slot(ev, slot);
+    HdrR hr; load_hdr(ev.hdr + tree, hr);
+    Node *nodes = tree_nodes(ev, tree, hr.base);
+    float val[G::P + 1];
+#pragma unroll
+    for (int j = 0; j < G::P + 1; j++) val[j] = hr.leaf_e ? 0.f : vrow[j];
+    AZG_TSTAMP(ev, slot, lane, 1);
+    backup_policy<G>(ev, slot, hr, nodes, pi, m_lds, scr, lane);
+    AZG_TSTAMP(ev, slot, lane, 2);
+    backup_path<G>(ev, slot, tree, hr, nodes, val, lane);
+    AZG_TSTAMP(ev, slot, lane, 3);
 }
 
 template <class G>
@@ -360,51 +399,68 @@ __global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, con
 }
 
 // backup of simulation k and find_leaf of simulation k + 1 of the same slot in one launch (they are consecutive in the lock-step
-// loop, SelfPlayAgent.pyx:87-92, and touch the same tree): one kernel boundary and one pass over the path's cache lines less.
-template <class G, typename OT, bool NHWC8 = false>
-__global__ __launch_bounds__(64) void k_backup_select(View ev, const float *policy, const float *value, OT *obs, const int32_t *row_of_slot) {
-    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
-    __shared__ float m_lds[G::A < 8 ? 8 : G::A];
+// loop, SelfPlayAgent.pyx:87-92, and touch the same tree), by TWO wavefronts per slot: wave 1 turns the network's row into the
+// priors of the leaf's children (softmax when handed logits, mask, renormalise, root temperature / noise) while wave 0 -- the
+// one that walks the tree -- updates the path and starts the next descent.  The only dependency is the priors themselves: wave 0
+// waits (the launch's single workgroup barrier) before it reads the child block of the node wave 1 is writing, i.e. when the
+// next descent walks into the previous leaf; otherwise the barrier is at the end.  Same arithmetic, same results.
+//   LOGITS: `policy` holds rows of stride `ld` with A policy logits then P + 1 value logits (as azg_policy_value_heads_f16 leaves
+//   them) instead of probabilities -- one launch and one HBM round trip of the probabilities less per simulation.
+template <class G, typename OT, bool NHWC8, bool LOGITS>
+__global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *policy, const float *value, int ld, OT *obs,
+                                                        const int32_t *row_of_slot, int do_select) {
+    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
+    constexpr int A = G::A, NV = G::P + 1;
+    __shared__ float m_lds[A < 8 ? 8 : A];
     __shared__ float scr[64];
     __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
-    const int slot = blockIdx.x;
+    __shared__ float pi_lds[LOGITS ? A : 1];
+    const int slot = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    AZG_TSTAMP(ev, slot, threadIdx.x, 8);
     const int row = row_of_slot ? row_of_slot[slot] : slot;
-    backup_slot<G>(ev, slot, threadIdx.x, policy + (size_t)row * G::A, value + (size_t)row * (G::P + 1), m_lds, scr);
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
-    select_slot<G>(ev, slot, threadIdx.x, act_lds, [&](const typename G::S &st, int lane) {
-        if (obs) {
-            if constexpr (NHWC8) G::write_obs_nhwc8(st, (_Float16 *)obs + (size_t)row * G::CELLS * 8, lane);
-            else G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);
+    const int tree = tree_of_slot(ev, slot);
+    HdrR hr; load_hdr(ev.hdr + tree, hr);
+    Node *nodes = tree_nodes(ev, tree, hr.base);
+    if (wave == 1) {                                                         // ---- the priors
+        if (!hr.leaf_e && hr.leaf_fc >= 0) {
+            const float *pi = policy + (size_t)row * ld;
+            if constexpr (LOGITS) { policy_softmax_row(pi, lane, A, pi_lds); wave_sync(); pi = pi_lds; }
+            backup_policy<G>(ev, slot, hr, nodes, pi, m_lds, scr, lane);
         }
-    });
-}
-
-// The same with the softmaxes of the wide heads folded in: the network hands over LOGITS rows (stride `ld`: A policy logits, then
-// P + 1 value logits, as azg_policy_value_heads_f16 leaves them in its workspace) and this wavefront turns its own row into
-// probabilities in LDS -- one launch and one HBM round trip of the probabilities less per simulation.  do_select = 0: backup only.
-template <class G, typename OT, bool NHWC8 = false>
-__global__ __launch_bounds__(64) void k_backup_select_logits(View ev, const float *logits, int ld, OT *obs, const int32_t *row_of_slot,
-                                                             int do_select) {
-    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
-    __shared__ float m_lds[G::A < 8 ? 8 : G::A];
-    __shared__ float scr[64];
-    __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
-    __shared__ float pi_lds[G::A], v_lds[G::P + 1];
-    const int slot = blockIdx.x;
-    const int row = row_of_slot ? row_of_slot[slot] : slot;
-    heads_softmax_row(logits + (size_t)row * ld, threadIdx.x, G::A, G::P + 1, pi_lds, v_lds);
-    __syncthreads();
-    backup_slot<G>(ev, slot, threadIdx.x, pi_lds, v_lds, m_lds, scr);
-    if (!do_select) return;
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
-    select_slot<G>(ev, slot, threadIdx.x, act_lds, [&](const typename G::S &st, int lane) {
-        if (obs) {
-            if constexpr (NHWC8) G::write_obs_nhwc8(st, (_Float16 *)obs + (size_t)row * G::CELLS * 8, lane);
-            else G::template write_obs<OT>(st, obs + (size_t)row * G::OBS, lane);
-        }
-    });
+        AZG_TSTAMP(ev, slot, lane, 9);
+        __syncthreads();
+        return;
+    }
+    const uint64_t ctr = ev.tape_ctr[slot];                                  // ---- the walk
+    typename G::S st = G::load(&ev.states[slot], lane);
+    float val[NV];
+    if constexpr (LOGITS) {
+        const float pv = value_softmax(policy + (size_t)row * ld + A, lane, NV);
+#pragma unroll
+        for (int j = 0; j < NV; j++) val[j] = rl(pv, j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; j++) val[j] = value[(size_t)row * NV + j];
+    }
+    const int prev_leaf = hr.leaf;
+    AZG_TSTAMP(ev, slot, lane, 1);
+    backup_path<G>(ev, slot, tree, hr, nodes, val, lane);
+    AZG_TSTAMP(ev, slot, lane, 3);
+    bool waited = false;
+    if (do_select) {
+        wave_sync();                                                         // the path stores land before the descent re-reads those nodes
+        select_tree<G>(ev, slot, tree, hr, st, ctr, lane, act_lds, [&](const typename G::S &ls, int ln) {
+            if (obs) {
+                if constexpr (NHWC8) G::write_obs_nhwc8(ls, (_Float16 *)obs + (size_t)row * G::CELLS * 8, ln);
+                else G::template write_obs<OT>(ls, obs + (size_t)row * G::OBS, ln);
+            }
+        }, [&](int node) {
+            if (waited || node != prev_leaf) return false;
+            __syncthreads(); waited = true;                                  // the previous leaf's priors are complete from here on
+            return node == LEAF_IS_ROOT;                                     // (root noise advanced the tape counter)
+        });
+    }
+    if (!waited) __syncthreads();
 }
 
 // ================================================================================================ root stats
@@ -413,14 +469,14 @@ template <class G>
 AZG_DEV void root_probs(const View &ev, const Node *nodes, int root_fc, int root_k, float temp, float *cnt, float *pr, float *scr, int lane) {
     constexpr int A = G::A;
     for (int a = lane; a < A; a += 64) cnt[a] = 0.f;
-    __syncthreads();
+    wave_sync();
     for (int i = lane; i < root_k; i += 64) cnt[nodes[root_fc + i].a] = (float)nodes[root_fc + i].n;    // counts :297-303
-    __syncthreads();
+    wave_sync();
     if (temp == 0.f) {                                                       // :313-317 one-hot first argmax
         float best = cnt[0]; int b = 0;
         for (int a = 1; a < A; a++) if (cnt[a] > best) { best = cnt[a]; b = a; }
         for (int a = lane; a < A; a += 64) pr[a] = a == b ? 1.f : 0.f;
-        __syncthreads();
+        wave_sync();
         return;
     }
     float s;
@@ -428,12 +484,12 @@ AZG_DEV void root_probs(const View &ev, const Node *nodes, int root_fc, int root
     else s = np_sum_wave(cnt, ev.plan, scr, lane);
     const double ex = 1.0 / (double)temp;
     for (int a = lane; a < A; a += 64) pr[a] = np_pow_f32(cnt[a] / s, ex);    // :320
-    __syncthreads();
+    wave_sync();
     float s2;
     if constexpr (A < 8) { s2 = 0.f; for (int a = 0; a < A; a++) s2 += pr[a]; }
     else s2 = np_sum_wave(pr, ev.plan, scr, lane);
     for (int a = lane; a < A; a += 64) pr[a] = pr[a] / s2;                    // :321
-    __syncthreads();
+    wave_sync();
 }
 
 template <class G>
@@ -448,7 +504,7 @@ __global__ __launch_bounds__(64) void k_root_stats(View ev, int what, float temp
     const int fc = hr.root.fc, k = hr.root.nchild;
     if (what == 0) {
         for (int a = lane; a < A; a += 64) counts[(size_t)slot * A + a] = 0;
-        __syncthreads();
+        wave_sync();
         for (int i = lane; i < k; i += 64) counts[(size_t)slot * A + nodes[fc + i].a] = nodes[fc + i].n;
     } else if (what == 1) {
         root_probs<G>(ev, nodes, fc, k, temp, cnt, pr, scr, lane);
@@ -483,7 +539,7 @@ AZG_DEV bool update_root(const View &ev, int slot, int tree, const typename G::S
         fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane);
         if (fc < 0) return false;
         if (lane == 0) { ev.tape_ctr[slot] = ctr; h->alloc = alloc; }
-        __syncthreads();
+        wave_sync();
     }
     int found = -1;
     for (int i0 = 0; i0 < k; i0 += 64) {
@@ -528,7 +584,7 @@ __global__ __launch_bounds__(64) void k_compact(View ev, int force) {
         for (int i = lane; i < k; i += 64) { uint4 lo, hi; load_node(from + hr.root.fc + i, lo, hi); uint4 *q = reinterpret_cast<uint4 *>(to + i); q[0] = lo; q[1] = hi; }
         nalloc = k;
     }
-    __syncthreads();
+    wave_sync();
     for (int scan = 0; scan < nalloc;) {                                     // nodes to[scan .. nalloc) still carry from-space child pointers
         const int end = min(scan + 64, nalloc), i = scan + lane;
         scan = end;
@@ -544,7 +600,7 @@ __global__ __launch_bounds__(64) void k_compact(View ev, int force) {
             for (int j = lane; j < sk; j += 64) { uint4 lo, hi; load_node(from + sfc + j, lo, hi); uint4 *q = reinterpret_cast<uint4 *>(to + dfc + j); q[0] = lo; q[1] = hi; }
         }
         nalloc += total;
-        __syncthreads();
+        wave_sync();
     }
     if (lane == 0) {
         if (hr.root.fc >= 0 && hr.root.nchild > 0) h->root.first_child = 0;
@@ -587,7 +643,7 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
         if (le) action = a + 1;
     }
     if (action >= A) action = A - 1;
-    __syncthreads();
+    wave_sync();
     if (lane == 0) { ev.tape_ctr[slot] = ctr + 1; ev.last_action[slot] = action; }
     if (record_history && !ev.arena && ev.max_hist > 0) {                                       // :161-165 history.append((clone, probs(T=1)))
         const int hl = __builtin_amdgcn_readfirstlane(ev.hist_len[slot]);
@@ -599,7 +655,7 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
             if (lane == 0) ev.hist_len[slot] = hl + 1;
         } else if (lane == 0) raise_error(ev, AZG_E_EXAMPLES_FULL);
     }
-    __syncthreads();
+    wave_sync();
     bool ok = true;                                                          // :167-170 update_root (every tree in arena)
     if (ev.arena) { for (int t = 0; t < ev.T; t++) ok = update_root<G>(ev, slot, slot * ev.T + t, st, action, act_lds, lane) && ok; }
     else ok = update_root<G>(ev, slot, tree, st, action, act_lds, lane);
