@@ -188,23 +188,32 @@ AZG_DEV uint64_t rl(uint64_t x, int lane) {
     c.i[0] = __builtin_amdgcn_readlane(c.i[0], lane); c.i[1] = __builtin_amdgcn_readlane(c.i[1], lane);
     return c.u;
 }
-AZG_DEV float wave_max(float m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    return m;
+// DPP lane permutations inside a row of 16 (no LDS crossbar, one VALU slot each): butterfly steps xor 1, xor 2, then the
+// half-row and row mirrors -- after the four every lane holds the reduction of its row of 16
+template <int CTRL> AZG_DEV int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false); }
+template <int CTRL> AZG_DEV float dpp_f(float x) { return __int_as_float(dpp_i<CTRL>(__float_as_int(x))); }
+enum { DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140, DPP_WAVE_ROR1 = 0x13C };
+AZG_DEV float wave_max(float m) {                              // every lane returns the maximum over the 64 lanes
+    m = fmaxf(m, dpp_f<DPP_QUAD_XOR1>(m)); m = fmaxf(m, dpp_f<DPP_QUAD_XOR2>(m));
+    m = fmaxf(m, dpp_f<DPP_ROW_HALF_MIRROR>(m)); m = fmaxf(m, dpp_f<DPP_ROW_MIRROR>(m));
+    return fmaxf(fmaxf(rl(m, 0), rl(m, 16)), fmaxf(rl(m, 32), rl(m, 48)));
 }
-// max over lanes [0, N) only (N a power of two <= 64; the other lanes must hold -inf or be ignored by the caller):
-// log2(N) butterfly steps instead of 6 -- the connect4 child block is 7 wide
+// max over lanes [0, N) only (N a power of two <= 64; the other lanes must hold -inf or be ignored by the caller)
 template <int N> AZG_DEV float wave_max_n(float m) {
-#pragma unroll
-    for (int o = N / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    return rl(m, 0);
+    m = fmaxf(m, dpp_f<DPP_QUAD_XOR1>(m)); m = fmaxf(m, dpp_f<DPP_QUAD_XOR2>(m));
+    if (N > 4) m = fmaxf(m, dpp_f<DPP_ROW_HALF_MIRROR>(m));
+    if (N > 8) m = fmaxf(m, dpp_f<DPP_ROW_MIRROR>(m));
+    float r = rl(m, 0);
+    if (N > 16) r = fmaxf(r, rl(m, 16));
+    if (N > 32) r = fmaxf(fmaxf(r, rl(m, 32)), rl(m, 48));
+    return r;
 }
-AZG_DEV int wave_sum_i(int m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
-    return m;
+AZG_DEV int wave_sum_i(int m) {                                // every lane returns the sum over the 64 lanes
+    m += dpp_i<DPP_QUAD_XOR1>(m); m += dpp_i<DPP_QUAD_XOR2>(m); m += dpp_i<DPP_ROW_HALF_MIRROR>(m); m += dpp_i<DPP_ROW_MIRROR>(m);
+    return (rl(m, 0) + rl(m, 16)) + (rl(m, 32) + rl(m, 48));
 }
+// number of set bits of a wave ballot below this lane (v_mbcnt: two VALU slots)
+AZG_DEV int lanes_below(uint64_t ballot) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0u)); }
 // Ordering point between the lanes of ONE wavefront (every tree function is one wave working on wave-private LDS and on its own
 // tree in HBM): earlier LDS / global accesses of the wave have completed before later ones start.  No s_barrier: the functions
 // can be called by several waves of a workgroup independently (the two-wave tree launch, the persistent search kernel).

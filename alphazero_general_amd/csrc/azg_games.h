@@ -244,30 +244,44 @@ struct BR {
         if (s.kc || !att_has) return 1;               // defenders (player 0) win: result[2 - 2]
         return 0;
     }
-    // Game.valid_moves (fastafl.pyx:171-178) + Board.legal_moves (cengine.pyx:109-132): ascending action list in LDS
+    // cells of a 7-cell line (bit p = the piece's own position) a sliding piece at p reaches: the runs of passable cells on
+    // both sides of p (Board.legal_moves walks them square by square, cengine.pyx:109-132)
+    static AZG_DEV unsigned reach7(unsigned line, int p) {
+        const unsigned up = line >> (p + 1);                                  // cells above p, bit 0 = p + 1
+        const unsigned run = (unsigned)__builtin_ctz(~up);                    // trailing ones (a 7-bit line: ~up is never 0)
+        const unsigned reach_up = ((1u << run) - 1u) << (p + 1);
+        const unsigned below = (1u << p) - 1u, blk = ~line & below;           // blockers below p
+        const unsigned cut = blk ? (2u << (31 - __builtin_clz(blk))) : 1u;    // first bit above the highest blocker
+        return reach_up | (line & below & ~(cut - 1u));
+    }
+    // Game.valid_moves (fastafl.pyx:171-178) + Board.legal_moves (cengine.pyx:109-132): ascending action list in LDS.
+    // Branch-free per lane: the row of the passable mask and (through the transposed board) its column are 7-bit lines, the
+    // reachable runs come from count-trailing-ones / count-leading-zeros, the move types from two shifts; the list offsets
+    // from twelve ballots (v_mbcnt) instead of a wave scan.
     static AZG_DEV int valid_list(const S &s, int lane, int *act_lds, int (&my_a)[2]) {
         const int team = 2 - (s.turns & 1);                                                  // Board.to_play :330-331
         const bool mine = lane < CELLS && (team == 1 ? is_att(s.cell) : s.cell == 2);
         const bool king = is_king(s.cell);
-        const uint64_t E = mask_eq(s, lane, 0), T = mask_eq(s, lane, 4), X = mask_eq(s, lane, 5);
-        const uint64_t pass = E | T | (king ? X : 0ULL);                                      // the ray continues over these
         const int x = lane % 7, y = lane / 7;
-        unsigned mv = 0;                                                                     // bit = move_type (0..11)
-        if (mine) {
-            for (int ny = y + 1; ny <= 6; ny++) { const int t = ny * 7 + x; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << (ny - 1); }
-            for (int ny = y - 1; ny >= 0; ny--) { const int t = ny * 7 + x; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << ny; }
-            for (int nx = x + 1; nx <= 6; nx++) { const int t = y * 7 + nx; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << (6 + nx - 1); }
-            for (int nx = x - 1; nx >= 0; nx--) { const int t = y * 7 + nx; if (!((pass >> t) & 1)) break; if (!((T >> t) & 1)) mv |= 1u << (6 + nx); }
-        }
-        const int cnt = __popc(mv);
-        const int off = wave_excl_scan(cnt, lane);
-        const int k = wave_sum_i(cnt);
-        wave_sync();
+        const int cellT = __shfl(s.cell, lane < CELLS ? x * 7 + y : 0);                      // the transposed board
+        const uint64_t E = mask_eq(s, lane, 0), T = mask_eq(s, lane, 4), X = mask_eq(s, lane, 5);
+        const uint64_t Et = __ballot(lane < CELLS && cellT == 0), Tt = __ballot(lane < CELLS && cellT == 4), Xt = __ballot(lane < CELLS && cellT == 5);
+        const uint64_t pass = E | T | (king ? X : 0ULL), passT = Et | Tt | (king ? Xt : 0ULL);     // the ray continues over these
+        const unsigned row = (unsigned)(pass >> (7 * y)) & 0x7Fu, col = (unsigned)(passT >> (7 * x)) & 0x7Fu;
+        const unsigned trow = (unsigned)(T >> (7 * y)) & 0x7Fu, tcol = (unsigned)(Tt >> (7 * x)) & 0x7Fu;
+        const unsigned rx = reach7(row, x) & ~trow, ry = reach7(col, y) & ~tcol;             // nobody lands on the empty throne
+        // move_type (fastafl.pyx:66-79): vertical ny -> ny or ny - 1, horizontal nx -> 6 + nx or 6 + nx - 1
+        const unsigned mvy = (ry & ((1u << y) - 1u)) | ((ry >> (y + 1)) << y), mvx = (rx & ((1u << x) - 1u)) | ((rx >> (x + 1)) << x);
+        const unsigned mv = mine ? (mvy | (mvx << 6)) : 0u;                                  // bit = move_type (0..11)
+        int off = 0, k = 0;
+#pragma unroll
+        for (int b = 0; b < 12; b++) { const uint64_t bal = __ballot((mv >> b) & 1u); off += lanes_below(bal); k += __popcll(bal); }
         int j = 0;
         for (unsigned m = mv; m; m &= m - 1) { if (off + j < MAXK) act_lds[off + j] = 12 * lane + (__ffs(m) - 1); j++; }
         wave_sync();
         my_a[0] = lane < k ? act_lds[lane] : -1;
         my_a[1] = 64 + lane < k ? act_lds[64 + lane] : -1;
+        wave_sync();
         return k < MAXK ? k : MAXK;
     }
     // Game.observation (fastafl.pyx:84-121,205-211): planes [black(2), white(1), king, to-move colour, 0] (Q18)

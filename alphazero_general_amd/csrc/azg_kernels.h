@@ -59,27 +59,38 @@ AZG_DEV void init_tree(const View &ev, int tree, int lane) {           // MCTS._
 // Node.add_children (:76-79): k stubs appended to the tree's live space, list order = ascending (tape key, index).
 // my_a[c] = action of child index c*64+lane (ascending action order), NC = chunks of 64 children actually in use.  `alloc` is the
 // arena cursor held by the caller; returns first_child (or -1 on overflow) and advances `alloc`; the caller stores it.
-template <class G, int NC>
-AZG_DEV int add_children(const View &ev, int slot, Node *nodes, int &alloc, int k, const int (&my_a)[(G::MAXK + 63) / 64], uint64_t &ctr, int lane) {
+// rank of child i among the k shuffled children = number of (key, index) pairs below its own
+struct NoRanks { AZG_DEV bool operator()(int, int, int &) const { return false; } };
+template <class G, int NC, class Ranks>
+AZG_DEV int add_children(const View &ev, int slot, Node *nodes, int &alloc, int k, const int (&my_a)[(G::MAXK + 63) / 64], uint64_t &ctr, int lane,
+                         Ranks &&ranks) {
     const int fc = alloc;
     if (fc + k > ev.cap) { if (lane == 0) raise_error(ev, AZG_E_TREE_FULL); return -1; }
-    uint64_t key[NC];
+    int pos[NC];
+    if (!(NC == 1 && ranks(k, lane, pos[0]))) {                              // (the two-wave launch has them ready)
+        uint64_t key[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) key[c] = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr + (uint64_t)(c * 64 + lane));
+        for (int c = 0; c < NC; c++) key[c] = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr + (uint64_t)(c * 64 + lane));
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            int i = c * 64 + lane, pc = 0;
+#pragma unroll
+            for (int c2 = 0; c2 < NC; c2++) {
+                int lim = min(64, k - c2 * 64);
+                for (int j = 0; j < lim; j++) {
+                    uint64_t kj = rl(key[c2], j);
+                    int jj = c2 * 64 + j;
+                    pc += (kj < key[c] || (kj == key[c] && jj < i)) ? 1 : 0;
+                }
+            }
+            pos[c] = pc;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        int i = c * 64 + lane, pos = 0;
-#pragma unroll
-        for (int c2 = 0; c2 < NC; c2++) {
-            int lim = min(64, k - c2 * 64);
-            for (int j = 0; j < lim; j++) {
-                uint64_t kj = rl(key[c2], j);
-                int jj = c2 * 64 + j;
-                pos += (kj < key[c] || (kj == key[c] && jj < i)) ? 1 : 0;
-            }
-        }
+        const int i = c * 64 + lane;
         if (i < k) {
-            uint4 *q = reinterpret_cast<uint4 *>(nodes + fc + pos);
+            uint4 *q = reinterpret_cast<uint4 *>(nodes + fc + pos[c]);
             q[0] = make_uint4(0, 0, 0, 0);
             q[1] = pack_hi(-1, my_a[c], 0, 0, 0);
         }
@@ -88,11 +99,26 @@ AZG_DEV int add_children(const View &ev, int slot, Node *nodes, int &alloc, int 
     ctr += (uint64_t)k;                                     // (no global high-water atomic here: 2048 waves on one word cost ~20 us)
     return fc;
 }
-template <class G>
-AZG_DEV int add_children_any(const View &ev, int slot, Node *nodes, int &alloc, int k, const int (&my_a)[(G::MAXK + 63) / 64], uint64_t &ctr, int lane) {
+template <class G, class Ranks>
+AZG_DEV int add_children_any(const View &ev, int slot, Node *nodes, int &alloc, int k, const int (&my_a)[(G::MAXK + 63) / 64], uint64_t &ctr, int lane,
+                             Ranks &&ranks) {
     constexpr int NCH = (G::MAXK + 63) / 64;
-    if constexpr (NCH > 1) { if (k > 64) return add_children<G, NCH>(ev, slot, nodes, alloc, k, my_a, ctr, lane); }
-    return add_children<G, 1>(ev, slot, nodes, alloc, k, my_a, ctr, lane);
+    if constexpr (NCH > 1) { if (k > 64) return add_children<G, NCH>(ev, slot, nodes, alloc, k, my_a, ctr, lane, NoRanks{}); }
+    return add_children<G, 1>(ev, slot, nodes, alloc, k, my_a, ctr, lane, ranks);
+}
+
+// For lane i: the set of j in [0, 64) whose (tape key, index) pair sorts below (key_i, i), keys of counters ctr .. ctr + 63.
+// The rank of child i among k <= 64 children is then popcount(mask & ((1 << k) - 1)): the all-pairs part of the shuffle does
+// not depend on k, so it can be prepared before the leaf is known.
+AZG_DEV uint64_t shuffle_less_mask(const View &ev, int slot, uint64_t ctr, int lane) {
+    const uint64_t key = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr + (uint64_t)lane);
+    uint64_t less = 0;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        const uint64_t kj = rl(key, j);
+        less |= (uint64_t)((kj < key || (kj == key && j < lane)) ? 1 : 0) << j;
+    }
+    return less;
 }
 
 // ================================================================================================ select
@@ -108,6 +134,7 @@ AZG_DEV int best_child(const View &ev, const Node *nodes, int fc, int k, const N
         if (i < k) load_node(nodes + fc + i, lo[c], hi[c]);
         else { lo[c] = make_uint4(0, 0, 0, 0); hi[c] = make_uint4(0, 0, 0, 0); }
     }
+    AZG_TSTAMP(ev, blockIdx.x, lane, 10);
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         int i = c * 64 + lane;
@@ -150,9 +177,9 @@ AZG_DEV int best_child(const View &ev, const Node *nodes, int fc, int k, const N
 // waits there for the priors the other wave is still writing); it returns true if the slot's tape counter must be re-read.
 // Dependent-load chain: header (the root is in it) -> one child block per level.
 struct NoGate { AZG_DEV bool operator()(int) const { return false; } };
-template <class G, class Sink, class Gate>
+template <class G, class Sink, class Gate, class Ranks>
 AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typename G::S st, uint64_t ctr, int lane, int *act_lds,
-                         Sink &&sink, Gate &&gate) {
+                         Sink &&sink, Gate &&gate, Ranks &&ranks) {
     constexpr int NCH = (G::MAXK + 63) / 64;
     TreeHdr *h = ev.hdr + tree;
     Node *nodes = tree_nodes(ev, tree, hr.base);
@@ -174,7 +201,9 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
             *reinterpret_cast<uint4 *>(path + depth) = ent;
         }
         cn = sel;
+        AZG_TSTAMP(ev, slot, lane, 11);
         G::play(st, cn.a);                                                   // :216
+        AZG_TSTAMP(ev, slot, lane, 12);
         depth++;
     }
     int expanded = 0;
@@ -187,7 +216,9 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
         const int e = G::win_bits(st);
         int my_a[NCH];
         const int k = G::valid_list(st, lane, act_lds, my_a);
-        const int fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane);
+        AZG_TSTAMP(ev, slot, lane, 13);
+        const int fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane, ranks);
+        AZG_TSTAMP(ev, slot, lane, 14);
         cn.fc = fc; cn.nchild = fc < 0 ? 0 : k; cn.player = st.player; cn.e = e;
         if (lane == 0) {
             ev.tape_ctr[slot] = ctr;
@@ -221,7 +252,7 @@ AZG_DEV void select_slot(const View &ev, int slot, int lane, int *act_lds, Sink 
     const int tree = tree_of_slot(ev, slot);
     HdrR hr; load_hdr(ev.hdr + tree, hr);
     const uint64_t ctr = ev.tape_ctr[slot];
-    select_tree<G>(ev, slot, tree, hr, G::load(&ev.states[slot], lane), ctr, lane, act_lds, sink, NoGate{});
+    select_tree<G>(ev, slot, tree, hr, G::load(&ev.states[slot], lane), ctr, lane, act_lds, sink, NoGate{}, NoRanks{});
 }
 
 template <class G, typename OT, bool NHWC8 = false>
@@ -398,12 +429,17 @@ __global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, con
     backup_slot<G>(ev, slot, threadIdx.x, policy + (size_t)row * G::A, value + (size_t)row * (G::P + 1), m_lds, scr);
 }
 
+// hand-off flags between the two wavefronts of a slot (LDS, workgroup-scope release / acquire)
+AZG_DEV void flag_set(int *f, int lane) { if (lane == 0) __hip_atomic_store(f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AZG_DEV void flag_wait(int *f) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1); }
+
 // backup of simulation k and find_leaf of simulation k + 1 of the same slot in one launch (they are consecutive in the lock-step
-// loop, SelfPlayAgent.pyx:87-92, and touch the same tree), by TWO wavefronts per slot: wave 1 turns the network's row into the
-// priors of the leaf's children (softmax when handed logits, mask, renormalise, root temperature / noise) while wave 0 -- the
-// one that walks the tree -- updates the path and starts the next descent.  The only dependency is the priors themselves: wave 0
-// waits (the launch's single workgroup barrier) before it reads the child block of the node wave 1 is writing, i.e. when the
-// next descent walks into the previous leaf; otherwise the barrier is at the end.  Same arithmetic, same results.
+// loop, SelfPlayAgent.pyx:87-92, and touch the same tree), by TWO wavefronts per slot.  Wave 0 walks the tree: path update of
+// simulation k, then the descent and expansion of simulation k + 1.  Wave 1 prepares what the walk will need: (1) the priors of
+// the previous leaf's children from the network's row (softmax when handed logits, mask, renormalise, root temperature / noise),
+// (2) the shuffle of the next expansion -- the all-pairs comparison of the next 64 tape keys, which does not depend on which
+// leaf gets expanded.  The walk waits for (1) only if the descent enters the previous leaf, and for (2) when it expands.
+// Same arithmetic as the one-wave functions, same results.
 //   LOGITS: `policy` holds rows of stride `ld` with A policy logits then P + 1 value logits (as azg_policy_value_heads_f16 leaves
 //   them) instead of probabilities -- one launch and one HBM round trip of the probabilities less per simulation.
 template <class G, typename OT, bool NHWC8, bool LOGITS>
@@ -415,24 +451,35 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     __shared__ float scr[64];
     __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
     __shared__ float pi_lds[LOGITS ? A : 1];
+    __shared__ unsigned long long less_lds[64];
+    __shared__ int flags[2];                                                 // 0: priors written, 1: shuffle masks ready
     const int slot = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     AZG_TSTAMP(ev, slot, threadIdx.x, 8);
+    if (threadIdx.x < 2) flags[threadIdx.x] = 0;
     const int row = row_of_slot ? row_of_slot[slot] : slot;
     const int tree = tree_of_slot(ev, slot);
     HdrR hr; load_hdr(ev.hdr + tree, hr);
+    const uint64_t ctr0 = ev.tape_ctr[slot];
     Node *nodes = tree_nodes(ev, tree, hr.base);
-    if (wave == 1) {                                                         // ---- the priors
-        if (!hr.leaf_e && hr.leaf_fc >= 0) {
+    const bool has_policy = !hr.leaf_e && hr.leaf_fc >= 0;
+    const bool root_noise = has_policy && hr.leaf == LEAF_IS_ROOT && ev.add_noise;     // the backup draws one tape number
+    __syncthreads();
+    if (wave == 1) {                                                         // ---- what the walk will need
+        if (has_policy) {
             const float *pi = policy + (size_t)row * ld;
             if constexpr (LOGITS) { policy_softmax_row(pi, lane, A, pi_lds); wave_sync(); pi = pi_lds; }
             backup_policy<G>(ev, slot, hr, nodes, pi, m_lds, scr, lane);
         }
+        flag_set(&flags[0], lane);
         AZG_TSTAMP(ev, slot, lane, 9);
-        __syncthreads();
+        if (do_select) {
+            less_lds[lane] = shuffle_less_mask(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+            flag_set(&flags[1], lane);
+        }
+        AZG_TSTAMP(ev, slot, lane, 0);
         return;
     }
-    const uint64_t ctr = ev.tape_ctr[slot];                                  // ---- the walk
-    typename G::S st = G::load(&ev.states[slot], lane);
+    typename G::S st = G::load(&ev.states[slot], lane);                      // ---- the walk
     float val[NV];
     if constexpr (LOGITS) {
         const float pv = value_softmax(policy + (size_t)row * ld + A, lane, NV);
@@ -446,21 +493,24 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     AZG_TSTAMP(ev, slot, lane, 1);
     backup_path<G>(ev, slot, tree, hr, nodes, val, lane);
     AZG_TSTAMP(ev, slot, lane, 3);
+    if (!do_select) return;
+    wave_sync();                                                             // the path stores land before the descent re-reads those nodes
     bool waited = false;
-    if (do_select) {
-        wave_sync();                                                         // the path stores land before the descent re-reads those nodes
-        select_tree<G>(ev, slot, tree, hr, st, ctr, lane, act_lds, [&](const typename G::S &ls, int ln) {
-            if (obs) {
-                if constexpr (NHWC8) G::write_obs_nhwc8(ls, (_Float16 *)obs + (size_t)row * G::CELLS * 8, ln);
-                else G::template write_obs<OT>(ls, obs + (size_t)row * G::OBS, ln);
-            }
-        }, [&](int node) {
-            if (waited || node != prev_leaf) return false;
-            __syncthreads(); waited = true;                                  // the previous leaf's priors are complete from here on
-            return node == LEAF_IS_ROOT;                                     // (root noise advanced the tape counter)
-        });
-    }
-    if (!waited) __syncthreads();
+    select_tree<G>(ev, slot, tree, hr, st, ctr0, lane, act_lds, [&](const typename G::S &ls, int ln) {
+        if (obs) {
+            if constexpr (NHWC8) G::write_obs_nhwc8(ls, (_Float16 *)obs + (size_t)row * G::CELLS * 8, ln);
+            else G::template write_obs<OT>(ls, obs + (size_t)row * G::OBS, ln);
+        }
+    }, [&](int node) {                                                       // before the child block of `node` is read
+        if (waited || node != prev_leaf) return false;
+        flag_wait(&flags[0]); waited = true;                                 // the previous leaf's priors are complete from here on
+        return root_noise;                                                   // (the tape counter moved)
+    }, [&](int k, int ln, int &pos) {                                        // ranks of the k new children
+        if (k > 64) return false;
+        flag_wait(&flags[1]);
+        pos = __popcll(less_lds[ln] & (k == 64 ? ~0ULL : ((1ULL << k) - 1ULL)));
+        return true;
+    });
 }
 
 // ================================================================================================ root stats
@@ -536,7 +586,7 @@ AZG_DEV bool update_root(const View &ev, int slot, int tree, const typename G::S
         k = G::valid_list(st, lane, act_lds, my_a);
         uint64_t ctr = ev.tape_ctr[slot];
         int alloc = hr.alloc;
-        fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane);
+        fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane, NoRanks{});
         if (fc < 0) return false;
         if (lane == 0) { ev.tape_ctr[slot] = ctr; h->alloc = alloc; }
         wave_sync();

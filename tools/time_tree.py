@@ -4,7 +4,7 @@
     AZG_LIB_PATH=gpurun_out/libazg_timing.so python tools/time_tree.py [brandubh|trimok]
 
 Stamps (shader cycles, last simulation of every slot).  Walk wave: 8 entry, 1 header / path / value row landed, 3 path stores
-issued, 4 descent starts, 5 descent done, 6 expansion done, 7 leaf stored.  Prior wave: 9 = softmax + leaf policy done."""
+issued, 4 descent starts, 5 descent done, 6 expansion done, 7 leaf stored.  Prior wave: 9 = softmax + leaf policy done, 0 = shuffle masks ready."""
 import ctypes as C
 import importlib
 import os
@@ -30,7 +30,7 @@ L = _abi.lib()
 L.azg_debug_tree_timing.argtypes = [C.c_void_p, C.c_void_p]
 names = ['loads', 'path stores', 'fence', 'descent', 'expansion', 'leaf store']
 order = [8, 1, 3, 4, 5, 6, 7]
-acc = np.zeros(len(names)); tot = 0.0; dep = 0.0; n = 0; w1 = 0.0
+acc = np.zeros(len(names)); tot = 0.0; dep = 0.0; n = 0; w1 = 0.0; w0 = 0.0; extra = {}; nx = 0
 ln, e = r.lanes[0], r.engine
 for rnd in range(8):
     r.play_round()                                               # (advance the games: realistic trees)
@@ -44,6 +44,17 @@ for rnd in range(8):
         t = buf[:, order].astype(np.int64)
         d = np.diff(t, axis=1)
         ok = (d >= 0).all(axis=1) & (t[:, 0] > 0) & (t[:, -1] - t[:, 0] < 200000)
+        b = buf.astype(np.int64)
+        okx = ok & (b[:, 15] >= 1) & (b[:, 10] < b[:, 11]) & (b[:, 11] < b[:, 12]) & (b[:, 12] <= b[:, 5]) & (b[:, 13] > b[:, 5]) & (b[:, 14] > b[:, 13])
+        for nm, (i0, i1) in {'last level: block load': (4, 10), 'last level: best_child': (10, 11), 'last level: play': (11, 12),
+                             'expansion: win + valid list': (5, 13), 'expansion: add_children': (13, 14), 'expansion: header stores': (14, 6)}.items():
+            if nm == 'last level: block load':
+                sel = okx & (b[:, 15] == 1)
+                extra[nm + ' (depth-1 slots)'] = extra.get(nm + ' (depth-1 slots)', 0.0) + (b[sel, i1] - b[sel, i0]).sum() * (okx.sum() / max(sel.sum(), 1))
+            else:
+                extra[nm] = extra.get(nm, 0.0) + (b[okx, i1] - b[okx, i0]).sum()
+        nx += okx.sum()
+        w0 += (buf[ok, 0].astype(np.int64) - t[ok, 0]).sum()
         w1 += (buf[ok, 9].astype(np.int64) - t[ok, 0]).sum(); acc += d[ok].sum(0); tot += (t[ok, -1] - t[ok, 0]).sum(); dep += buf[ok, 15].astype(np.float64).sum(); n += ok.sum()
     e.backup_select_logits(ln.net.run_logits(), None, select=False)
     e.advance(True)
@@ -51,4 +62,7 @@ print('%s: %d samples, mean depth %.2f, shader cycles per phase:' % (game, n, de
 for nm, v in zip(names, acc / n):
     print('  %-14s %8.1f' % (nm, v))
 print('  %-14s %8.1f' % ('total (walk)', tot / n))
-print('  %-14s %8.1f' % ('prior wave', w1 / n))
+print('  %-14s %8.1f' % ('priors ready', w1 / n))
+print('  %-14s %8.1f' % ('shuffle ready', w0 / n))
+for k_, v_ in sorted(extra.items()):
+    print('  %-28s %8.1f' % (k_, v_ / max(nx, 1)))
