@@ -128,10 +128,31 @@ class SelfPlayRunner:
             with torch.cuda.stream(ln.stream):
                 self._step_lane(ln)
 
+    def _issue_round(self, ln, sims, fast):
+        """The launch sequence of one whole round of a lane: sims x (find_leaf, network, process_results) + playMoves, with
+        backup k and select k + 1 sharing a launch (or the whole loop in one persistent launch)."""
+        e = ln.engine
+        if self.fused_search:
+            self.nnet._hip.search(e, sims)
+            e.advance(record_history=not fast)
+            return
+        e.select(ln.obs)
+        logits_path = not self.warmup and ln.net.run_logits is not None    # wide heads: softmax inside the tree launch
+        for i in range(sims):                                    # backup k and select k + 1 share a launch
+            if logits_path:
+                e.backup_select_logits(ln.net.run_logits(), ln.obs, select=i + 1 < sims)
+                continue
+            p, v = (ln.policy, ln.value) if self.warmup else ln.net.run()
+            if i + 1 < sims:
+                e.backup_select(p, v, ln.obs)
+            else:
+                e.backup(p, v)
+        e.advance(record_history=not fast)
+
     def _round_graph(self, ln, sims, fast):
-        """One whole round of a lane -- sims x (select, network, backup) + advance -- as ONE hipGraph: every launch is
-        stream-ordered and nothing is read on the host, so the host issues one replay per move instead of 3 calls per
-        simulation (the small configs are otherwise bound by host launch rate, not by the GPU)."""
+        """One whole round of a lane as ONE hipGraph: every launch is stream-ordered and nothing is read on the host, so the
+        host issues one replay per move instead of 3 calls per simulation (the small configs are otherwise bound by host
+        launch rate, not by the GPU)."""
         key = (sims, fast)
         if key not in ln.round_graphs:
             e = ln.engine
@@ -140,24 +161,7 @@ class SelfPlayRunner:
             torch.cuda.synchronize(e.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
-                if self.fused_search:
-                    self.nnet._hip.search(e, sims)
-                    e.advance(record_history=not fast)
-                    sims = 0
-                else:
-                    e.select(ln.obs)
-                logits_path = not self.warmup and ln.net.run_logits is not None    # wide heads: softmax inside the tree launch
-                for i in range(sims):                                # backup k and select k + 1 share a launch
-                    if logits_path:
-                        e.backup_select_logits(ln.net.run_logits(), ln.obs, select=i + 1 < sims)
-                        continue
-                    p, v = (ln.policy, ln.value) if self.warmup else ln.net.run()
-                    if i + 1 < sims:
-                        e.backup_select(p, v, ln.obs)
-                    else:
-                        e.backup(p, v)
-                if not self.fused_search:
-                    e.advance(record_history=not fast)
+                self._issue_round(ln, sims, fast)
             ln.round_graphs[key] = g
         return ln.round_graphs[key]
 
@@ -174,9 +178,14 @@ class SelfPlayRunner:
                         self._round_graph(ln, sims, fast)
         return self
 
-    def play_round(self):
+    def play_round(self, eager=False):
+        """eager=True issues the captured launch sequence as plain launches (measurement: events between the launches)."""
         sims, fast = self._sims_for_round()
-        if self.round_graph and not any(getattr(ln.engine, 'profiling', False) for ln in self.lanes):
+        if self.round_graph and eager:
+            for ln in self.lanes:
+                with torch.cuda.stream(ln.stream), torch.no_grad():
+                    self._issue_round(ln, sims, fast)
+        elif self.round_graph and not any(getattr(ln.engine, 'profiling', False) for ln in self.lanes):
             for ln in self.lanes:
                 with torch.cuda.stream(ln.stream):
                     self._round_graph(ln, sims, fast).replay()
@@ -377,9 +386,12 @@ class ArenaRunner:
             self._round_device_split(int(self.args.get('numMCTSSims', 100)))
         self._graph = g
 
-    def play_round(self):
+    def play_round(self, eager=False):
         if self.device_split and self._graph is not None:
-            self._graph.replay()
+            if eager:
+                self._round_device_split(int(self.args.get('numMCTSSims', 100)))
+            else:
+                self._graph.replay()
             return
         for _ in range(int(self.args.get('numMCTSSims', 100))):
             self.step()

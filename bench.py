@@ -1,13 +1,21 @@
-"""bench.py -- self-play throughput of the MI355X engine on BASELINE.json's headline config.
+"""bench.py -- self-play throughput of the MI355X engine on BASELINE.json's configurations.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--workload connect4|brandubh|arena|trimok] --gpus N --steps K --warmup W
 
-Workload (config.workload): connect4, 2048 concurrent games per GPU x 100 MCTS sims per move, fp16 ResNet 128ch x 8
-(envs/connect4/train.py net + search hyper-parameters), random-init weights, games from the empty board, root noise +
-root temperature on, probFastSim = 0.  One "step" = one self-play round of the hot path over
-the whole batch: 100 x [select -> network -> backup] + advance, i.e. 204 800 simulations per GPU.  value = MCTS node
-expansions per second summed over all GPUs (games/s is reported next to it).  Everything is resident in HBM; the
-only host traffic in the timed region is one 40-byte counter read per round.
+Default workload = the headline config (BASELINE.json configs[1]): connect4, 2048 concurrent games per GPU x 100 MCTS sims per
+move, fp16 ResNet 128ch x 8 (envs/connect4/train.py net + search hyper-parameters), random-init weights, games from the empty
+board, root noise + root temperature on, probFastSim = 0.  The other workloads are configs 3-5 at their
+per-GPU size.  One "step" = one self-play round of the hot path over the whole batch: sims x [find_leaf -> network ->
+process_results] + playMoves.  value = MCTS node expansions per second summed over all GPUs (games/s next to it).  Everything is
+resident in HBM; the only host traffic in the timed region is one counter read per run.
+
+N > 1: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run, one per GPU, RCCL); under an external
+torch.distributed.run it uses the ranks it was given.  n_gpus in the output is the number of ranks that actually ran.
+
+Measured inside the run (HIP events on the launch stream, one eagerly launched round in the middle of the timed region):
+`roofline` = the dominant kernel of a simulation step, `tree_roofline` = the tree launch.  `traffic` (HBM bytes per launch) comes
+from the committed rocprofv3 --pmc summary profiles/r02_pmc.json (tools/collect_profiles.py, run on the GPU box), never from a
+constant in this file.  `cpu_baseline` (rank 0, N = 1 only) = the C oracle on the host cores, bounded sample.
 """
 import argparse
 import json
@@ -24,240 +32,151 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from alphazero_general_amd import distributed as D  # noqa: E402
-from alphazero_general_amd.envs.connect4 import Game  # noqa: E402
-from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper  # noqa: E402
-from alphazero_general_amd.selfplay import SelfPlayRunner  # noqa: E402
+from alphazero_general_amd import nnet as nn_mod  # noqa: E402
+from alphazero_general_amd.nnet import HipResNet, NNetWrapper  # noqa: E402
+from alphazero_general_amd.selfplay import ArenaRunner, SelfPlayRunner  # noqa: E402
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
-B_PER_GPU, SIMS = 2048, 100
-NN_REPS = 8                                                           # back-to-back tower launches timed by one event pair
-# algorithmic figures (DESIGN.md "Roofline"): bytes one simulation moves through the tree kernels / FLOPs per leaf
-C4_SELECT_BYTES_PER_SIM = 5 * (32 + 7 * 32) + (32 + 7 * 32) + 2 * 80 + 336 + 5 * 4   # D=5 levels read, expand write, states, fp16 obs, path
-C4_BACKUP_BYTES_PER_SIM = 7 * 4 + 12 + 7 * 4 + 5 * (4 + 16) + 32
-C4_NET_FLOPS_PER_LEAF = 205e6
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
-TOWER_TRAFFIC_BYTES = 50850000   # PMC per launch @2048 boards, (2 x FETCH_SIZE + WRITE_SIZE) KB (profiles/r01_pmc_summary.csv, rows
-                                 # tower2_r1c): 43 MB fetched at the L2 <-> fabric boundary = the 4.7 MB weight stream once per XCD
-                                 # (8 x 4.7 = 38 MB; Infinity-Cache hits are counted) + inputs, 6.4 MB written (52 B/lane of spills)
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
+CALIBRATION_FILE = os.path.join(ROOT, 'profiles', 'cpu_oracle_vs_reference.json')
+
+# name: game module, net args, games / GPU, sims / move, cpuct, fpu reduction, typical (children, depth) of the tree bytes model
+WORKLOADS = {
+    'connect4': dict(game='connect4', net='CONNECT4_NET_ARGS', B=2048, sims=100, cpuct=4.0, fpu=0.4, kbar=7, depth=5, oracle_game=0),
+    'brandubh': dict(game='brandubh', net='BRANDUBH_NET_ARGS', B=512, sims=200, cpuct=1.25, fpu=0.2, kbar=40, depth=4, oracle_game=1),
+    'trimok': dict(game='trimok', net='DEFAULT_NET_ARGS', B=256, sims=50, cpuct=1.25, fpu=0.2, kbar=20, depth=4, oracle_game=2),
+    'arena': dict(game='connect4', net='CONNECT4_NET_ARGS', B=256, sims=100, cpuct=4.0, fpu=0.4, kbar=7, depth=5, oracle_game=0),
+}
 
 
-SEARCH_TRAFFIC_BYTES = 7169000000  # one azg_search_f16 launch, 2048 games x 100 sims
-
-
-def selfplay_args(games):
-    return dotdict(cpuct=4.0, fpu_reduction=0.4, root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0,
-                   numMCTSSims=SIMS, numFastSims=20, numWarmupSims=5, probFastSim=0.0, gamesPerIteration=games,
+def selfplay_args(W, games=1 << 30):
+    return dotdict(cpuct=W['cpuct'], fpu_reduction=W['fpu'], root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0,
+                   numMCTSSims=W['sims'], numFastSims=20, numWarmupSims=5, probFastSim=0.0, gamesPerIteration=games,
                    add_root_noise=True, add_root_temp=True, symmetricSamples=True, mctsResetThreshold=None,
                    startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
 
 
-def library_gemm_tflops(dev, n=8192, reps=10):
-    """fp16 n^3 GEMM through torch (hipBLASLt), TFLOP/s."""
-    x = torch.randn(n, n, device=dev, dtype=torch.float16); y = torch.randn(n, n, device=dev, dtype=torch.float16)
-    best = 0.0
-    for _ in range(2):
-        for _ in range(3):
-            x @ y
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            x @ y
-        e1.record(); torch.cuda.synchronize()
-        best = max(best, 2 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12)
-    return best
+# ---------------------------------------------------------------------------------------------- algorithmic figures
+def net_flops_per_leaf(game_cls, a):
+    """FLOPs of one evaluation of the reference's ResNet (NNetArchitecture.py:69-120), 2 per multiply-add: stem + 2 convs per
+    block + the two 1x1 head convs + the dense chains (205 MFLOP for connect4 128ch x 8)."""
+    C, H, W = game_cls.observation_size()
+    hw, ch = H * W, a.num_channels
+    f = 2 * 9 * C * ch * hw + a.depth * 2 * (2 * 9 * ch * ch * hw)
+    for heads, dense, out in ((a.value_head_channels, a.value_dense_layers, game_cls.num_players() + game_cls.has_draw()),
+                              (a.policy_head_channels, a.policy_dense_layers, game_cls.action_size())):
+        f += 2 * ch * heads * hw
+        sizes = [hw * heads] + list(dense) + [out]
+        f += sum(2 * sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
+    return float(f)
 
 
-def cpu_baseline_threads(net, threads=16, seconds=6.0):
-    """The reference's own arrangement (Coach.py:291-342): `workers` agent processes, each searching its batch of games
-    on one host core, all of them queueing on ONE GPU network.  Here: `threads` oracle agents on `threads` host cores
-    (the C oracle runs outside the GIL), 256 games each, the GPU net behind a lock.  Bounded sample."""
-    import threading
-    import oracle_lib as ol
-    Bc = 256
-    threads = max(1, min(threads, (os.cpu_count() or 1) - 2))
-    lock = threading.Lock()
-    agents = [ol.OAgent(0, Bc, sims=SIMS, games_per_iteration=1 << 30, seed=100 + i, cpuct=4.0, fpu_reduction=0.4,
-                        add_root_noise=True, add_root_temp=True) for i in range(threads)]
-    stop = time.time() + seconds
-
-    def work(ag):
-        while time.time() < stop:
-            ag.begin_round()
-            for s in range(SIMS):
-                obs, _, _ = ag.generate_batch()
-                with lock:
-                    p, v = net.process(torch.from_numpy(obs))
-                    p, v = p.cpu().numpy(), v.cpu().numpy()
-                ag.process_batch(p, v)
-            ag.play_moves()
-
-    t0 = time.time()
-    ts = [threading.Thread(target=work, args=(ag,)) for ag in agents]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    dt = time.time() - t0
-    total = sum(ag.expansions for ag in agents)
-    return {'value': round(total / dt, 1), 'unit': 'expansions/s', 'cores': threads,
-            'sample': '%d oracle agents x %d games x %d sims on %d host cores for %.1f s, one shared GPU net' % (threads, Bc, SIMS, threads, dt)}
+def tree_bytes_per_sim(game_cls, W):
+    """Algorithmic bytes one simulation moves through the tree launch (SURVEY.md 8d formula with this build's 32-byte node records,
+    64-byte tree header, 16-byte path entries): find_leaf = header + D child blocks read + one child block written + root and leaf
+    state (2 x 80) + the fp16 NHWC8 observation + D path entries; process_results = header + policy and value row + k priors
+    written + D x (path entry read + (n, q) written)."""
+    k, Dp = W['kbar'], W['depth']
+    C, H, Wd = game_cls.observation_size()
+    A, NV = game_cls.action_size(), game_cls.num_players() + 1
+    select = 64 + Dp * k * 32 + (32 + k * 32) + 2 * 80 + H * Wd * 16 + Dp * 16
+    backup = 64 + 4 * (A + NV) + 4 * k + k * 2 + Dp * (16 + 8) + 12
+    return select, backup
 
 
-def cpu_tree_only_threads(threads=64, seconds=4.0):
-    """Tree-only leg on many host cores (BASELINE.md section 3 variant i): warm-up evaluator semantics -- uniform policy and
-    value (SelfPlayAgent.pyx:48-52,111-114) -- so only select / expand / backup / playMoves run; one oracle agent of 256 games
-    per thread, no shared resource."""
-    import threading
-    import oracle_lib as ol
-    Bc = 256
-    threads = max(1, min(threads, (os.cpu_count() or 1) - 2))
-    agents = [ol.OAgent(0, Bc, sims=SIMS, games_per_iteration=1 << 30, seed=200 + i, cpuct=4.0, fpu_reduction=0.4,
-                        add_root_noise=True, add_root_temp=True) for i in range(threads)]
-    pol = np.full((Bc, 7), 1 / 7, np.float32); val = np.full((Bc, 3), 1 / 3, np.float32)
-    stop = time.time() + seconds
-
-    L = ol.lib()
-
-    def work(ag):
-        obs = np.zeros((Bc, ag.O), np.float32); rg = np.zeros(Bc, np.int32); rm = np.zeros(Bc, np.int32)   # (preallocated: the
-        while time.time() < stop:                                    #  threads only meet at the GIL between C calls)
-            ag.begin_round()
-            for s in range(SIMS):
-                L.azo_agent_generate_batch(ag.h, obs, rg, rm)
-                L.azo_agent_process_batch(ag.h, pol, val)
-            ag.play_moves()
-
-    t0 = time.time()
-    ts = [threading.Thread(target=work, args=(ag,)) for ag in agents]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    dt = time.time() - t0
-    return {'value': round(sum(ag.expansions for ag in agents) / dt, 1), 'unit': 'expansions/s', 'cores': threads,
-            'sample': '%d oracle agents x %d games x %d sims, uniform evaluator, %.1f s' % (threads, Bc, SIMS, dt)}
-
-
-def cpu_baseline(net, seconds=12.0):
-    """The CPU path timed beside the GPU number: the C oracle (bit-exact restatement of the reference Cython path,
-    oracle/) drives the same workload on ONE host core, leaves evaluated by the same GPU network through host
-    buffers (the reference's own arrangement, Coach.py:337-342).  Bounded sample."""
-    import oracle_lib as ol
-    Bc = 256
-    ag = ol.OAgent(0, Bc, sims=SIMS, games_per_iteration=1 << 30, seed=1, cpuct=4.0, fpu_reduction=0.4,
-                   add_root_noise=True, add_root_temp=True)
-    t_tree = t_all = 0.0
-    sims_done = 0
-    t_start = time.time()
-    while time.time() - t_start < seconds:
-        ag.begin_round()
-        for s in range(SIMS):
-            t0 = time.time()
-            obs, _, _ = ag.generate_batch()
-            t1 = time.time()
-            p, v = net.process(torch.from_numpy(obs))
-            p, v = p.cpu().numpy(), v.cpu().numpy()
-            t2 = time.time()
-            ag.process_batch(p, v)
-            t3 = time.time()
-            t_tree += (t1 - t0) + (t3 - t2); t_all += t3 - t0
-            sims_done += Bc
-        t0 = time.time(); ag.play_moves(); dt = time.time() - t0
-        t_tree += dt; t_all += dt
-    many = cpu_baseline_threads(net)
-    tree_many = cpu_tree_only_threads()
-    return {'value': round(ag.expansions / t_all, 1), 'unit': 'expansions/s', 'cores': 1, 'kind': 'port', 'many_cores': many, 'tree_only_many_cores': tree_many,
-            'sample': 'connect4 %d games x %d sims, %d simulations in %.1f s on one host core, leaves evaluated by the same GPU net '
-                      'through host buffers' % (Bc, SIMS, sims_done, t_all),
-            'tree_only_value': round(ag.expansions / t_tree, 1), 'host_cpus': os.cpu_count(),
-            # BASELINE.md section 3 calibration, measured in the build container (same core for both; the reference cannot travel):
-            'vs_reference_cython': 'tree-only, connect4 256 games x 100 sims, one core: C oracle 201.6 k sims/s, reference Cython '
-                                   'MCTS/SelfPlayAgent 8.2 k sims/s -> the port is 24.6x the reference'}
-
-
-WORKLOADS = {
-    # name: (game module, net args, games/GPU, sims, cpuct, fpu)   -- BASELINE.json configs 2..5 (SURVEY.md 8d)
-    'connect4': ('connect4', 'CONNECT4_NET_ARGS', 2048, 100, 4.0, 0.4),
-    'brandubh': ('brandubh', 'BRANDUBH_NET_ARGS', 512, 200, 1.25, 0.2),
-    'trimok': ('trimok', 'DEFAULT_NET_ARGS', 256, 50, 1.25, 0.2),
-    'arena': ('connect4', 'CONNECT4_NET_ARGS', 256, 100, 4.0, 0.4),
-}
-
-
-# algorithmic bytes one simulation moves through the tree kernels (SURVEY.md 8d formula with 32-B node records):
-# D*(32 + k*32) select reads + (32 + k*32) expansion writes + 2*80 states + fp16 obs + D*4 path ; backup: 4*A + 4*(P+1) + 4*k + D*20 + 32
-TREE_BYTES = {'brandubh': (4 * (32 + 40 * 32) + (32 + 40 * 32) + 160 + 49 * 16 + 16, 4 * 588 + 12 + 160 + 80 + 32),
-              'trimok': (4 * (32 + 20 * 32) + (32 + 20 * 32) + 160 + 25 * 16 + 16, 4 * 25 + 16 + 80 + 80 + 32)}
-
-
-def tree_roofline_other(workload, prof, B):
-    if prof is None or workload not in TREE_BYTES or not prof['select_n']:
+def load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
-    sb, bb = TREE_BYTES[workload]
-    sel_us = prof['select_ms'] * 1e3 / prof['select_n']; bak_us = prof['backup_ms'] * 1e3 / max(prof['backup_n'], 1)
-    g = sb * B / (sel_us * 1e-6) / 1e9
-    return {'kernel': 'k_select<%s>' % {'brandubh': 'BR', 'trimok': 'TM'}[workload], 'bound': 'hbm', 'achieved': round(g, 2), 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(g / HBM_PEAK_GBS, 6), 'avg_launch_us': round(sel_us, 2), 'algorithmic_bytes_per_launch': sb * B,
-            'backup_us': round(bak_us, 2), 'backup_GBps': round(bb * B / (bak_us * 1e-6) / 1e9, 2), 'traffic': None}
 
 
-def run_other_workload(a, rank, local_rank, world):
-    """configs 3-5: not the headline bench line; same timing protocol, reported with their own config.workload."""
-    import importlib
-    from alphazero_general_amd import nnet as nn_mod
-    from alphazero_general_amd.selfplay import ArenaRunner
-    gmod, netargs, B, sims, cpuct, fpu = WORKLOADS[a.workload]
-    B = a.slots or B
-    Game_ = importlib.import_module('alphazero_general_amd.envs.' + gmod).Game
-    dev = torch.device('cuda', local_rank)
-    args = selfplay_args(1 << 30)
-    args.update(cpuct=cpuct, fpu_reduction=fpu, numMCTSSims=sims)
-    if a.workload == 'arena':
-        nets = []
-        for sd in (0, 1):                                            # two differently seeded random-init nets
-            torch.manual_seed(sd)
-            nets.append(NNetWrapper(Game_, getattr(nn_mod, netargs), device=dev, dtype=torch.float16))
-        runner = ArenaRunner(Game_, nets, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
-                             result_capacity=B * (a.steps + a.warmup + 8) // 5 + 2 * B)
-        counters = lambda: runner.engine.counters()
-    else:
-        torch.manual_seed(0)
-        net = NNetWrapper(Game_, getattr(nn_mod, netargs), device=dev, dtype=torch.float16)
-        per_game = (Game_.max_turns() + 1) * len(Game_().symmetries(np.zeros(Game_.action_size(), np.float32)))
-        runner = SelfPlayRunner(Game_, net, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
-                                example_capacity=int(B * (a.steps + a.warmup + 4) / 5.0 + 2 * B) * per_game)
-        counters = lambda: runner.counters()
-    if hasattr(runner, 'prepare'):
-        runner.prepare()                                             # graph capture stays out of the timed region even at --warmup 0
-    for _ in range(a.warmup):
-        runner.play_round()
-    c0 = counters()
-    D.barrier(); torch.cuda.synchronize()
-    t0 = time.time()
-    prof = None
-    eng = getattr(runner, 'engine', None)
-    for k in range(a.steps):
-        timed = a.workload != 'arena' and eng is not None and k == a.steps // 2      # one eagerly launched round with HIP events
-        if timed:
-            torch.cuda.synchronize(); eng.profile(True)
-        runner.play_round()
-        if timed:
-            prof = eng.profile_read(); eng.profile(False)
-    c1 = counters()
-    torch.cuda.synchronize(); D.barrier()
-    dt = D.max_over_ranks(time.time() - t0)
-    tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'], c1['games_played'] - c0['games_played']])
-    if rank == 0:
-        exp, sm, gm = [int(x) for x in tall]
-        print(json.dumps({'metric': 'mcts_node_expansions_per_sec', 'value': round(exp / dt, 1), 'unit': 'expansions/s',
-                          'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
-                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net',
-                          'data': 'synthetic', 'games_per_sec': round(gm / dt, 2), 'simulations_per_sec': round(sm / dt, 1),
-                          'config': {'workload': '%s, %d games/GPU x %d sims/move, net %s' % (a.workload, B, sims, netargs)},
-                          'tree_roofline': tree_roofline_other(a.workload, prof, B)}))
+def measured_traffic(workload, kernel_substr):
+    """HBM bytes per launch of a kernel from the committed PMC summary (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes;
+    MI355X_MICROARCH.md 'HBM': FETCH_SIZE counts half the bytes of wide loads on gfx950).  None when no profile is committed."""
+    pmc = load_json(PMC_FILE)
+    if not pmc:
+        return None, None
+    for name, rec in pmc.get('workloads', {}).get(workload, {}).items():
+        if kernel_substr in name:
+            return int(rec['traffic_bytes']), 'profiles/r02_pmc.json @%s (%d dispatches)' % (pmc.get('git', '?'), rec.get('dispatches', 0))
+    return None, None
 
 
+# ---------------------------------------------------------------------------------------------- CPU baseline (rank 0, N = 1)
+def cpu_baseline(W, nets, arena=False, budget_s=24.0):
+    """The CPU path timed beside the GPU number: the C oracle -- the bit-exact restatement of the reference's
+    Cython MCTS / SelfPlayAgent, oracle/ -- with one agent per host core (oracle/azg_pool_ref.c: the reference's `workers`
+    processes, Coach.py:291-342), same game, network and search parameters, same number of concurrent games.
+      end to end: every simulation step the agents' leaves form ONE batch evaluated by the same GPU network through host
+                  buffers (the reference's arrangement, Coach.py:337-342), so only where the tree lives differs;
+      tree only : the warm-up evaluator's uniform policy / value (SelfPlayAgent.pyx:48-52), agents free-running.
+    Thread counts from all host cores downwards are sampled for ~2 s each and the best is reported (`cores` = threads used)."""
+    import oracle_lib as ol
+    ncpu = os.cpu_count() or 1
+    G, games, sims = W['oracle_game'], W['B'], W['sims']
+    kw = dict(sims=sims, games_per_iteration=1 << 30, seed=1, cpuct=W['cpuct'], fpu_reduction=W['fpu'], add_root_noise=not arena,
+              add_root_temp=not arena, is_arena=arena)
+    net = nets[0]
+
+    def evaluate(pool, obs):
+        if not arena:
+            p, v = net.process(torch.from_numpy(obs))
+            return p.cpu().numpy(), v.cpu().numpy()
+        rm = pool.row_models()                                       # every model evaluates its own rows (Arena.pyx:262-281)
+        p = np.zeros((obs.shape[0], pool.A), np.float32); v = np.zeros((obs.shape[0], pool.NV), np.float32)
+        for m, nn_ in enumerate(nets):
+            idx = np.flatnonzero(rm == m)
+            if len(idx):
+                pm, vm = nn_.process(torch.from_numpy(obs[idx]))
+                p[idx], v[idx] = pm.cpu().numpy(), vm.cpu().numpy()
+        return p, v
+
+    counts = sorted({max(1, min(n, games)) for n in (ncpu, ncpu // 2, ncpu // 4, 32, 8)}, reverse=True)
+    per = max(1.5, budget_s / (2 * len(counts) + 1))
+    best_e2e, best_tree, tried = None, None, []
+    for n in counts:
+        Bc = (games + n - 1) // n                                    # games per agent: the config's concurrent games spread over n cores
+        pool = ol.OPool(G, n, Bc, **kw)
+        # ---- end to end ----
+        t0 = time.time(); e0 = pool.expansions
+        while time.time() - t0 < per:
+            pool.begin_round()
+            for _ in range(sims):
+                p, v = evaluate(pool, pool.generate())
+                pool.process(p, v)
+            pool.play()
+        dt = time.time() - t0
+        e2e = (pool.expansions - e0) / dt
+        # ---- tree only ----
+        e1 = pool.expansions
+        dt2 = pool.run_tree_only(per)
+        tree = (pool.expansions - e1) / dt2
+        tried.append({'threads': n, 'games_per_thread': Bc, 'end_to_end': round(e2e, 1), 'tree_only': round(tree, 1)})
+        if best_e2e is None or e2e > best_e2e[0]:
+            best_e2e = (e2e, n, Bc, dt)
+        if best_tree is None or tree > best_tree[0]:
+            best_tree = (tree, n, Bc, dt2)
+        del pool
+    # one core, as the per-core figure
+    one = ol.OPool(G, 1, min(games, 256), **kw)
+    dt1 = one.run_tree_only(per)
+    tree1 = one.expansions / dt1
+    out = {'value': round(best_e2e[0], 1), 'unit': 'expansions/s', 'cores': best_e2e[1], 'kind': 'port', 'host_cpus': ncpu,
+           'sample': '%s%s: %d oracle agents x %d games x %d sims/move on %d host threads for %.1f s, leaves of all agents evaluated as one '
+                     'batch by the same GPU net(s) through host buffers' % (W['game'], ' arena' if arena else '', best_e2e[1], best_e2e[2], sims, best_e2e[1], best_e2e[3]),
+           'tree_only': {'value': round(best_tree[0], 1), 'cores': best_tree[1], 'per_core_1_thread': round(tree1, 1),
+                         'sample': '%d agents x %d games, uniform evaluator, free-running for %.1f s' % (best_tree[1], best_tree[2], best_tree[3])},
+           'thread_counts_tried': tried}
+    cal = load_json(CALIBRATION_FILE)
+    if cal:
+        out['vs_reference_cython'] = cal                             # BASELINE.md section 3 calibration (tools/calibrate_oracle.py)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- launcher
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL), same
     arguments; rank 0 of the child job prints the JSON line.  Returns the job's exit code."""
@@ -267,6 +186,11 @@ def self_launch(n):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode
+
+
+def event_stats(pairs):
+    ms = [a.elapsed_time(b) for a, b in pairs]
+    return (sum(ms) / len(ms) * 1e3, len(ms)) if ms else (None, 0)
 
 
 def main():
@@ -290,127 +214,143 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (there is no CPU fallback)'
     if not os.environ.get('AZG_SINGLE_DEVICE'):
         assert torch.cuda.device_count() >= world, '%d ranks but only %d visible GPU(s)' % (world, torch.cuda.device_count())
-    a.gpus = world                                                    # n_gpus in the output = the ranks actually initialised
     torch.cuda.set_device(local_rank)
-    if a.workload != 'connect4':
-        return run_other_workload(a, rank, local_rank, world)
     dev = torch.device('cuda', local_rank)
-    torch.manual_seed(0)                                            # same random-init weights on every rank
-    B = a.slots or B_PER_GPU
-    net = NNetWrapper(Game, CONNECT4_NET_ARGS, device=dev, dtype=torch.float16)
-    games = 1 << 30
-    per_game = 43 * 2
-    runner = SelfPlayRunner(Game, net, selfplay_args(games), num_slots=B, seed=0, slot_base=D.slot_base(rank, B),
-                            device=local_rank, use_graph=not a.no_graph, pipelines=a.pipelines, fused_search=False if (a.no_fused_search or a.pipelines > 1) else None,
-                            example_capacity=int(B * (a.steps + a.warmup + 8) / 7.0 + 2 * B) * per_game)
-    eng = runner.engine
-    lanes = runner.lanes
-    runner.prepare()                                                 # graph capture stays out of the timed region even at --warmup 0
+
+    import importlib
+    W = dict(WORKLOADS[a.workload])
+    B = W['B'] = a.slots or W['B']
+    sims = W['sims']
+    Game = importlib.import_module('alphazero_general_amd.envs.' + W['game']).Game
+    netargs = getattr(nn_mod, W['net'])
+    arena = a.workload == 'arena'
+    args = selfplay_args(W)
+    nsym = len(Game().symmetries(np.zeros(Game.action_size(), np.float32)))
+    rounds = a.steps + a.warmup + 8
+    if arena:
+        nets = []
+        for sd in (0, 1):                                            # two differently seeded random-init nets (SURVEY.md 8d config 4)
+            torch.manual_seed(sd)
+            nets.append(NNetWrapper(Game, netargs, device=dev, dtype=torch.float16))
+        net = nets[0]
+        runner = ArenaRunner(Game, nets, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
+                             use_graph=not a.no_graph, result_capacity=B * rounds // 5 + 2 * B)
+        engines = [runner.engine]
+        counters = runner.engine.counters
+        fused_search = False
+    else:
+        torch.manual_seed(0)                                         # same random-init weights on every rank
+        net = NNetWrapper(Game, netargs, device=dev, dtype=torch.float16)
+        per_game = (Game.max_turns() + 1) * nsym
+        runner = SelfPlayRunner(Game, net, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
+                                use_graph=not a.no_graph, pipelines=a.pipelines,
+                                fused_search=False if (a.no_fused_search or a.pipelines > 1) else None,
+                                example_capacity=int(B * rounds / 5.0 + 2 * B) * per_game)
+        engines = [ln.engine for ln in runner.lanes]
+        counters = runner.counters
+        fused_search = bool(runner.fused_search)
+        runner.prepare()                                             # graph capture stays out of the timed region even at --warmup 0
+    hipnet = net._hip is not None
     for _ in range(a.warmup):
         runner.play_round()
-    c0 = runner.counters()
-    ex0 = [ln.engine.counters()['num_examples'] for ln in lanes]
-    ev_nn, ev_search = [], []
+    c0 = counters()
+    ex0 = [e.counters()['num_examples'] for e in engines] if not arena else None
+    net_events, search_events, prof = [], [], None
     D.barrier(); torch.cuda.synchronize()
     t0 = time.time()
     for k in range(a.steps):
-        if k == a.steps // 2:                                       # HIP-event timing of the kernels for ONE round
-            torch.cuda.synchronize()
-            if runner.use_graph:                                    # (events around every launch perturb the pipeline)
-                with torch.cuda.stream(lanes[0].stream):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    for _ in range(8):                               # warm launch path and clocks (a short burst after a pause
-                        lanes[0].net.replay()                        #  runs at boost clock: 0.24 ms instead of the sustained 0.28)
-                    e0.record()
-                    for _ in range(NN_REPS):
-                        lanes[0].net.replay()
-                    e1.record(); ev_nn.append((e0, e1))
-                torch.cuda.synchronize()
-            eng.profile(True)
-        if runner.fused_search and k == a.steps // 2 + 1:           # HIP events around ONE search launch (= all simulations of a move)
-            with torch.cuda.stream(lanes[0].stream):
-                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s0.record(); net._hip.search(eng, SIMS); s1.record()
-                eng.advance(True)
-            runner.sims_per_round.append(SIMS); runner._actr += 1    # (probFastSim = 0: the agent-level coin of this round is unused)
-            ev_search.append((s0, s1))
-        else:
+        timed = a.pipelines == 1 and (k == a.steps // 2 or (fused_search and k == a.steps // 2 + 1))
+        if not timed:
             runner.play_round()
-        if k == a.steps // 2:
-            prof = eng.profile_read()
-            eng.profile(False)
-    c1 = runner.counters()
-    # the exchange step of an iteration: all-gather the example shards (RCCL) + tallies
-    obs, pi, z = runner.samples(ex0)
-    gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
+            continue
+        # an eagerly launched round with HIP events (on the launch stream) around every launch: the same launch sequence the
+        # graph replays.  With the persistent search launch: one such round, then one round of the two-launches-per-simulation
+        # form of the same move loop, which shows the tree launch and the tower launch on their own
+        torch.cuda.synchronize()
+        second = fused_search and k == a.steps // 2 + 1
+        if second:
+            runner.fused_search = False
+        engines[0].profile(True); HipResNet.timer = search_events if (fused_search and not second) else net_events
+        runner.play_round(eager=True)
+        HipResNet.timer = None
+        if second or not fused_search:
+            prof = engines[0].profile_read()
+        engines[0].profile(False)
+        if second:
+            runner.fused_search = True
+    c1 = counters()
+    nsamples = 0
+    if not arena:                                                    # the exchange step of an iteration: all-gather the example shards
+        obs, pi, z = runner.samples(ex0)
+        gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
+        nsamples = gobs.shape[0]
     torch.cuda.synchronize(); D.barrier()
     dt = D.max_over_ranks(time.time() - t0)
     tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'],
-                                 c1['games_played'] - c0['games_played'], gobs.shape[0] if rank == 0 else 0])
+                                 c1['games_played'] - c0['games_played'], nsamples if rank == 0 else 0])
     if rank != 0:
-        return
-    expansions, sims, games_done, nsamples = [int(x) for x in tall]
-    sel_us = prof['select_ms'] * 1e3 / max(prof['select_n'], 1)
-    bak_us = prof['backup_ms'] * 1e3 / max(prof['backup_n'], 1)
-    adv_us = prof['advance_ms'] * 1e3 / max(prof['advance_n'], 1)
-    Bl = B // a.pipelines                                           # slots per launch
-    sel_gbs = C4_SELECT_BYTES_PER_SIM * Bl / (sel_us * 1e-6) / 1e9
-    nn_ms = ev_nn[0][0].elapsed_time(ev_nn[0][1]) / NN_REPS if ev_nn else None
-    tree = {'kernel': 'k_select<C4>', 'bound': 'hbm', 'achieved': round(sel_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(sel_gbs / HBM_PEAK_GBS, 6),
-            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_tree.py):
-            # 2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE, profiles/r01_pmc_summary.csv; 2048-slot launch only
-            'traffic': 5995000 if Bl == 2048 else None, 'avg_launch_us': round(sel_us, 2),
-            'algorithmic_bytes_per_launch': C4_SELECT_BYTES_PER_SIM * Bl,
-            'backup_us': round(bak_us, 2), 'advance_us': round(adv_us, 2),
-            'backup_GBps': round(C4_BACKUP_BYTES_PER_SIM * Bl / (bak_us * 1e-6) / 1e9, 2)}
-    if nn_ms is not None:
-        # the dominant kernel of the step (~94 % of the time): the network tower + heads, ONE launch (k_tower2), MFMA-bound
-        tf = C4_NET_FLOPS_PER_LEAF * Bl / (nn_ms * 1e-3) / 1e12
-        roof = {'kernel': 'k_tower2<6,7,4> (ResNet 128ch x 8 tower + heads, one launch per evaluation)', 'bound': 'mfma',
-                'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4),
-                'avg_launch_us': round(nn_ms * 1e3, 1), 'algorithmic_flops_per_launch': C4_NET_FLOPS_PER_LEAF * Bl,
-                # HBM bytes per launch (PMC, profiles/r01_pmc_summary.csv): weights + input planes + probabilities
-                'traffic': TOWER_TRAFFIC_BYTES if Bl == 2048 else None}
+        return 0
+    expansions, nsims, games_done, nsamples = [int(x) for x in tall]
+    Bl = B // a.pipelines                                            # slots per launch
+
+    # ---- roofline of the network launch (MFMA) and of the tree launch (HBM), from the eager rounds' events
+    flops_leaf = net_flops_per_leaf(Game, net.args)
+
+    def mfma_roof(events, kname, kmatch, units):
+        us, n = event_stats(events)
+        if not us:
+            return None
+        tf = flops_leaf * units / (us * 1e-6) / 1e12
+        traffic, src = measured_traffic(a.workload, kmatch)
+        return {'kernel': kname, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
+                'algorithmic_flops_per_launch': flops_leaf * units, 'traffic': traffic, 'traffic_source': src}
+
+    roof_search = mfma_roof(search_events, 'k_tower2<6,7,4,128,1,SearchArgs<C4>> (azg_search_f16: %d x [find_leaf, ResNet + heads, backup] on '
+                            'every game, one persistent launch per move)' % sims, 'SearchArgs', Bl * sims)
+    roof_net = mfma_roof(net_events, 'k_tower2 (%s, one launch per simulation)' % ('both models on their row ranges' if arena else 'ResNet tower'
+                                                                                     + ('' if net._hip is None or net._hip.wide_head else ' + heads')),
+                         'NoSearch', Bl)
+    if roof_net is not None and not hipnet:
+        roof_net['kernel'] = 'network through PyTorch / MIOpen (no MFMA tower instantiated for this shape)'
+    roof_tree = None
+    if prof is not None and prof['backup_n'] > 0:
+        sel_b, bak_b = tree_bytes_per_sim(Game, W)
+        us = prof['backup_ms'] * 1e3 / prof['backup_n']              # backup k + select k + 1 share a launch
+        gbs = (sel_b + bak_b) * Bl / (us * 1e-6) / 1e9
+        traffic, src = measured_traffic(a.workload, 'k_backup_select2')
+        roof_tree = {'kernel': 'k_backup_select2 (process_results of simulation k + find_leaf of k + 1, two wavefronts per tree)',
+                     'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 6),
+                     'avg_launch_us': round(us, 2), 'launches_timed': prof['backup_n'], 'algorithmic_bytes_per_launch': (sel_b + bak_b) * Bl,
+                     'traffic': traffic, 'traffic_source': src,
+                     'advance_us': round(prof['advance_ms'] * 1e3 / max(prof['advance_n'], 1), 1)}
+    # the dominant kernel of a simulation step: the persistent search launch if that is what ran, else the longer of the two launches
+    if roof_search:
+        roofline = roof_search
+    elif roof_net and roof_tree:
+        roofline = roof_net if roof_net['avg_launch_us'] >= roof_tree['avg_launch_us'] else roof_tree
     else:
-        roof = tree
-    if ev_search:
-        # default path: the whole simulation loop of a move is ONE persistent launch (azg_search_f16): tree walk, tower + heads and
-        # backup of every simulation.  Its FLOPs are the network's; the tree phases ride inside the launch time.
-        sms = ev_search[0][0].elapsed_time(ev_search[0][1])
-        stf = C4_NET_FLOPS_PER_LEAF * Bl * SIMS / (sms * 1e-3) / 1e12
-        roof = {'kernel': 'k_tower2<6,7,4,128,1,SearchArgs<C4>> (azg_search_f16: %d x [find_leaf, ResNet 128ch x 8 + heads, backup] '
-                          'on every game, one persistent launch per move)' % SIMS, 'bound': 'mfma', 'achieved': round(stf, 1),
-                'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(stf / MFMA_F16_PEAK_TFLOPS, 4),
-                'avg_launch_us': round(sms * 1e3, 1), 'algorithmic_flops_per_launch': C4_NET_FLOPS_PER_LEAF * Bl * SIMS,
-                # PMC per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_summary.csv rows search_r1d): 72 MB per simulation
-                # = the tower's 51 MB (weight stream per XCD) + the trees' ~8 MB + ~13 MB of spill traffic
-                'traffic': SEARCH_TRAFFIC_BYTES if (Bl == 2048 and SIMS == 100) else None,
-                # the same tower + heads as its own launch (one evaluation), timed as a burst of NN_REPS launches: after the
-                # lighter search launches the chip boosts, so this runs faster than the same kernel does in a sustained stream
-                # (0.28 ms = 60 % with --no-fused-search, where it is launched 100 times per move)
-                'net_eval_only': roof}
+        roofline = roof_net or roof_tree
     out = {
         'metric': 'mcts_node_expansions_per_sec', 'value': round(expansions / dt, 1), 'unit': 'expansions/s',
-        'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net', 'data': 'synthetic',
-        'config': {'workload': 'connect4 self-play, %d games/GPU x %d sims/move, fp16 ResNet 128ch x 8, random-init, noise+temp on'
-                               % (B, SIMS), 'games_per_gpu': B, 'sims_per_move': SIMS, 'hipgraph_net': bool(runner.use_graph),
-                   'stream_pipelines': a.pipelines, 'fused_search_launch': bool(runner.fused_search)},
-        'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(sims / dt, 1),
+        'config': {'workload': '%s %s, %d games/GPU x %d sims/move, fp16 ResNet %dch x %d, random-init, %s'
+                               % (W['game'], 'arena (two nets)' if arena else 'self-play', B, sims, net.args.num_channels, net.args.depth,
+                                  'arenaTemp 0.25' if arena else 'noise+temp on'),
+                   'games_per_gpu': B, 'sims_per_move': sims, 'hipgraph_rounds': not a.no_graph, 'stream_pipelines': a.pipelines,
+                   'fused_search_launch': fused_search, 'mfma_tower': hipnet, 'ranks': world,
+                   'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
+        'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(nsims / dt, 1),
         'games_finished': games_done, 'samples_gathered': nsamples,
-        'roofline': roof, 'tree_roofline': tree,
+        'roofline': roofline, 'tree_roofline': roof_tree,
     }
-    if nn_ms is not None:
-        # context for the MFMA fraction: the best plain fp16 GEMM the vendor library reaches on this very GPU (outside the
-        # timed region; SURVEY.md 8d asks for it next to the datasheet peak)
-        lib_tf = library_gemm_tflops(dev)
-        tgt = out['roofline'].get('net_eval_only', out['roofline'])
-        tgt['library_gemm_tflops'] = round(lib_tf, 1)
-        tgt['vs_library_gemm'] = round(tf / lib_tf, 3)
-    if a.gpus == 1 and not a.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(net)
+    if roof_net is not None and roofline is not roof_net:
+        out['net_roofline'] = roof_net
+    if world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(W, nets if arena else [net], arena)
     print(json.dumps(out))
+    return 0
 
 
 if __name__ == '__main__':

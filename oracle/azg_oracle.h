@@ -143,6 +143,21 @@ azo_mcts  *azo_agent_mcts(azo_agent *ag, int slot, int player);
 uint64_t   azo_agent_sims_done(const azo_agent *ag);
 uint64_t   azo_agent_expansions(const azo_agent *ag);
 
+/* ---- many agents on many host cores (azg_pool_ref.c; bench.py's cpu_baseline leg) ------------------ */
+typedef struct azo_pool azo_pool;
+azo_pool  *azo_pool_new(int game, const azo_agent_args *a, int n_agents);   /* one thread per agent; agent i: slot_base + i * B */
+void       azo_pool_free(azo_pool *p);
+void       azo_pool_begin_round(azo_pool *p);
+void       azo_pool_generate(azo_pool *p, float *obs /*[n*B, C*H*W]*/);
+void       azo_pool_process(azo_pool *p, const float *policy /*[n*B, A]*/, const float *value /*[n*B, P+1]*/);
+int        azo_pool_play(azo_pool *p);
+double     azo_pool_run_tree_only(azo_pool *p, double seconds);
+uint64_t   azo_pool_expansions(const azo_pool *p);
+uint64_t   azo_pool_sims(const azo_pool *p);
+int        azo_pool_games_played(const azo_pool *p);
+azo_agent *azo_pool_agent(azo_pool *p, int i);
+void       azo_pool_row_models(const azo_pool *p, int32_t *out /*[n*B]*/);   /* arena: model of every row of the last generate */
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,15 @@ def lib():
         'azo_agent_player_to_index': (C.POINTER(i32), [vp]),
         'azo_agent_mcts': (vp, [vp, C.c_int, C.c_int]),
         'azo_agent_sims_done': (u64, [vp]), 'azo_agent_expansions': (u64, [vp]),
+        'azo_pool_new': (vp, [C.c_int, C.POINTER(AgentArgs), C.c_int]), 'azo_pool_free': (None, [vp]),
+        'azo_pool_begin_round': (None, [vp]),
+        'azo_pool_generate': (None, [vp, _fp(np.float32)]),
+        'azo_pool_process': (None, [vp, _fp(np.float32), _fp(np.float32)]),
+        'azo_pool_play': (C.c_int, [vp]),
+        'azo_pool_run_tree_only': (f64, [vp, f64]),
+        'azo_pool_expansions': (u64, [vp]), 'azo_pool_sims': (u64, [vp]), 'azo_pool_games_played': (C.c_int, [vp]),
+        'azo_pool_agent': (vp, [vp, C.c_int]),
+        'azo_pool_row_models': (None, [vp, _fp(np.int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -272,7 +281,7 @@ class OAgent:
                  root_noise_frac=0.1, root_policy_temp=1.1, add_root_noise=False, add_root_temp=False,
                  symmetric=True, prob_fast=0.0, fast_sims=20, warmup_sims=5, start_temp=1.0, arena_temp=0.25,
                  temp_fn=default_temp_scaling, reset_threshold=0, is_arena=False, is_warmup=False,
-                 ref_misroute=False, slot_base=0):
+                 ref_misroute=False, slot_base=0, _pool_of=0):
         self.game, self.gi = game, game_info(game)
         self.B = batch_size
         self._tt = temp_table(temp_fn, start_temp, self.gi.max_turns)
@@ -289,8 +298,8 @@ class OAgent:
         a.temp_table = self._tt.ctypes.data_as(C.POINTER(C.c_float))
         a.is_arena, a.is_warmup, a.arena_ref_misroute, a.slot_base = int(is_arena), int(is_warmup), int(ref_misroute), slot_base
         self.args = a
-        self.h = lib().azo_agent_new(game, C.byref(a))
         self.O = self.gi.obs_c * self.gi.obs_h * self.gi.obs_w
+        self.h = None if _pool_of else lib().azo_agent_new(game, C.byref(a))
 
     def __del__(self):
         if getattr(self, 'h', None):
@@ -358,6 +367,66 @@ class OAgent:
     @property
     def expansions(self):
         return lib().azo_agent_expansions(self.h)
+
+
+class OPool:
+    """n oracle agents of `batch_size` games, one host thread each (oracle/azg_pool_ref.c): the reference's `workers` agent
+    processes (Coach.py:291-342) for the C restatement.  Agent i owns the global slots [slot_base + i * B, + B).  Keyword
+    arguments as OAgent."""
+
+    def __init__(self, game, n_agents, batch_size, **kw):
+        tmpl = OAgent(game, batch_size, _pool_of=1, **kw)                 # (only builds the argument block)
+        self._keep = tmpl
+        self.game, self.gi, self.n, self.B, self.O = game, tmpl.gi, int(n_agents), int(batch_size), tmpl.O
+        self.A, self.NV = self.gi.action_size, self.gi.num_players + 1
+        self.h = lib().azo_pool_new(game, C.byref(tmpl.args), self.n)
+        self.obs = np.zeros((self.n * self.B, self.O), np.float32)
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            lib().azo_pool_free(self.h)
+            self.h = None
+
+    def begin_round(self):
+        lib().azo_pool_begin_round(self.h)
+
+    def generate(self):
+        """leaf observations of every agent's games: [n * B, C, H, W] (a view of one reused buffer)"""
+        lib().azo_pool_generate(self.h, self.obs)
+        return self.obs.reshape(self.n * self.B, self.gi.obs_c, self.gi.obs_h, self.gi.obs_w)
+
+    def process(self, policy, value):
+        lib().azo_pool_process(self.h, np.ascontiguousarray(policy, np.float32), np.ascontiguousarray(value, np.float32))
+
+    def play(self):
+        return lib().azo_pool_play(self.h)
+
+    def row_models(self):
+        """arena mode: which model evaluates each row of the last generate() ([n * B] int32)"""
+        out = np.zeros(self.n * self.B, np.int32)
+        lib().azo_pool_row_models(self.h, out)
+        return out
+
+    def run_tree_only(self, seconds):
+        """every agent plays whole rounds with the uniform evaluator on its own thread for `seconds`; returns the wall time"""
+        return lib().azo_pool_run_tree_only(self.h, float(seconds))
+
+    def agent_last_actions(self, i):
+        a = np.zeros(self.B, np.int32)
+        lib().azo_agent_last_actions(lib().azo_pool_agent(self.h, i), a)
+        return a
+
+    @property
+    def expansions(self):
+        return lib().azo_pool_expansions(self.h)
+
+    @property
+    def sims_done(self):
+        return lib().azo_pool_sims(self.h)
+
+    @property
+    def games_played(self):
+        return lib().azo_pool_games_played(self.h)
 
 
 def fake_eval(seed, slot, sim, A, nv):

@@ -100,3 +100,27 @@ def test_game_quotas_sum_exactly():
         for world in (1, 2, 3, 4, 8):
             q = [D.shard_games(total, r, world) for r in range(world)]
             assert sum(q) == total and max(q) - min(q) <= 1 and q == sorted(q, reverse=True)
+
+
+def test_oracle_pool_equals_one_agent():
+    """oracle/azg_pool_ref.c (bench.py's all-cores CPU baseline): 4 agents x 6 games on 4 threads, stepped in lock step with one
+    leaf batch, play exactly what one agent of 24 games plays (global slot ids key the tape); the free-running tree-only loop
+    makes progress on every thread."""
+    import oracle_lib as ol
+    kw = dict(sims=6, games_per_iteration=1 << 30, seed=3)
+    big, pool = ol.OAgent(0, 24, **kw), ol.OPool(0, 4, 6, **kw)
+    for rnd in range(5):
+        big.begin_round(); pool.begin_round()
+        for s in range(6):
+            ob, _, _ = big.generate_batch()
+            assert (ob == pool.generate()).all()
+            pol = np.zeros((24, 7), np.float32); val = np.zeros((24, 3), np.float32)
+            for i in range(24):
+                pol[i], val[i] = ol.fake_eval(3, i, rnd * 6 + s, 7, 3)
+            big.process_batch(pol.copy(), val.copy()); pool.process(pol.copy(), val.copy())
+        big.play_moves(); pool.play()
+        assert (np.concatenate([pool.agent_last_actions(i) for i in range(4)]) == big.last_actions()).all()
+    assert pool.expansions == big.expansions and pool.sims_done == big.sims_done == 24 * 6 * 5
+    free = ol.OPool(0, 3, 4, sims=5, games_per_iteration=1 << 30, seed=9)
+    dt = free.run_tree_only(0.3)
+    assert dt >= 0.3 and free.sims_done >= 3 * 4 * 5 and free.expansions > 0

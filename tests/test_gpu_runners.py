@@ -132,10 +132,12 @@ def test_warmup_runner_round_graph_equals_eager():
         assert x.shape == y.shape and (x == y).all()
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+def test_bench_two_ranks_on_one_gpu(launcher):
     """bench.py's multi-rank path end to end -- rendezvous, slot sharding by rank, timed loop, all-gather of the example shards,
     tally all-reduce, max-over-ranks -- with two ranks sharing GPU 0 over gloo (RCCL refuses two ranks on one device; the
-    8-GPU run itself is the driver's)."""
+    8-GPU run itself is the driver's).  launcher = 'self': plain `python bench.py --gpus 2` must start its own two ranks and
+    report n_gpus = 2 from two live ranks; 'torchrun': the driver's launch line."""
     import json
     import os
     import signal
@@ -143,8 +145,11 @@ def test_bench_two_ranks_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, AZG_DIST_BACKEND='gloo', AZG_SINGLE_DEVICE='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29613', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '1', '--slots', '256']
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    tail = [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '1', '--slots', '256']
+    cmd = [sys.executable] + tail if launcher == 'self' else \
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29613'] + tail
     p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
     try:
         out, _ = p.communicate(timeout=240)
@@ -154,9 +159,22 @@ def test_bench_two_ranks_on_one_gpu():
     lines = [l for l in out.decode(errors='replace').splitlines() if l.startswith('{"metric"')]
     assert p.returncode == 0 and len(lines) == 1, out.decode(errors='replace')[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and d['games_finished'] > 0
+    assert d['n_gpus'] == 2 and d['config']['ranks'] == 2 and d['config']['backend'] == 'gloo'
+    assert d['scaling'] == 'weak' and d['value'] > 0 and d['games_finished'] > 0
     assert d['samples_gathered'] >= d['games_finished'] * 7 * 2          # both ranks' shards arrived
     assert 'cpu_baseline' not in d                                       # rank 0, N = 1 only
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """one rank launched, --gpus 2 claimed: bench.py must fail instead of printing n_gpus = 2 for a one-GPU run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29614', AZG_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--slots', '64'],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert r.returncode != 0 and b'"metric"' not in r.stdout and b'rank(s) were launched' in r.stdout
 
 
 @pytest.mark.parametrize('game', ['brandubh', 'trimok'])

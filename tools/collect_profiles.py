@@ -1,0 +1,102 @@
+"""Collect the rocprofv3 evidence bench.py and DESIGN.md cite -- run ON the GPU box:
+
+    python tools/collect_profiles.py --git <short hash of the commit being profiled> [--workloads connect4 brandubh arena trimok]
+
+Per workload: (1) `rocprofv3 --kernel-trace --stats` of the bench command -> profiles/r02_<workload>_kernel_stats.csv and the bench
+line printed under the profiler; (2) PMC passes of the same command, one counter set per pass as MI355X_MICROARCH.md prescribes
+(FETCH_SIZE and WRITE_SIZE cannot share a pass; never combined with --stats / trace domains other than the kernel trace):
+per-kernel averages -> profiles/r02_pmc_summary.csv, and HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; the
+guide's gfx950 correction: FETCH_SIZE reports half the bytes of wide loads) -> profiles/r02_pmc.json, which bench.py reads for its
+`traffic` fields.  The connect4 run adds an MFMA / LDS / clock pass for the search launch."""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, 'profiles')
+SCRATCH = os.path.join(ROOT, 'gpurun_out', 'r02_prof')
+KEEP = ('k_tower2', 'k_backup_select2', 'k_heads', 'k_select', 'k_backup', 'k_play', 'k_compact', 'k_emit', 'k_finalize', 'k_arena_rows')
+
+
+def rocprof(tag, extra, bench_args, timeout=600):
+    out = os.path.join(SCRATCH, tag)
+    shutil.rmtree(out, ignore_errors=True)
+    env = dict(os.environ, TMPDIR='/tmp')
+    cmd = ['rocprofv3'] + extra + ['--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(ROOT, 'bench.py')] + bench_args
+    r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    line = [l for l in r.stdout.decode(errors='replace').splitlines() if l.startswith('{"metric"')]
+    return out, (line[0] if line else None), r.returncode
+
+
+def short(name):
+    """a readable kernel label: template name up to the argument list"""
+    n = name.replace('void ', '').replace('azg::', '')
+    return n.split('(')[0][:120]
+
+
+def pmc_averages(outdir):
+    acc = {}
+    for f in glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row['Kernel_Name'])
+                if not any(s in k for s in KEEP):
+                    continue
+                key = (k, row['Counter_Name'])
+                a = acc.setdefault(key, [0.0, 0])
+                a[0] += float(row['Counter_Value']); a[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--git', default=os.environ.get('AZG_GIT', 'unknown'))
+    ap.add_argument('--workloads', nargs='*', default=['connect4', 'brandubh', 'arena', 'trimok'])
+    a = ap.parse_args()
+    os.makedirs(PROF, exist_ok=True); os.makedirs(SCRATCH, exist_ok=True)
+    summary_rows, pmc = [], {'git': a.git, 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
+    for w in a.workloads:
+        base = ['--workload', w, '--no-cpu-baseline']
+        out, line, rc = rocprof('kt_' + w, ['--kernel-trace', '--stats'], base + ['--steps', '12', '--warmup', '2'])
+        stats = glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True)
+        if stats:
+            shutil.copy(stats[0], os.path.join(PROF, 'r02_%s_kernel_stats.csv' % w))
+        if line:
+            with open(os.path.join(PROF, 'r02_%s_bench_line_under_rocprof.json' % w), 'w') as fh:
+                fh.write(line + '\n')
+        print(w, 'kernel trace rc', rc, 'stats' if stats else 'NO STATS', flush=True)
+        passes = [['FETCH_SIZE'], ['WRITE_SIZE']]
+        if w == 'connect4':
+            passes += [['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_WAIT_INST_ANY',
+                        'GRBM_GUI_ACTIVE'], ['TCC_HIT_sum', 'TCC_MISS_sum']]
+        per_kernel = {}
+        for cs in passes:
+            out, _, rc = rocprof('pmc_%s_%s' % (w, cs[0]), ['--pmc'] + cs, base + ['--steps', '4', '--warmup', '1'])
+            av = pmc_averages(out)
+            print(w, cs, 'rc', rc, len(av), 'kernel-counter pairs', flush=True)
+            for (k, c), (v, n) in sorted(av.items()):
+                summary_rows.append([w, k, c, n, '%.3f' % v])
+                per_kernel.setdefault(k, {})[c] = (v, n)
+        rec = {}
+        for k, cs in per_kernel.items():
+            if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
+                f, wv = cs['FETCH_SIZE'][0], cs['WRITE_SIZE'][0]
+                rec[k] = {'fetch_kb': round(f, 2), 'write_kb': round(wv, 2), 'traffic_bytes': int((2 * f + wv) * 1024),
+                          'dispatches': int(cs['FETCH_SIZE'][1])}
+        pmc['workloads'][w] = rec
+    with open(os.path.join(PROF, 'r02_pmc.json'), 'w') as fh:
+        json.dump(pmc, fh, indent=1, sort_keys=True)
+    with open(os.path.join(PROF, 'r02_pmc_summary.csv'), 'w', newline='') as fh:
+        wr = csv.writer(fh)
+        wr.writerow(['workload', 'kernel', 'counter', 'dispatches', 'avg_per_dispatch'])
+        wr.writerows(summary_rows)
+    print('wrote profiles/r02_pmc.json, profiles/r02_pmc_summary.csv')
+
+
+if __name__ == '__main__':
+    main()
