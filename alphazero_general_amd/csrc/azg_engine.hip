@@ -601,6 +601,52 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
     return AZG_OK;
 }
 
+// ---- timing hooks for the network launches (no engine handle there: process-wide, same event scheme as azg_profile_*) ----------
+struct NetProf {
+    std::mutex mu; bool on = false;
+    std::vector<EvPair> ev[3], pool;
+    double ms[3] = {0, 0, 0}; int64_t n[3] = {0, 0, 0};
+};
+static NetProf g_netprof;
+static bool netprof_begin(hipStream_t s, EvPair &p) {
+    std::lock_guard<std::mutex> lk(g_netprof.mu);
+    if (!g_netprof.on) return false;
+    if (!g_netprof.pool.empty()) { p = g_netprof.pool.back(); g_netprof.pool.pop_back(); }
+    else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    (void)hipEventRecord(p.a, s);
+    return true;
+}
+static void netprof_end(hipStream_t s, int fam, bool on, EvPair &p) {
+    if (!on) return;
+    (void)hipEventRecord(p.b, s);
+    std::lock_guard<std::mutex> lk(g_netprof.mu);
+    g_netprof.ev[fam].push_back(p); g_netprof.n[fam]++;
+}
+static void netprof_drain() {
+    for (int f = 0; f < 3; f++) {
+        for (auto &p : g_netprof.ev[f]) {
+            (void)hipEventSynchronize(p.b);
+            float t = 0; (void)hipEventElapsedTime(&t, p.a, p.b);
+            g_netprof.ms[f] += t; g_netprof.pool.push_back(p);
+        }
+        g_netprof.ev[f].clear();
+    }
+}
+extern "C" int azg_profile_net_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_netprof.mu);
+    netprof_drain();
+    g_netprof.on = on != 0;
+    if (on) for (int f = 0; f < 3; f++) { g_netprof.ms[f] = 0; g_netprof.n[f] = 0; }
+    return AZG_OK;
+}
+extern "C" int azg_profile_net_read(double *ms3, int64_t *launches3) {
+    if (!ms3 || !launches3) return fail(AZG_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_netprof.mu);
+    netprof_drain();
+    for (int f = 0; f < 3; f++) { ms3[f] = g_netprof.ms[f]; launches3[f] = g_netprof.n[f]; }
+    return AZG_OK;
+}
+
 // Boards per workgroup tile: the big tile has the least MFMA padding, small ones fill the chip at small batches (the arena,
 // the single-tree API, brandubh's 512 games per GPU).  AZG_TOWER_BOARDS overrides the choice (measurement knob).
 static int dispatch_tower(hipStream_t s, int game, int channels, const TowerParams &P) {
@@ -642,7 +688,10 @@ extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const
     if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, {}};
-    return dispatch_tower((hipStream_t)stream, game, channels, P);
+    EvPair ep; const bool prof = netprof_begin((hipStream_t)stream, ep);
+    const int r = dispatch_tower((hipStream_t)stream, game, channels, P);
+    netprof_end((hipStream_t)stream, 0, prof, ep);
+    return r;
 }
 
 extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
@@ -652,7 +701,10 @@ extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x
     if (A <= 0 || NV <= 0 || A + NV > 16) return fail(AZG_E_UNSUPPORTED, "fused heads need A + NV <= 16");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr, nullptr, 0, {}};
-    return dispatch_tower((hipStream_t)stream, game, 128, P);
+    EvPair ep; const bool prof = netprof_begin((hipStream_t)stream, ep);
+    const int r = dispatch_tower((hipStream_t)stream, game, 128, P);
+    netprof_end((hipStream_t)stream, 0, prof, ep);
+    return r;
 }
 
 extern "C" int azg_resnet_policy_value_multi_f16(void *stream, int game, const void *x, int nmodels, const void *const *w, const float *const *bias,
@@ -671,7 +723,10 @@ extern "C" int azg_resnet_policy_value_multi_f16(void *stream, int game, const v
                   head_w[0], head_b[0], policy, value, A, NV, nullptr, rows_per_model, nmodels, {}};
     for (int m = 1; m < nmodels; m++)
         P.alt[m - 1] = TowerParams::Model{w[m], bias[m], nblocks ? pre_scale[m] : nullptr, nblocks ? pre_shift[m] : nullptr, head_w[m], head_b[m]};
-    return dispatch_tower((hipStream_t)stream, game, 128, P);
+    EvPair ep; const bool prof = netprof_begin((hipStream_t)stream, ep);
+    const int r = dispatch_tower((hipStream_t)stream, game, 128, P);
+    netprof_end((hipStream_t)stream, 0, prof, ep);
+    return r;
 }
 
 extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
@@ -683,7 +738,10 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     const int A = e->gi.action_size, NV = e->gi.num_players + 1;
     TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, head_w, head_b, nullptr, nullptr, A, NV, nullptr, nullptr, 0, {}};
     SearchArgs<C4> sa{e->v, sims};
-    return launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
+    EvPair ep; const bool prof = sims > 0 && netprof_begin((hipStream_t)stream, ep);
+    const int r = launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
+    netprof_end((hipStream_t)stream, 2, prof, ep);
+    return r;
 }
 
 extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,
@@ -692,8 +750,10 @@ extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const voi
     if (boards <= 0 || k <= 0 || (k & 31) || A <= 0 || A > 1024 || NV <= 0 || NV > 64) return fail(AZG_E_INVALID_ARG, "boards > 0, k a multiple of 32, 0 < A <= 1024, 0 < NV <= 64");
     const int osub = (A + NV + 15) / 16, nchunks = (osub + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
+    EvPair ep; const bool prof = netprof_begin(s, ep);
     hipLaunchKernelGGL(k_heads, dim3(groups * nchunks), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)y, (const half8 *)head_w_packed, head_b, logits_ws,
                        boards, k / 32, osub);
+    netprof_end(s, 1, prof, ep);
     if (policy)                                              // (NULL: leave the logits for azg_backup_select_logits)
         hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
     HIPCHK(hipGetLastError());

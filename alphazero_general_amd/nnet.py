@@ -203,21 +203,20 @@ class HipResNet:
     behind the tower in the same launch when A + P+1 <= 16 at 128 channels (azg_resnet_policy_value_f16), else in the wide-head
     kernel (azg_policy_value_heads_f16).  The input is the engine's obs_dtype 2 format [B, H*W, 8] fp16."""
 
-    timer = None      # measurement hook (bench.py): a list that receives one (start, end) HIP event pair, recorded on the launch
-                      # stream, per network evaluation launched through this class while it is set
+    @staticmethod
+    def profile(on=True):
+        """HIP-event timing of every network launch of this process, recorded by the library on the launch stream
+        (azg_profile_net_enable); read with profile_read()."""
+        from . import _abi
+        _abi.check(_abi.lib().azg_profile_net_enable(int(on)))
 
-    @classmethod
-    def _t0(cls):
-        if cls.timer is None:
-            return None
-        e = torch.cuda.Event(enable_timing=True); e.record()
-        return e
-
-    @classmethod
-    def _t1(cls, e0):
-        if e0 is not None:
-            e1 = torch.cuda.Event(enable_timing=True); e1.record()
-            cls.timer.append((e0, e1))
+    @staticmethod
+    def profile_read():
+        import ctypes as C
+        from . import _abi
+        ms = (C.c_double * 3)(); n = (C.c_int64 * 3)()
+        _abi.check(_abi.lib().azg_profile_net_read(ms, n))
+        return dict(tower_ms=ms[0], heads_ms=ms[1], search_ms=ms[2], tower_n=n[0], heads_n=n[1], search_n=n[2])
 
     def __init__(self, folded: FoldedResNet, game_id, device):
         from . import _abi
@@ -308,7 +307,6 @@ class HipResNet:
         """x: [B, H*W, 8] fp16 -> (policy [B, A], value [B, P+1]) float32 probabilities.  `key` selects a private set
         of activation buffers (one per captured graph, so that graphs on different streams never share scratch)."""
         B = x.shape[0]
-        t0 = self._t0()
         if self.fused_head and not logits_only:                  # tower + heads + softmax in ONE launch
             import ctypes as C
             vp = lambda q: C.c_void_p(q.data_ptr())
@@ -319,7 +317,6 @@ class HipResNet:
             self._check(self.L.azg_resnet_policy_value_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
                                                            vp(self.tower_pt), int(B), len(self.blocks), vp(self.head_w_packed),
                                                            vp(self.head_b16), int(self.A), int(self.NV), vp(pol), vp(val)))
-            self._t1(t0)
             return pol, val
         s = self._buffers(B, key)
         import ctypes as C                                       # tower: one persistent launch, activations resident in LDS
@@ -334,7 +331,6 @@ class HipResNet:
         self._check(self.L.azg_policy_value_heads_f16(st, vp(s), vp(self.head_w_wide), vp(self.head_b_wide), int(B), self.HW * self.CH,
                                                       int(self.A), int(self.NV), vp(ws), null if logits_only else vp(pol),
                                                       null if logits_only else vp(val)))
-        self._t1(t0)
         return ws if logits_only else (pol, val)
 
     def search(self, engine, sims):
@@ -346,10 +342,8 @@ class HipResNet:
         import ctypes as C
         vp = lambda q: C.c_void_p(q.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        t0 = self._t0() if sims else None
         self._check(self.L.azg_search_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
                                           len(self.blocks), vp(self.head_w_packed), vp(self.head_b16), int(sims)))
-        self._t1(t0)
 
     @staticmethod
     def forward_models(nets, x_all, policy_all, value_all, rows_per_model):
@@ -365,13 +359,11 @@ class HipResNet:
         arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         vp = lambda q: C.c_void_p(q.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        t0 = HipResNet._t0()
         n0._check(n0.L.azg_resnet_policy_value_multi_f16(
             st, n0.game, vp(x_all), len(nets), arr([n.tower_w for n in nets]), arr([n.tower_b for n in nets]),
             arr([n.tower_ps for n in nets]), arr([n.tower_pt for n in nets]), int(x_all.shape[0]), len(n0.blocks),
             arr([n.head_w_packed for n in nets]), arr([n.head_b16 for n in nets]), int(n0.A), int(n0.NV), vp(policy_all), vp(value_all),
             vp(rows_per_model)))
-        HipResNet._t1(t0)
 
     def to_nhwc8(self, batch):
         """[B, C, H, W] (any float dtype) -> [B, H*W, 8] fp16."""

@@ -188,11 +188,6 @@ def self_launch(n):
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode
 
 
-def event_stats(pairs):
-    ms = [a.elapsed_time(b) for a, b in pairs]
-    return (sum(ms) / len(ms) * 1e3, len(ms)) if ms else (None, 0)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -255,7 +250,7 @@ def main():
         runner.play_round()
     c0 = counters()
     ex0 = [e.counters()['num_examples'] for e in engines] if not arena else None
-    net_events, search_events, prof = [], [], None
+    netprof, prof = {}, None
     D.barrier(); torch.cuda.synchronize()
     t0 = time.time()
     for k in range(a.steps):
@@ -270,9 +265,11 @@ def main():
         second = fused_search and k == a.steps // 2 + 1
         if second:
             runner.fused_search = False
-        engines[0].profile(True); HipResNet.timer = search_events if (fused_search and not second) else net_events
+        engines[0].profile(True); HipResNet.profile(True)
         runner.play_round(eager=True)
-        HipResNet.timer = None
+        for kk, vv in HipResNet.profile_read().items():             # (GPU ms and launch counts per family: tower, wide heads, search)
+            netprof[kk] = netprof.get(kk, 0) + vv
+        HipResNet.profile(False)
         if second or not fused_search:
             prof = engines[0].profile_read()
         engines[0].profile(False)
@@ -296,23 +293,24 @@ def main():
     # ---- roofline of the network launch (MFMA) and of the tree launch (HBM), from the eager rounds' events
     flops_leaf = net_flops_per_leaf(Game, net.args)
 
-    def mfma_roof(events, kname, kmatch, units):
-        us, n = event_stats(events)
-        if not us:
+    def mfma_roof(fam, kname, kmatch, units):
+        n = int(netprof.get(fam + '_n', 0))
+        if not n:
             return None
+        us = netprof[fam + '_ms'] * 1e3 / n
         tf = flops_leaf * units / (us * 1e-6) / 1e12
         traffic, src = measured_traffic(a.workload, kmatch)
         return {'kernel': kname, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
                 'algorithmic_flops_per_launch': flops_leaf * units, 'traffic': traffic, 'traffic_source': src}
 
-    roof_search = mfma_roof(search_events, 'k_tower2<6,7,4,128,1,SearchArgs<C4>> (azg_search_f16: %d x [find_leaf, ResNet + heads, backup] on '
+    roof_search = mfma_roof('search', 'k_tower2<6,7,4,128,1,SearchArgs<C4>> (azg_search_f16: %d x [find_leaf, ResNet + heads, backup] on '
                             'every game, one persistent launch per move)' % sims, 'SearchArgs', Bl * sims)
-    roof_net = mfma_roof(net_events, 'k_tower2 (%s, one launch per simulation)' % ('both models on their row ranges' if arena else 'ResNet tower'
+    roof_net = mfma_roof('tower', 'k_tower2 (%s, one launch per simulation)' % ('both models on their row ranges' if arena else 'ResNet tower'
                                                                                      + ('' if net._hip is None or net._hip.wide_head else ' + heads')),
                          'NoSearch', Bl)
-    if roof_net is not None and not hipnet:
-        roof_net['kernel'] = 'network through PyTorch / MIOpen (no MFMA tower instantiated for this shape)'
+    if roof_net is not None and netprof.get('heads_n'):             # wide heads: their own launch behind the tower
+        roof_net['heads_launch_us'] = round(netprof['heads_ms'] * 1e3 / netprof['heads_n'], 2)
     roof_tree = None
     if prof is not None and prof['backup_n'] > 0:
         sel_b, bak_b = tree_bytes_per_sim(Game, W)

@@ -258,6 +258,12 @@ int  azg_profile_enable(azg_engine *e, int on);
 /* accumulated GPU ms + launch counts per kernel family: select, backup, advance. blocking. */
 int  azg_profile_read(azg_engine *e, double *ms3, int64_t *launches3);
 
+/* the same for the network launches of this process (they take no engine): GPU ms + launch counts per family: 0 = the tower
+ * (azg_resnet_tower_f16 / _policy_value_f16 / _multi_f16), 1 = the wide heads GEMM (azg_policy_value_heads_f16, its softmax
+ * launch excluded), 2 = the persistent search launch (azg_search_f16).  Events are recorded on the launch's own stream. */
+int  azg_profile_net_enable(int on);
+int  azg_profile_net_read(double *ms3, int64_t *launches3);                                        /* blocking */
+
 /* ---- random tape (exposed so that host code can draw the agent-level numbers) ------------------------------- */
 uint64_t azg_tape_u64(uint64_t seed, uint64_t stream, uint64_t ctr);
 double   azg_tape_uniform(uint64_t seed, uint64_t stream, uint64_t ctr);
