@@ -661,6 +661,11 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
         return launch_tower<C4::H, C4::W, 4, 128>(s, P);
     }
     if (game == AZG_GAME_CONNECT4 && channels == 64) return launch_tower<C4::H, C4::W, 4, 64>(s, P);
+    if (game == AZG_GAME_CONNECT4 && channels == 32) {           // the default net of Coach.py:108-116 (BASELINE config 1): one cout group,
+        const int bt = forced ? forced : n <= 1024 ? 2 : 4;      // the tile's pixel subtiles dealt to two waves
+        if (bt == 2) return launch_tower<C4::H, C4::W, 2, 32, 2>(s, P);
+        return launch_tower<C4::H, C4::W, 4, 32, 2>(s, P);
+    }
     if (game == AZG_GAME_BRANDUBH && channels == 64) {           // two cout groups: split the pixels too at small batches
         // measured (us per evaluation incl. heads, 256 / 512 / 1024 / 2048 boards): 1 board, no split 39 / 47 / 66 / 107;
         // 1 board, split 35 / 46 / 80 / 113; 2 boards, split 39 / 43 / 63 / 113
@@ -680,7 +685,7 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
         if (bt == 2) return launch_tower<TM::H, TM::W, 2, 32>(s, P);
         return launch_tower<TM::H, TM::W, 5, 32>(s, P);
     }
-    return fail(AZG_E_UNSUPPORTED, "no MFMA tower for this game / channel count (supported: connect4 x {64,128}, brandubh x {64,128}, trimok x 32 channels)");
+    return fail(AZG_E_UNSUPPORTED, "no MFMA tower for this game / channel count (supported: connect4 x {32,64,128}, brandubh x {64,128}, trimok x 32 channels)");
 }
 
 extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
@@ -774,7 +779,7 @@ static int tower_layout_of(int16_t *map, int32_t *qrow, int32_t *info) {
 extern "C" int azg_tower_layout(int game, int boards_per_tile, int channels, int16_t *pixmap, int32_t *qrow, int32_t *info8) {
     if (!info8) return fail(AZG_E_INVALID_ARG, "null argument");
 #define AZG_LAYOUT(GM, BT, CH) if (game == GM::ID && boards_per_tile == BT && channels == CH) return tower_layout_of<GM::H, GM::W, BT, CH>(pixmap, qrow, info8)
-    AZG_LAYOUT(C4, 1, 128); AZG_LAYOUT(C4, 2, 128); AZG_LAYOUT(C4, 4, 128); AZG_LAYOUT(C4, 4, 64);
+    AZG_LAYOUT(C4, 1, 128); AZG_LAYOUT(C4, 2, 128); AZG_LAYOUT(C4, 4, 128); AZG_LAYOUT(C4, 4, 64); AZG_LAYOUT(C4, 2, 32); AZG_LAYOUT(C4, 4, 32);
     AZG_LAYOUT(BR, 1, 64); AZG_LAYOUT(BR, 2, 64); AZG_LAYOUT(BR, 2, 128);
     AZG_LAYOUT(TM, 2, 32); AZG_LAYOUT(TM, 5, 32);
 #undef AZG_LAYOUT

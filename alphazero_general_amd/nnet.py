@@ -419,7 +419,7 @@ class NNetWrapper:
         self._infer, self._graph, self._hip = net.eval(), None, None
         use_hip = self.backend == 'hip' or (self.backend == 'auto' and self.device.type == 'cuda'
                                             and (getattr(self.game_cls, 'AZG_GAME_ID', None), self.args.num_channels) in
-                                            ((0, 64), (0, 128), (1, 64), (1, 128), (2, 32)))
+                                            ((0, 32), (0, 64), (0, 128), (1, 64), (1, 128), (2, 32)))
         if use_hip:
             self._hip = HipResNet(FoldedResNet(self.nnet).to(self.device), self.game_cls.AZG_GAME_ID, self.device)
         return self

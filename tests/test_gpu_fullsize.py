@@ -1,0 +1,135 @@
+"""Parity of the TIMED paths at the sizes bench.py times them (BASELINE.json configs 2 and 4):
+
+  * azg_search_f16 (the persistent launch behind the headline number) against the launch-per-phase path
+    azg_select / azg_resnet_policy_value_f16 / azg_backup on a twin engine at 2048 games x 100 simulations;
+  * the native arena (ArenaRunner: two 128-channel nets in one multi-model launch, the whole move one hipGraph) at 256 games x
+    100 simulations against its host-split form, and at 64 games against the CPU oracle (reference routing bug off) fed by
+    the same networks, past the first finished games.
+
+Integer / index work is compared bit-exactly (torch.equal); the networks are the same kernels on both sides, and a board's
+probabilities do not depend on its batch position (tests/test_gpu_nnet.py), so the float tree values are bit-equal too."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(seed):
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
+    torch.manual_seed(seed)
+    n = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    n.refresh()
+    return n
+
+
+def _args(**kw):
+    from alphazero_general_amd.utils import dotdict, default_temp_scaling
+    a = dotdict(numMCTSSims=100, numFastSims=20, probFastSim=0.0, gamesPerIteration=1 << 30, cpuct=4.0, fpu_reduction=0.4,
+                root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0, add_root_noise=True, add_root_temp=True,
+                symmetricSamples=True, mctsResetThreshold=0, startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
+    a.update(kw)
+    return a
+
+
+def test_search_launch_equals_phase_launches_at_2048x100():
+    """the bench's launch (2048 games, 100 simulations per launch, noise + root temperature on) for 4 moves from the start and 3
+    more after 12 cheaper moves (mid-game trees, compaction has run): visit counts, pi at T = 1, sampled actions, tape counters,
+    counters and the emitted samples must be identical to the three-launch path."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    hip = _net(0)._hip
+    B, sims = 2048, 100
+    kw = dict(cpuct=4.0, fpu_reduction=0.4, add_root_noise=True, add_root_temp=True, seed=0, games_per_iteration=1 << 30,
+              example_capacity=B * 43 * 2 * 2, sims_hint=sims)
+    ea, eb = DeviceEngine(0, B, **kw), DeviceEngine(0, B, **kw)
+    obs = torch.zeros((B, 42, 8), dtype=torch.float16, device=ea.device)
+
+    def move(n):
+        hip.search(ea, n)
+        for _ in range(n):
+            eb.select(obs)
+            p, v = hip.forward_nhwc8(obs)
+            eb.backup(p, v)
+        assert torch.equal(ea.root_counts(), eb.root_counts())
+        assert torch.equal(ea.root_probs(1.0), eb.root_probs(1.0))
+        assert torch.equal(ea.root_value(False), eb.root_value(False))
+        ea.advance(True); eb.advance(True)
+        assert torch.equal(ea.last_actions(), eb.last_actions())
+        assert (ea.tape_counters() == eb.tape_counters()).all()
+
+    for _ in range(4):
+        move(sims)
+    for _ in range(12):
+        move(9)
+    for _ in range(3):
+        move(sims)
+    a, b = ea.counters(), eb.counters()
+    assert a == b and a['sims'] == B * (7 * sims + 12 * 9) and a['games_played'] > 0
+    for x, y in zip(ea.examples(), eb.examples()):
+        assert x.shape[0] > 0 and torch.equal(x, y)
+    for x, y in zip(ea.results(), eb.results()):
+        assert (x == y).all()
+
+
+def test_arena_256x100_graph_equals_host_split():
+    """config 4 at its per-GPU size: 256 concurrent games x 100 simulations, two differently seeded 128ch x 8 nets.  The product
+    path (device-side row split, both models in one launch, a whole move replayed as one hipGraph) against the host-split loop
+    (one .cpu() read of the split per simulation, one launch per model): same moves, tallies and results after 16 moves."""
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.selfplay import ArenaRunner
+    nets = [_net(0), _net(1)]
+    runs = []
+    for mode in ('graph', 'host'):
+        r = ArenaRunner(Game, nets, _args(), num_slots=256, seed=3, use_graph=(mode == 'graph'))
+        assert r.device_split and (r._graph is not None) == (mode == 'graph')
+        if mode == 'host':
+            r.device_split = False
+        acts = []
+        for _ in range(16):
+            r.play_round()
+            acts.append(r.engine.last_actions().cpu().numpy().copy())
+        runs.append((np.array(acts), r.engine.counters(), r.results(), [x.copy() for x in r.engine.results()]))
+    (a0, c0, res0, raw0), (a1, c1, res1, raw1) = runs
+    assert (a0 == a1).all() and c0 == c1 and res0 == res1
+    assert c0['sims'] == 256 * 100 * 16 and c0['games_played'] > 0                   # games have ended and restarted
+    for x, y in zip(raw0, raw1):
+        assert (x == y).all()
+
+
+def test_arena_64_slots_vs_oracle_with_real_nets():
+    """64 arena games x 40 simulations, both sides evaluated by the same two networks, until 70 games have finished (every slot
+    has restarted at least once, the batch split between the models changes every simulation): the native runner's graph
+    against the CPU oracle with the reference's row mis-routing switched off.  Actions, tallies, results."""
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.selfplay import ArenaRunner
+    nets = [_net(0), _net(1)]
+    B, sims, games, seed = 64, 40, 70, 11
+    r = ArenaRunner(Game, nets, _args(numMCTSSims=sims, gamesPerIteration=games), num_slots=B, seed=seed)
+    ag = ol.OAgent(0, B, sims=sims, games_per_iteration=games, seed=seed, cpuct=4.0, fpu_reduction=0.4, is_arena=True, ref_misroute=False)
+    assert ag.player_to_index() == r.player_to_index
+    rounds = 0
+    while ag.games_played < games:
+        ag.begin_round()
+        for _ in range(sims):
+            oobs, rg, rm = ag.generate_batch()
+            pol = np.zeros((B, 7), np.float32); val = np.zeros((B, 3), np.float32)
+            for m, n in enumerate(nets):
+                idx = np.flatnonzero(rm == m)
+                if len(idx):
+                    p, v = n.process(torch.from_numpy(oobs[idx]))
+                    pol[idx], val[idx] = p.cpu().numpy(), v.cpu().numpy()
+            ag.process_batch(pol, val)
+        ag.play_moves()
+        r.play_round()
+        assert (r.engine.last_actions().cpu().numpy() == ag.last_actions()).all(), rounds
+        rounds += 1
+    c = r.engine.counters()
+    assert c['games_played'] == ag.games_played == games and c['sims'] == ag.sims_done and c['expansions'] == ag.expansions
+    ws, turns, slot = r.engine.results()
+    ows, oturns, oslot = ag.results()
+    assert (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all() and len(ws) >= games

@@ -33,8 +33,18 @@ def rocprof(tag, extra, bench_args, timeout=600):
     return out, (line[0] if line else None), r.returncode
 
 
+_DEMANGLED = {}
+
+
 def short(name):
-    """a readable kernel label: template name up to the argument list"""
+    """a readable kernel label: demangled template name up to the argument list"""
+    if name.startswith('_Z'):
+        if name not in _DEMANGLED:
+            try:
+                _DEMANGLED[name] = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], stdout=subprocess.PIPE, timeout=20).stdout.decode().strip() or name
+            except Exception:
+                _DEMANGLED[name] = name
+        name = _DEMANGLED[name]
     n = name.replace('void ', '').replace('azg::', '')
     return n.split('(')[0][:120]
 
