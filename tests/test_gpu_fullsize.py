@@ -133,3 +133,74 @@ def test_arena_64_slots_vs_oracle_with_real_nets():
     ws, turns, slot = r.engine.results()
     ows, oturns, oslot = ag.results()
     assert (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all() and len(ws) >= games
+
+
+@pytest.mark.parametrize('game,B,sims,moves', [(0, 192, 24, 44), (1, 48, 40, 36)])
+def test_node_reclamation_is_invisible(game, B, sims, moves):
+    """Semi-space compaction of the node store after a move (the GPU counterpart of the reference dropping the played move's
+    siblings, MCTS.pyx:185-195) must not change a single result: an engine whose node store is so small that it compacts after
+    nearly every move against one that never has to -- same counts, moves, samples, results, tape counters -- while its live
+    store stays bounded.  Both the separate and the fused (backup + select, two wavefronts) launches are used."""
+    import torch
+    from alphazero_general_amd import _abi
+    from alphazero_general_amd.engine import DeviceEngine
+    gi = _abi.game_info(game)
+    A, NV = gi.action_size, gi.num_players + 1
+    per_move = sims * gi.max_children
+    kw = dict(cpuct=1.5, fpu_reduction=0.3, add_root_noise=True, add_root_temp=True, seed=5, games_per_iteration=1 << 30,
+              example_capacity=B * (gi.max_turns + 1) * gi.num_symmetries * 2, sims_hint=sims)
+    big = DeviceEngine(game, B, nodes_per_tree=(moves + 2) * per_move, **kw)             # never compacts
+    small = DeviceEngine(game, B, nodes_per_tree=4 * per_move, **kw)                    # compacts whenever < 1 move's worth is free
+    g = torch.Generator(device='cpu'); g.manual_seed(2)
+    obs_b, obs_s = big.new_obs(torch.float16), small.new_obs(torch.float16)
+    peak_small = 0
+    for mv in range(moves):
+        big.select(obs_b); small.select(obs_s)
+        for s in range(sims):
+            pol = torch.rand((B, A), generator=g) ** 3 + 1e-4                           # peaked priors: deep, reused subtrees
+            pol = (pol / pol.sum(1, keepdim=True)).to(big.device)
+            val = torch.rand((B, NV), generator=g) + 1e-3
+            val = (val / val.sum(1, keepdim=True)).to(big.device)
+            if s + 1 < sims:
+                big.backup_select(pol, val, obs_b); small.backup_select(pol, val, obs_s)
+                if s % 8 == 0:
+                    assert torch.equal(obs_b, obs_s), (mv, s, small.counters())
+            else:
+                big.backup(pol, val); small.backup(pol, val)
+        assert torch.equal(big.root_counts(), small.root_counts()), mv
+        assert torch.equal(big.root_value(True), small.root_value(True))
+        peak_small = max(peak_small, small.counters()['max_nodes_used'])
+        big.advance(True); small.advance(True)
+        assert torch.equal(big.last_actions(), small.last_actions())
+    cb, cs = big.counters(), small.counters()
+    assert cb['max_nodes_used'] > 4 * per_move >= peak_small                            # the big store really outgrew the small one
+    for k in ('sims', 'expansions', 'games_played', 'num_results', 'num_examples'):
+        assert cb[k] == cs[k], k
+    assert cb['games_played'] > 0
+    assert (big.tape_counters() == small.tape_counters()).all()
+    for x, y in zip(big.examples(), small.examples()):
+        assert torch.equal(x, y)
+    for x, y in zip(big.results(), small.results()):
+        assert (x == y).all()
+
+
+def test_brandubh_4096_games_fit_one_gpu():
+    """BASELINE config 3's WHOLE job (4096 games x 200 simulations) on one GPU: with reclaimed node stores the trees take
+    4096 x 2 x 153 664 nodes x 32 B = 40 GB (round 1: 82 MB per tree = 336 GB, did not fit).  A short run, properties only."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    B, sims = 4096, 200
+    eng = DeviceEngine(1, B, cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=1, sims_hint=sims,
+                       example_capacity=B * 8, games_per_iteration=1 << 30)
+    pol = torch.full((B, eng.A), 1.0 / eng.A, device=eng.device); val = torch.full((B, eng.NV), 1.0 / eng.NV, device=eng.device)
+    obs = torch.zeros((B, 49, 8), dtype=torch.float16, device=eng.device)
+    for mv in range(2):
+        eng.select(obs)
+        for s in range(24):
+            eng.backup_select(pol, val, obs)
+        eng.backup(pol, val)
+        eng.advance(True)
+    c = eng.counters()
+    assert c['sims'] == 2 * 25 * B and 0 < c['max_nodes_used'] <= 8 * sims * 96 + 64
+    assert all(t == 2 for (_, _, t) in eng.get_states(B - 4, 4))
+    eng.close()
