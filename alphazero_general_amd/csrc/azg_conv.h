@@ -39,6 +39,14 @@ struct TowerParams {
     float *policy, *value;    // [boards, A], [boards, NV]
     int A, NV;
     unsigned long long *dbg;  // AZG_TOWER_TIMING builds only: s_memtime stamps of workgroup 0 [layer][wave][5]
+    // optional factorised heads, first stage (head1_w != null, head_w == null): instead of the final stream the launch writes the
+    // 32 head channels of every pixel -- the two 1x1 head convolutions with their BatchNorms folded (NNetArchitecture.py:88-89,
+    // 97-98), 16 policy channels then 16 value channels -- as feature rows feat[board][2][feat_k] fp16, feature index pos * 16 + c
+    // (feat_k = H*W*16 rounded up to 32; the padding is never written: the buffer must start zeroed)
+    const void *head1_w;      // packed fragments [C/32][2][64] x 16 B: lane g*16+i holds W1[out = ms*16 + i][cin = ks*32 + g*8 + j]
+    const float *head1_b;     // [32]
+    void *feat;
+    int feat_k;
     // optional multi-model launch (the arena: every model evaluates its own contiguous slice of the leaf batch and the split
     // is only known on the device): model m owns boards [sum(rows_per_model[0..m)), + rows_per_model[m]) of x / policy /
     // value / y and brings its own parameters (model 0: the fields above, model m > 0: alt[m-1]); tiles never straddle
@@ -376,7 +384,48 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             AZG_STAMP2(4);
         }
         AZG_WGSTAMP(5);
-        if (P.head_w == nullptr) {
+        if (P.head_w == nullptr && P.head1_w != nullptr) {
+            // first stage of the factorised heads: 32 head channels per pixel, centre tap only; the waves of cout group 0
+            // compute them for their own pixel subtiles straight out of the image (the final stream)
+            if (cg == 0) {
+                int opaque = 0;
+                asm volatile("" : "+s"(opaque));                 // (keeps these loop invariants from being hoisted across the layers)
+                const half8 *hw1 = reinterpret_cast<const half8 *>(P.head1_w) + lane + opaque;
+                floatx4 hacc[2][NSUB];
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const int c0 = m * 16 + g * 4;
+                    const floatx4 bv = {P.head1_b[c0], P.head1_b[c0 + 1], P.head1_b[c0 + 2], P.head1_b[c0 + 3]};
+#pragma unroll
+                    for (int ps = 0; ps < NSUB; ps++) hacc[m][ps] = bv;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const half8 a0 = hw1[(size_t)(ks * 2) * 64], a1 = hw1[(size_t)(ks * 2 + 1) * 64];
+#pragma unroll
+                    for (int ps = 0; ps < NSUB; ps++) {
+                        const half8 b = *reinterpret_cast<const half8 *>(img + lb[ps] + (GEO::BIAS + ks * 64));
+                        hacc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, hacc[0][ps], 0, 0, 0);
+                        hacc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, hacc[1][ps], 0, 0, 0);
+                    }
+                }
+                _Float16 *fg = reinterpret_cast<_Float16 *>(P.feat);
+#pragma unroll
+                for (int ps = 0; ps < NSUB; ps++) {
+                    const int gs = ph * NSUB + ps;
+                    const int p = gs < NSUBT ? pixmap[min(gs, NSUBT - 1) * 16 + i16] : -1;
+                    if (p >= 0 && p < rows_here) {
+                        const int bd = p / HW, pos = p - bd * HW;
+                        _Float16 *dst = fg + (size_t)(tile * BOARDS + bd) * 2 * P.feat_k + pos * 16 + g * 4;
+#pragma unroll
+                        for (int m = 0; m < 2; m++) {
+                            const half4 h = {(_Float16)hacc[m][ps][0], (_Float16)hacc[m][ps][1], (_Float16)hacc[m][ps][2], (_Float16)hacc[m][ps][3]};
+                            *reinterpret_cast<half4 *>(dst + m * P.feat_k) = h;
+                        }
+                    }
+                }
+            }
+        } else if (P.head_w == nullptr) {
             uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * CPR;
             for (int c = tid; c < rows_here * CPR; c += NT) {
                 const int p = c / CPR, chunk = c - p * CPR;
@@ -492,24 +541,21 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
 // The job is L2->CU bandwidth bound: (HEAD_NS*16 + 16) * K * 2 bytes per workgroup.
 constexpr int HEAD_NS = 5, HEAD_WAVES = 8, HEAD_U = 4;   // (batches of 2-4 k-steps measured best; 7 is 2-6 % slower)
 
-__global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
-                                                          int ksteps, int osub) {
-    __shared__ float red[HEAD_WAVES][HEAD_NS * 256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
-    const int nchunks = (osub + HEAD_NS - 1) / HEAD_NS, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
-    const int b0 = grp * 16, s0 = chunk * HEAD_NS, opad = osub * 16;
-    const size_t K8 = (size_t)ksteps * 4;                                     // half8 per board row
-    const half8 *yrow = reinterpret_cast<const half8 *>(y) + (size_t)min(b0 + i16, boards - 1) * K8 + g;
-    const half8 *wl = wp + (size_t)s0 * 64 + lane;
+// One workgroup of the heads GEMM: 16 boards x nsub <= HEAD_NS output subtiles over `ksteps` k-steps of 32.  yrow: this lane's A
+// operand stream (board i16, k offset g * 8); wl: this lane's B fragments of subtile 0 of the chunk, `wstride` fragments (64 lanes
+// each) from one k-step to the next.  The eight waves split K and work in batches of HEAD_U k-steps: all the fragment loads of a
+// batch are issued back to back (the job is L2 latency and bandwidth, not MFMA), branch-free: subtiles past the end re-read the
+// last real one (their accumulators are never stored), k-steps past the end re-read the last one with the A fragment zeroed.
+// logits[board][out0 + s * 16 + i] for s < nsub, columns below out_lim only.
+__device__ __forceinline__ void heads_chunk(float (*red)[HEAD_NS * 256], const half8 *yrow, const half8 *wl, size_t wstride, int ksteps, int nsub,
+                                            const float *bias, float *logits, int opad, int b0, int boards, int out0, int out_lim) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     floatx4 acc[HEAD_NS];
 #pragma unroll
     for (int s = 0; s < HEAD_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    // The waves split K (k-steps wave, wave + 8, ...) and work in batches of HEAD_U k-steps: all 6 * HEAD_U fragment loads of a
-    // batch are issued back to back (the job is L2 latency and bandwidth, not MFMA), branch-free: subtiles past the end re-read the last real
-    // one (their accumulators are never stored), k-steps past the end re-read the last one with the A fragment zeroed.
     size_t soff[HEAD_NS];
 #pragma unroll
-    for (int s = 0; s < HEAD_NS; s++) soff[s] = (size_t)(min(s0 + s, osub - 1) - s0) * 64;
+    for (int s = 0; s < HEAD_NS; s++) soff[s] = (size_t)min(s, nsub - 1) * 64;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k0 = wave; k0 < ksteps; k0 += HEAD_WAVES * HEAD_U) {
         half8 a[HEAD_U], b[HEAD_U][HEAD_NS];
@@ -519,7 +565,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, co
             a[u] = yrow[(size_t)kc * 4];
             if (ks >= ksteps) a[u] = zero8;
 #pragma unroll
-            for (int s = 0; s < HEAD_NS; s++) b[u][s] = wl[(size_t)kc * osub * 64 + soff[s]];
+            for (int s = 0; s < HEAD_NS; s++) b[u][s] = wl[(size_t)kc * wstride + soff[s]];
         }
         __builtin_amdgcn_sched_barrier(0);                      // (left alone hipcc sinks every load next to its MFMA and waits)
 #pragma unroll
@@ -533,11 +579,42 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, co
         for (int r = 0; r < 4; r++) red[wave][(s * 4 + r) * 64 + lane] = acc[s][r];
     __syncthreads();
     for (int e = tid; e < HEAD_NS * 256; e += HEAD_WAVES * 64) {              // D[m = board g*4 + r][n = output i16]
-        const int s = e >> 8, r = (e >> 6) & 3, ln = e & 63, board = b0 + (ln >> 4) * 4 + r, out = (s0 + s) * 16 + (ln & 15);
+        const int s = e >> 8, r = (e >> 6) & 3, ln = e & 63, board = b0 + (ln >> 4) * 4 + r, out = out0 + s * 16 + (ln & 15);
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < HEAD_WAVES; w++) sum += red[w][e];
-        if (board < boards && s0 + s < osub) logits[(size_t)board * opad + out] = sum + bias[out];
+        if (board < boards && s < nsub && out < out_lim) logits[(size_t)board * opad + out] = sum + bias[out];
+    }
+}
+
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
+                                                          int ksteps, int osub) {
+    __shared__ float red[HEAD_WAVES][HEAD_NS * 256];
+    const int lane = threadIdx.x & 63, g = lane >> 4, i16 = lane & 15;
+    const int nchunks = (osub + HEAD_NS - 1) / HEAD_NS, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
+    const int b0 = grp * 16, s0 = chunk * HEAD_NS;
+    const half8 *yrow = reinterpret_cast<const half8 *>(y) + (size_t)min(b0 + i16, boards - 1) * ((size_t)ksteps * 4) + g;
+    heads_chunk(red, yrow, wp + (size_t)s0 * 64 + lane, (size_t)osub * 64, ksteps, min(HEAD_NS, osub - s0), bias, logits, osub * 16, b0, boards,
+                s0 * 16, osub * 16);
+}
+
+// Second stage of the factorised heads (NNetArchitecture.py:90-93,99-102, the Linear chains collapsed: they have no activation):
+// policy logits from the 16 policy channels of every pixel, value logits from the 16 value channels, out of the feature rows
+// feat[board][2][fk] the tower launch wrote.  Chunks 0 .. nchunks_p - 1 of a board group are policy output subtiles
+// (k-steps over the first feature half, weights wp [fk/32][osp][64]), the last chunk is the value subtile (second half,
+// weights wv [fk/32][1][64]).  A quarter of the weight traffic of the fully collapsed [H*W*C, A + NV] matrix at 64 channels.
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads_fact(const _Float16 *feat, const half8 *wp, const half8 *wv, const float *bias, float *logits,
+                                                               int boards, int fk, int osp, int A, int NV, int opad) {
+    __shared__ float red[HEAD_WAVES][HEAD_NS * 256];
+    const int lane = threadIdx.x & 63, g = lane >> 4, i16 = lane & 15;
+    const int ncp = (osp + HEAD_NS - 1) / HEAD_NS, nchunks = ncp + 1, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
+    const int b0 = grp * 16, ksteps = fk / 32;
+    const half8 *frow = reinterpret_cast<const half8 *>(feat) + (size_t)min(b0 + i16, boards - 1) * ((size_t)fk / 4) + g;    // 2 * fk halves per board
+    if (chunk < ncp) {
+        const int s0 = chunk * HEAD_NS;
+        heads_chunk(red, frow, wp + (size_t)s0 * 64 + lane, (size_t)osp * 64, ksteps, min(HEAD_NS, osp - s0), bias, logits, opad, b0, boards, s0 * 16, A);
+    } else {
+        heads_chunk(red, frow + fk / 8, wv + lane, (size_t)64, ksteps, 1, bias, logits, opad, b0, boards, A, A + NV);
     }
 }
 

@@ -692,7 +692,21 @@ extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const
                                     const float *pre_shift, void *y, int boards, int nblocks, int channels) {
     if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
-    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, {}};
+    TowerParams P{x, w, bias, pre_scale, pre_shift, y, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, {}};
+    EvPair ep; const bool prof = netprof_begin((hipStream_t)stream, ep);
+    const int r = dispatch_tower((hipStream_t)stream, game, channels, P);
+    netprof_end((hipStream_t)stream, 0, prof, ep);
+    return r;
+}
+
+extern "C" int azg_resnet_tower_features_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
+                                             const float *pre_shift, int boards, int nblocks, int channels, const void *head1_w, const float *head1_b,
+                                             void *feat, int feat_k) {
+    if (!x || !w || !bias || !head1_w || !head1_b || !feat || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
+    if (feat_k <= 0 || (feat_k & 31)) return fail(AZG_E_INVALID_ARG, "feat_k must be a positive multiple of 32");
+    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, head1_w, head1_b, feat, feat_k,
+                  nullptr, 0, {}};
     EvPair ep; const bool prof = netprof_begin((hipStream_t)stream, ep);
     const int r = dispatch_tower((hipStream_t)stream, game, channels, P);
     netprof_end((hipStream_t)stream, 0, prof, ep);
@@ -705,7 +719,7 @@ extern "C" int azg_resnet_policy_value_f16(void *stream, int game, const void *x
     if (!x || !w || !bias || !head_w || !head_b || !policy || !value || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");
     if (A <= 0 || NV <= 0 || A + NV > 16) return fail(AZG_E_UNSUPPORTED, "fused heads need A + NV <= 16");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
-    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr, nullptr, 0, {}};
+    TowerParams P{x, w, bias, pre_scale, pre_shift, nullptr, boards, nblocks, head_w, head_b, policy, value, A, NV, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, {}};
     EvPair ep; const bool prof = netprof_begin((hipStream_t)stream, ep);
     const int r = dispatch_tower((hipStream_t)stream, game, 128, P);
     netprof_end((hipStream_t)stream, 0, prof, ep);
@@ -725,7 +739,7 @@ extern "C" int azg_resnet_policy_value_multi_f16(void *stream, int game, const v
         if (!w[m] || !bias[m] || !head_w[m] || !head_b[m] || (nblocks > 0 && (!pre_scale[m] || !pre_shift[m]))) return fail(AZG_E_INVALID_ARG, "null model parameter");
     // the grid is sized for max_boards rows plus one partial tile per extra model
     TowerParams P{x, w[0], bias[0], nblocks ? pre_scale[0] : nullptr, nblocks ? pre_shift[0] : nullptr, nullptr, max_boards, nblocks,
-                  head_w[0], head_b[0], policy, value, A, NV, nullptr, rows_per_model, nmodels, {}};
+                  head_w[0], head_b[0], policy, value, A, NV, nullptr, nullptr, nullptr, nullptr, 0, rows_per_model, nmodels, {}};
     for (int m = 1; m < nmodels; m++)
         P.alt[m - 1] = TowerParams::Model{w[m], bias[m], nblocks ? pre_scale[m] : nullptr, nblocks ? pre_shift[m] : nullptr, head_w[m], head_b[m]};
     EvPair ep; const bool prof = netprof_begin((hipStream_t)stream, ep);
@@ -741,7 +755,7 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     if (e->cfg.game != AZG_GAME_CONNECT4 || e->v.arena)
         return fail(AZG_E_UNSUPPORTED, "the fused search kernel is built for connect4 self-play with a 128-channel tower (use azg_select / network / azg_backup)");
     const int A = e->gi.action_size, NV = e->gi.num_players + 1;
-    TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, head_w, head_b, nullptr, nullptr, A, NV, nullptr, nullptr, 0, {}};
+    TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, head_w, head_b, nullptr, nullptr, A, NV, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, {}};
     SearchArgs<C4> sa{e->v, sims};
     EvPair ep; const bool prof = sims > 0 && netprof_begin((hipStream_t)stream, ep);
     const int r = launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
@@ -760,6 +774,22 @@ extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const voi
                        boards, k / 32, osub);
     netprof_end(s, 1, prof, ep);
     if (policy)                                              // (NULL: leave the logits for azg_backup_select_logits)
+        hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_policy_value_heads_fact_f16(void *stream, const void *feat, const void *wp_packed, const void *wv_packed, const float *head_b, int boards,
+                                               int feat_k, int A, int NV, float *logits_ws, float *policy, float *value) {
+    if (!feat || !wp_packed || !wv_packed || !head_b || !logits_ws || (!policy != !value)) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (boards <= 0 || feat_k <= 0 || (feat_k & 31) || A <= 0 || A > 1024 || NV <= 0 || NV > 16) return fail(AZG_E_INVALID_ARG, "boards > 0, feat_k a multiple of 32, 0 < A <= 1024, 0 < NV <= 16");
+    const int osp = (A + 15) / 16, osub = (A + NV + 15) / 16, ncp = (osp + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    EvPair ep; const bool prof = netprof_begin(s, ep);
+    hipLaunchKernelGGL(k_heads_fact, dim3(groups * (ncp + 1)), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)feat, (const half8 *)wp_packed, (const half8 *)wv_packed,
+                       head_b, logits_ws, boards, feat_k, osp, A, NV, osub * 16);
+    netprof_end(s, 1, prof, ep);
+    if (policy)
         hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
     HIPCHK(hipGetLastError());
     return AZG_OK;

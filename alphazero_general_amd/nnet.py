@@ -276,6 +276,28 @@ class HipResNet:
             self.head_b_wide = torch.zeros(OS * 16, **f32)
             self.head_b_wide[:A + NV] = self.head_b
             self.head_opad = OS * 16
+            # the heads FACTORISED like the reference computes them (1x1 head convs in the tower launch, then the collapsed
+            # Linear chains on 16 + 16 head channels per pixel): a quarter of the collapsed matrix's weight traffic at 64 channels
+            pc = hw.shape[0] - vc
+            self.fact_head = (not self.fused_head) and vc == 16 and pc == 16
+            if self.fact_head:
+                FK = (HW * 16 + 31) // 32 * 32
+                self.feat_k = FK
+                w1 = torch.cat([hw[vc:], hw[:vc]])                                            # [32, CH]: policy rows, then value rows
+                # A fragments [ks][ms][lane g*16+i][j] = W1[ms*16 + i, ks*32 + g*8 + j]
+                self.head1_w = w1.reshape(2, 16, CH // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().reshape(-1) \
+                                 .to(self.device, torch.float16).contiguous()
+                self.head1_b = torch.cat([hb[vc:], hb[:vc]]).to(**f32).contiguous()
+                OSP = (A + 15) // 16
+                w2p = torch.zeros((FK, OSP * 16), dtype=torch.float32, device=Wp.device)      # feature pos*16 + c  <-  flatten index c*HW + pos
+                w2p[:HW * 16, :A] = Wp.reshape(A, pc, HW).permute(2, 1, 0).reshape(HW * pc, A)
+                w2v = torch.zeros((FK, 16), dtype=torch.float32, device=Wv.device)
+                w2v[:HW * 16, :NV] = Wv.reshape(NV, vc, HW).permute(2, 1, 0).reshape(HW * vc, NV)
+                frag = lambda w, osub: w.reshape(FK // 32, 4, 8, osub, 16).permute(0, 3, 1, 4, 2).contiguous().reshape(-1) \
+                                        .to(self.device, torch.float16).contiguous()
+                self.head2_wp, self.head2_wv = frag(w2p, OSP), frag(w2v, 1)
+                self.head2_b = torch.zeros(OS * 16, **f32)
+                self.head2_b[:A] = bp; self.head2_b[A:A + NV] = bv
         self._bufs = {}
 
     @property
@@ -318,16 +340,25 @@ class HipResNet:
                                                            vp(self.tower_pt), int(B), len(self.blocks), vp(self.head_w_packed),
                                                            vp(self.head_b16), int(self.A), int(self.NV), vp(pol), vp(val)))
             return pol, val
-        s = self._buffers(B, key)
-        import ctypes as C                                       # tower: one persistent launch, activations resident in LDS
+        import ctypes as C
         vp = lambda q: C.c_void_p(q.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        self._check(self.L.azg_resnet_tower_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
-                                                vp(self.tower_pt), vp(s), int(B), len(self.blocks), int(self.CH)))
-        # heads GEMM + both softmaxes: two launches (or one, stopping at the logits)
         pol, val, ws = [t[:B] for t in self._scratch('pvw', key, B, lambda n: tuple(
             torch.empty((n, w), dtype=torch.float32, device=self.device) for w in (self.A, self.NV, self.head_opad)))]
         null = C.c_void_p(0)
+        if self.fact_head:                                       # tower + 1x1 head convs: one launch; collapsed dense chains: one more
+            feat = self._scratch('feat', key, B, lambda n: (torch.zeros((n, 2 * self.feat_k), dtype=torch.float16, device=self.device),))[0][:B]
+            self._check(self.L.azg_resnet_tower_features_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
+                                                             vp(self.tower_pt), int(B), len(self.blocks), int(self.CH), vp(self.head1_w),
+                                                             vp(self.head1_b), vp(feat), int(self.feat_k)))
+            self._check(self.L.azg_policy_value_heads_fact_f16(st, vp(feat), vp(self.head2_wp), vp(self.head2_wv), vp(self.head2_b), int(B),
+                                                               int(self.feat_k), int(self.A), int(self.NV), vp(ws),
+                                                               null if logits_only else vp(pol), null if logits_only else vp(val)))
+            return ws if logits_only else (pol, val)
+        s = self._buffers(B, key)                                # tower: one persistent launch, activations resident in LDS
+        self._check(self.L.azg_resnet_tower_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
+                                                vp(self.tower_pt), vp(s), int(B), len(self.blocks), int(self.CH)))
+        # fully collapsed heads GEMM + both softmaxes: two launches (or one, stopping at the logits)
         self._check(self.L.azg_policy_value_heads_f16(st, vp(s), vp(self.head_w_wide), vp(self.head_b_wide), int(B), self.HW * self.CH,
                                                       int(self.A), int(self.NV), vp(ws), null if logits_only else vp(pol),
                                                       null if logits_only else vp(val)))

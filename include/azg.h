@@ -248,6 +248,22 @@ int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const
 int  azg_policy_value_heads_f16(void *stream, const void *y_dev, const void *head_w_packed_dev, const float *head_b_dev,
                                 int boards, int k, int A, int NV, float *logits_ws_dev, float *policy_dev, float *value_dev);
 
+/* The same heads FACTORISED the way the reference computes them (NNetArchitecture.py:88-102): stage 1 inside the tower launch --
+ * the two 1x1 head convolutions (+ BatchNorm, folded), 16 policy and 16 value channels per pixel, written as feature rows
+ * feat_dev[boards][2][feat_k] fp16 (policy half then value half, feature index pos * 16 + channel, feat_k = H*W*16 rounded up to
+ * 32; the buffer must start zeroed, the padding is never written) instead of the final stream; head1_w_packed: fragments
+ * [C/32][2][64 lanes][8 halves], lane g*16+i, half j = W1[out = ms*16 + i][cin = ks*32 + g*8 + j], rows 0-15 policy, 16-31 value;
+ * head1_b: f32[32].  Stage 2 = azg_policy_value_heads_fact_f16: the collapsed Linear chains, policy logits from the policy half
+ * (wp_packed [feat_k/32][ceil(A/16)][64][8], half j of lane g*16+i = Wp[k = ks*32 + g*8 + j][out = sub*16 + i]), value logits from
+ * the value half (wv_packed [feat_k/32][64][8]); head_b / logits_ws / policy / value as azg_policy_value_heads_f16.  For 64
+ * channels a quarter of the weight traffic of the fully collapsed matrix.  Needs 16 + 16 head channels. */
+int  azg_resnet_tower_features_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
+                                   const float *pre_scale_dev, const float *pre_shift_dev, int boards, int nblocks, int channels,
+                                   const void *head1_w_packed_dev, const float *head1_b_dev, void *feat_dev, int feat_k);
+int  azg_policy_value_heads_fact_f16(void *stream, const void *feat_dev, const void *wp_packed_dev, const void *wv_packed_dev,
+                                     const float *head_b_dev, int boards, int feat_k, int A, int NV, float *logits_ws_dev,
+                                     float *policy_dev, float *value_dev);
+
 /* Host-side layout tables of one tower instantiation (no device needed; for tests and tooling): pixmap[NSUB*16] = pixel of
  * (subtile, lane & 15) or -1, qrow[ROWS] = padded LDS row of pixel p, info8 = {NSUB, ROWS, row stride B, tile rows, tile bytes,
  * padded width, lead rows, board stride}.  pixmap / qrow may be NULL.  AZG_E_UNSUPPORTED for a shape that is not instantiated. */
