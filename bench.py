@@ -105,6 +105,23 @@ def measured_traffic(workload, kernel_substr):
     return None, None
 
 
+def library_gemm_tflops(dev, n=8192, reps=10):
+    """best plain fp16 n^3 GEMM through torch (hipBLASLt) on this GPU, TFLOP/s: context for the MFMA fraction."""
+    x = torch.randn(n, n, device=dev, dtype=torch.float16); y = torch.randn(n, n, device=dev, dtype=torch.float16)
+    best = 0.0
+    for _ in range(2):
+        for _ in range(3):
+            x @ y
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            x @ y
+        e1.record(); torch.cuda.synchronize()
+        best = max(best, 2 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
 # ---------------------------------------------------------------------------------------------- CPU baseline (rank 0, N = 1)
 def cpu_baseline(W, nets, arena=False, budget_s=24.0):
     """The CPU path timed beside the GPU number: the C oracle -- the bit-exact restatement of the reference's
@@ -345,6 +362,10 @@ def main():
     }
     if roof_net is not None and roofline is not roof_net:
         out['net_roofline'] = roof_net
+    if world == 1 and roofline is not None and roofline['bound'] == 'mfma':
+        lib_tf = library_gemm_tflops(dev)                            # outside the timed region
+        roofline['library_gemm_tflops'] = round(lib_tf, 1)
+        roofline['vs_library_gemm'] = round(roofline['achieved'] / lib_tf, 3)
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(W, nets if arena else [net], arena)
     print(json.dumps(out))
