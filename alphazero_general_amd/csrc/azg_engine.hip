@@ -1,6 +1,7 @@
 // azg_engine.hip -- host side of libazg_hip.so: the C ABI of include/azg.h over the kernels of azg_kernels.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC  (alphazero_general_amd/build.py)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +17,15 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(AZG_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
 
-struct EvPair { hipEvent_t a, b; };
+struct EvPair { hipEvent_t a, b; bool ext; };
+
+// Timing of ONE kernel: while a profile hook is armed (g_kev), the next AZG_LAUNCH goes through hipExtLaunchKernelGGL, which stamps
+// the pair's events with the dispatch's own begin / end timestamps -- the kernel's execution time as rocprofv3 reports it, without
+// the ~2 us of marker packets that hipEventRecord brackets add to a 10 us kernel.
+static thread_local EvPair *g_kev = nullptr;
+#define AZG_LAUNCH(kernel, grid, block, lds, stream, ...) do { \
+    if (g_kev) { hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_kev->a, g_kev->b, 0, __VA_ARGS__); g_kev = nullptr; } \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); } while (0)
 
 struct azg_engine {
     azg_config cfg;
@@ -92,12 +101,13 @@ static void prof_begin(azg_engine *e, hipStream_t s, int fam, EvPair &p) {
     if (!e->profile) return;
     if (!e->pool.empty()) { p = e->pool.back(); e->pool.pop_back(); }
     else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
-    (void)hipEventRecord(p.a, s);
-    (void)fam;
+    p.ext = fam != 2;                                          // select / backup: one kernel each; advance: a sequence of launches
+    if (p.ext) g_kev = &p; else (void)hipEventRecord(p.a, s);
 }
 static void prof_end(azg_engine *e, hipStream_t s, int fam, EvPair &p) {
     if (!e->profile) return;
-    (void)hipEventRecord(p.b, s);
+    if (!p.ext) (void)hipEventRecord(p.b, s);
+    g_kev = nullptr;
     e->ev[fam].push_back(p);
     e->launches[fam]++;
 }
@@ -254,9 +264,9 @@ extern "C" int azg_select(azg_engine *e, void *stream, void *obs, int obs_dtype,
     if (obs_dtype < 0 || obs_dtype > 2) return fail(AZG_E_INVALID_ARG, "obs_dtype must be 0 (f32), 1 (f16) or 2 (f16 NHWC8)");
     hipStream_t s = (hipStream_t)stream;
     EvPair p; prof_begin(e, s, 0, p);
-    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, float>), dim3(e->v.B), dim3(64), 0, s, e->v, (float *)obs, row_of_slot)); }
-    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, _Float16>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
-    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_select<G, _Float16, true>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
+    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_select<G, float>), dim3(e->v.B), dim3(64), 0, s, e->v, (float *)obs, row_of_slot)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_select<G, _Float16>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
+    else { GAME_SWITCH(e, AZG_LAUNCH((k_select<G, _Float16, true>), dim3(e->v.B), dim3(64), 0, s, e->v, (_Float16 *)obs, row_of_slot)); }
     prof_end(e, s, 0, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -287,7 +297,7 @@ extern "C" int azg_backup(azg_engine *e, void *stream, const float *policy, cons
     View v = e->v;
     if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
-    GAME_SWITCH(e, hipLaunchKernelGGL((k_backup<G>), dim3(e->v.B), dim3(64), 0, s, v, policy, value, row_of_slot));
+    GAME_SWITCH(e, AZG_LAUNCH((k_backup<G>), dim3(e->v.B), dim3(64), 0, s, v, policy, value, row_of_slot));
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -302,9 +312,9 @@ extern "C" int azg_backup_select(azg_engine *e, void *stream, const float *polic
     if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
     const int A = e->gi.action_size;
-    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, float, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (float *)obs, row_of_slot, 1)); }
-    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
-    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, true, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
+    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, float, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (float *)obs, row_of_slot, 1)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
+    else { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, true, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -321,9 +331,9 @@ extern "C" int azg_backup_select_logits(azg_engine *e, void *stream, const float
     if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
     const float *nov = nullptr;
-    if (obs_dtype == 0) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, float, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (float *)obs, row_of_slot, do_select)); }
-    else if (obs_dtype == 1) { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
-    else { GAME_SWITCH(e, hipLaunchKernelGGL((k_backup_select2<G, _Float16, true, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
+    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, float, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (float *)obs, row_of_slot, do_select)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
+    else { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, true, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -577,7 +587,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
         static unsigned long long *dbg = nullptr; static int calls = 0;
         if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 8) * 8)); }
         TowerParams Q = P; Q.dbg = dbg;
-        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev], sa);
+        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev], sa);
         if (++calls == 8) {
             unsigned long long h[64 * 4 * 5];
             HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
@@ -594,7 +604,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
                                                    w[b * 8 + 4] - w[b * 8], w[b * 8 + 5] - w[b * 8 + 4], w[b * 8 + 6] - w[b * 8 + 5], w[b * 8 + 7] - w[b * 8 + 6], w[b * 8 + 1] - w[b * 8 + 7]);
         }
 #else
-        hipLaunchKernelGGL((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev], sa);
+        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev], sa);
 #endif
     }
     HIPCHK(hipGetLastError());
@@ -613,12 +623,12 @@ static bool netprof_begin(hipStream_t s, EvPair &p) {
     if (!g_netprof.on) return false;
     if (!g_netprof.pool.empty()) { p = g_netprof.pool.back(); g_netprof.pool.pop_back(); }
     else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
-    (void)hipEventRecord(p.a, s);
+    p.ext = true; g_kev = &p; (void)s;
     return true;
 }
 static void netprof_end(hipStream_t s, int fam, bool on, EvPair &p) {
     if (!on) return;
-    (void)hipEventRecord(p.b, s);
+    g_kev = nullptr; (void)s;
     std::lock_guard<std::mutex> lk(g_netprof.mu);
     g_netprof.ev[fam].push_back(p); g_netprof.n[fam]++;
 }
@@ -770,11 +780,11 @@ extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const voi
     const int osub = (A + NV + 15) / 16, nchunks = (osub + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     EvPair ep; const bool prof = netprof_begin(s, ep);
-    hipLaunchKernelGGL(k_heads, dim3(groups * nchunks), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)y, (const half8 *)head_w_packed, head_b, logits_ws,
+    AZG_LAUNCH(k_heads, dim3(groups * nchunks), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)y, (const half8 *)head_w_packed, head_b, logits_ws,
                        boards, k / 32, osub);
     netprof_end(s, 1, prof, ep);
     if (policy)                                              // (NULL: leave the logits for azg_backup_select_logits)
-        hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
+        AZG_LAUNCH(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }
@@ -786,11 +796,11 @@ extern "C" int azg_policy_value_heads_fact_f16(void *stream, const void *feat, c
     const int osp = (A + 15) / 16, osub = (A + NV + 15) / 16, ncp = (osp + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     EvPair ep; const bool prof = netprof_begin(s, ep);
-    hipLaunchKernelGGL(k_heads_fact, dim3(groups * (ncp + 1)), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)feat, (const half8 *)wp_packed, (const half8 *)wv_packed,
+    AZG_LAUNCH(k_heads_fact, dim3(groups * (ncp + 1)), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)feat, (const half8 *)wp_packed, (const half8 *)wv_packed,
                        head_b, logits_ws, boards, feat_k, osp, A, NV, osub * 16);
     netprof_end(s, 1, prof, ep);
     if (policy)
-        hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
+        AZG_LAUNCH(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }

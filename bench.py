@@ -215,6 +215,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--pipelines', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-library-gemm', action='store_true', help='skip the hipBLASLt context GEMM (keeps profiler traces to our own kernels)')
     ap.add_argument('--no-fused-search', action='store_true',
                     help='2 launches per simulation (tower, backup+select) instead of one persistent launch per move (azg_search_f16)')
     a = ap.parse_args()
@@ -362,7 +363,7 @@ def main():
     }
     if roof_net is not None and roofline is not roof_net:
         out['net_roofline'] = roof_net
-    if world == 1 and roofline is not None and roofline['bound'] == 'mfma':
+    if world == 1 and roofline is not None and roofline['bound'] == 'mfma' and not a.no_library_gemm:
         lib_tf = library_gemm_tflops(dev)                            # outside the timed region
         roofline['library_gemm_tflops'] = round(lib_tf, 1)
         roofline['vs_library_gemm'] = round(roofline['achieved'] / lib_tf, 3)

@@ -71,7 +71,7 @@ def main():
     os.makedirs(PROF, exist_ok=True); os.makedirs(SCRATCH, exist_ok=True)
     summary_rows, pmc = [], {'git': a.git, 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
     for w in a.workloads:
-        base = ['--workload', w, '--no-cpu-baseline']
+        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm']
         out, line, rc = rocprof('kt_' + w, ['--kernel-trace', '--stats'], base + ['--steps', '12', '--warmup', '2'])
         stats = glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True)
         if stats:
