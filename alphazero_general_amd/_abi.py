@@ -38,7 +38,7 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [('sims', C.c_int64), ('expansions', C.c_int64), ('games_played', C.c_int32), ('num_results', C.c_int32),
-                ('num_examples', C.c_int32), ('error', C.c_int32), ('max_nodes_used', C.c_int32), ('reserved', C.c_int32)]
+                ('num_examples', C.c_int32), ('error', C.c_int32), ('max_nodes_used', C.c_int32), ('max_nodes_kept', C.c_int32)]
 
 
 # every symbol include/azg.h declares: name -> (restype, argtypes)

@@ -79,7 +79,7 @@ struct View {
     int32_t  *fin_counted; // [B]
     int32_t  *fin_soff;    // [B] sample offset
     int64_t  *slot_sims, *slot_exp;   // [B]
-    int32_t  *gcount;      // [8]: 0 games_played, 1 num_results, 2 num_examples, 3 error, 4 max_nodes
+    int32_t  *gcount;      // [8]: 0 games_played, 1 num_results, 2 num_examples, 3 error, 4 max_nodes, 5 max nodes kept by a compaction
     float    *ex_obs, *ex_pi, *ex_z;  // examples
     uint8_t  *res_ws; int32_t *res_turns, *res_slot;
     const float *temp_table; const SumPlan *plan;
@@ -98,7 +98,7 @@ struct View {
 #define AZG_TSTAMP(ev, slot, lane, i) do { } while (0)
 #endif
 
-enum { GC_GAMES = 0, GC_RESULTS = 1, GC_EXAMPLES = 2, GC_ERROR = 3, GC_MAXNODES = 4 };
+enum { GC_GAMES = 0, GC_RESULTS = 1, GC_EXAMPLES = 2, GC_ERROR = 3, GC_MAXNODES = 4, GC_MAXLIVE = 5 };
 
 // ------------------------------------------------------------------------------------------------ random tape
 // Definition in DESIGN.md "Random tape"; independent re-implementation of the spec (the oracle has its own).

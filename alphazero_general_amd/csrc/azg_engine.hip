@@ -506,7 +506,7 @@ extern "C" int azg_read_counters(azg_engine *e, void *stream, azg_counters *out)
     memset(out, 0, sizeof(*out));
     for (int i = 0; i < e->v.B; i++) { out->sims += sims[i]; out->expansions += exps[i]; }
     out->games_played = gc[GC_GAMES]; out->num_results = gc[GC_RESULTS]; out->num_examples = gc[GC_EXAMPLES];
-    out->error = gc[GC_ERROR]; out->max_nodes_used = gc[GC_MAXNODES];
+    out->error = gc[GC_ERROR]; out->max_nodes_used = gc[GC_MAXNODES]; out->max_nodes_kept = gc[GC_MAXLIVE];
     return AZG_OK;
 }
 

@@ -655,6 +655,7 @@ __global__ __launch_bounds__(64) void k_compact(View ev, int force) {
     if (lane == 0) {
         if (hr.root.fc >= 0 && hr.root.nchild > 0) h->root.first_child = 0;
         h->base = nbase; h->alloc = nalloc;
+        atomicMax(&ev.gcount[GC_MAXLIVE], nalloc);                           // (rare: a few trees per move; how full the kept subtrees get)
         h->leaf = LEAF_IS_ROOT; h->leaf_fc = -1; h->depth = 0;               // the last find_leaf's indices are void now
     }
 }

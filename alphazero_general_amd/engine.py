@@ -250,7 +250,7 @@ class DeviceEngine:
         if c.error:
             raise _abi.AzgError(c.error, 'raised on device (tree arena or example buffer overflow / invalid action)')
         return dict(sims=c.sims, expansions=c.expansions, games_played=c.games_played, num_results=c.num_results,
-                    num_examples=c.num_examples, max_nodes_used=c.max_nodes_used)
+                    num_examples=c.num_examples, max_nodes_used=c.max_nodes_used, max_nodes_kept=c.max_nodes_kept)
 
     def examples(self, first=0, count=None):
         """(obs [n,C,H,W], pi [n,A], z [n,P+1]) float32 device tensors, reference output_queue order."""

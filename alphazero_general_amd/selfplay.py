@@ -209,6 +209,7 @@ class SelfPlayRunner:
                 for k in ('sims', 'expansions', 'games_played', 'num_results', 'num_examples'):
                     tot[k] += c[k]
                 tot['max_nodes_used'] = max(tot['max_nodes_used'], c['max_nodes_used'])
+                tot['max_nodes_kept'] = max(tot['max_nodes_kept'], c['max_nodes_kept'])
         return tot
 
     def run(self, games=None, max_rounds=None, poll_every=1):

@@ -100,8 +100,8 @@ typedef struct azg_counters {
     int32_t  num_results;       /* result_queue length (every finished game)           */
     int32_t  num_examples;      /* output_queue length                                             */
     int32_t  error;             /* sticky azg_status raised on device (tree/example overflow ...)  */
-    int32_t  max_nodes_used;    /* high-water mark of any tree arena                               */
-    int32_t  reserved;
+    int32_t  max_nodes_used;    /* high-water mark of any tree's live node space (garbage included)  */
+    int32_t  max_nodes_kept;    /* largest subtree a compaction has kept: + one move must fit nodes_per_tree */
 } azg_counters;
 
 /* ---- library ------------------------------------------------------------------------------------------- */
