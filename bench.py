@@ -130,9 +130,16 @@ def cpu_baseline(W, nets, arena=False, budget_s=24.0):
       end to end: every simulation step the agents' leaves form ONE batch evaluated by the same GPU network through host
                   buffers (the reference's arrangement, Coach.py:337-342), so only where the tree lives differs;
       tree only : the warm-up evaluator's uniform policy / value (SelfPlayAgent.pyx:48-52), agents free-running.
-    Thread counts from all host cores downwards are sampled for ~2 s each and the best is reported (`cores` = threads used)."""
+    Thread counts from all logical host CPUs down to half the container's CPU quota (cgroup cpu.max; the GPU boxes give this container
+    16 CPUs' worth of time on a 256-CPU host) are sampled for ~2 s each and the best is reported (`cores` = threads used)."""
     import oracle_lib as ol
     ncpu = os.cpu_count() or 1
+    quota = None                                                     # the container's CPU-time quota (cgroup v2 cpu.max), in CPUs
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        quota = None if q == 'max' else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
     G, games, sims = W['oracle_game'], W['B'], W['sims']
     kw = dict(sims=sims, games_per_iteration=1 << 30, seed=1, cpuct=W['cpuct'], fpu_reduction=W['fpu'], add_root_noise=not arena,
               add_root_temp=not arena, is_arena=arena)
@@ -151,7 +158,8 @@ def cpu_baseline(W, nets, arena=False, budget_s=24.0):
                 p[idx], v[idx] = pm.cpu().numpy(), vm.cpu().numpy()
         return p, v
 
-    counts = sorted({max(1, min(n, games)) for n in (ncpu, ncpu // 2, ncpu // 4, 32, 8)}, reverse=True)
+    qn = int(quota) if quota else 16
+    counts = sorted({max(1, min(n, games)) for n in (ncpu, 4 * qn, 2 * qn, qn, max(qn // 2, 1))}, reverse=True)
     per = max(1.5, budget_s / (2 * len(counts) + 1))
     best_e2e, best_tree, tried = None, None, []
     for n in counts:
@@ -181,7 +189,7 @@ def cpu_baseline(W, nets, arena=False, budget_s=24.0):
     one = ol.OPool(G, 1, min(games, 256), **kw)
     dt1 = one.run_tree_only(per)
     tree1 = one.expansions / dt1
-    out = {'value': round(best_e2e[0], 1), 'unit': 'expansions/s', 'cores': best_e2e[1], 'kind': 'port', 'host_cpus': ncpu,
+    out = {'value': round(best_e2e[0], 1), 'unit': 'expansions/s', 'cores': best_e2e[1], 'kind': 'port', 'host_cpus': ncpu, 'cgroup_cpu_quota': quota,
            'sample': '%s%s: %d oracle agents x %d games x %d sims/move on %d host threads for %.1f s, leaves of all agents evaluated as one '
                      'batch by the same GPU net(s) through host buffers' % (W['game'], ' arena' if arena else '', best_e2e[1], best_e2e[2], sims, best_e2e[1], best_e2e[3]),
            'tree_only': {'value': round(best_tree[0], 1), 'cores': best_tree[1], 'per_core_1_thread': round(tree1, 1),
