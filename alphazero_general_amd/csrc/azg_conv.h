@@ -599,22 +599,68 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, co
 }
 
 // Second stage of the factorised heads (NNetArchitecture.py:90-93,99-102, the Linear chains collapsed: they have no activation):
-// policy logits from the 16 policy channels of every pixel, value logits from the 16 value channels, out of the feature rows
-// feat[board][2][fk] the tower launch wrote.  Chunks 0 .. nchunks_p - 1 of a board group are policy output subtiles
-// (k-steps over the first feature half, weights wp [fk/32][osp][64]), the last chunk is the value subtile (second half,
-// weights wv [fk/32][1][64]).  A quarter of the weight traffic of the fully collapsed [H*W*C, A + NV] matrix at 64 channels.
-__global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads_fact(const _Float16 *feat, const half8 *wp, const half8 *wv, const float *bias, float *logits,
-                                                               int boards, int fk, int osp, int A, int NV, int opad) {
-    __shared__ float red[HEAD_WAVES][HEAD_NS * 256];
-    const int lane = threadIdx.x & 63, g = lane >> 4, i16 = lane & 15;
-    const int ncp = (osp + HEAD_NS - 1) / HEAD_NS, nchunks = ncp + 1, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
-    const int b0 = grp * 16, ksteps = fk / 32;
-    const half8 *frow = reinterpret_cast<const half8 *>(feat) + (size_t)min(b0 + i16, boards - 1) * ((size_t)fk / 4) + g;    // 2 * fk halves per board
-    if (chunk < ncp) {
-        const int s0 = chunk * HEAD_NS;
-        heads_chunk(red, frow, wp + (size_t)s0 * 64 + lane, (size_t)osp * 64, ksteps, min(HEAD_NS, osp - s0), bias, logits, opad, b0, boards, s0 * 16, A);
-    } else {
-        heads_chunk(red, frow + fk / 8, wv + lane, (size_t)64, ksteps, 1, bias, logits, opad, b0, boards, A, A + NV);
+// policy logits from the 16 policy channels of every pixel, value logits from the 16 value channels.  One output subtile (16
+// outputs) of 16 boards = FOUR MFMA accumulation chains, one per contiguous quarter of the k-steps, summed as
+// (q0 + q1) + (q2 + q3): a fixed association that the persistent search kernel reproduces (four accumulators per subtile), so
+// both paths give bit-identical logits.  `afrag(ks)` delivers the A operand (16 boards x 32 features: global feature rows here,
+// LDS there), wl this lane's weight fragments (`wstride` half8 from one k-step to the next).  The loads of a chain are issued in
+// batches of HEADF_U k-steps, branch-free (k-steps past the end re-read the last one with the A fragment zeroed).
+constexpr int HEADF_U = 7, HEADF_Q = 4, HEADF_NS = 5;            // k-steps per load batch, K quarters, subtiles per wavefront
+// NS chains at once (they share the A fragments): acc[s] += sum over k-steps [k_begin, k_end) of afrag(ks) x wl[ks * wstride + soff[s]]
+template <int NS, class AF>
+__device__ __forceinline__ void heads_fact_chains(AF &&afrag, const half8 *wl, size_t wstride, const size_t (&soff)[NS], int k_begin, int k_end,
+                                                  floatx4 (&acc)[NS]) {
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = k_begin; k0 < k_end; k0 += HEADF_U) {
+        half8 a[HEADF_U], b[HEADF_U][NS];
+#pragma unroll
+        for (int u = 0; u < HEADF_U; u++) {
+            const int ks = k0 + u, kc = min(ks, k_end - 1);
+            a[u] = afrag(kc);
+            if (ks >= k_end) a[u] = zero8;
+#pragma unroll
+            for (int s = 0; s < NS; s++) b[u][s] = wl[(size_t)kc * wstride + soff[s]];
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // (left alone hipcc sinks every load next to its MFMA and waits)
+#pragma unroll
+        for (int u = 0; u < HEADF_U; u++)
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][s], acc[s], 0, 0, 0);
+    }
+}
+// the factorised heads' parameters: subtile s < osp = policy outputs s*16.. from the policy half of the features (weights wp
+// [fk/32][osp][64]), subtile osp = the value outputs from the value half (weights wv [fk/32][64])
+struct HeadsFact { const half8 *wp, *wv; const float *bias; int fk, osp, A, NV; };
+__device__ __forceinline__ int heads_fact_kq(int ksteps) { return (ksteps + HEADF_Q - 1) / HEADF_Q; }      // k-steps per quarter
+
+// workgroup = 16 boards x one chunk of HEADF_NS policy subtiles (or the value subtile), wave = K quarter
+__global__ __launch_bounds__(HEADF_Q * 64) void k_heads_fact(const _Float16 *feat, HeadsFact hf, float *logits, int boards, int opad) {
+    __shared__ floatx4 red[HEADF_Q][HEADF_NS][64];
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, g = lane >> 4, i16 = lane & 15;
+    const int ncp = (hf.osp + HEADF_NS - 1) / HEADF_NS, nchunks = ncp + 1, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
+    const int b0 = grp * 16, ksteps = hf.fk / 32, KQ = heads_fact_kq(ksteps);
+    const bool is_v = chunk == ncp;
+    const int s0 = is_v ? hf.osp : chunk * HEADF_NS, nsub = is_v ? 1 : min(HEADF_NS, hf.osp - s0);
+    const half8 *frow = reinterpret_cast<const half8 *>(feat) + (size_t)min(b0 + i16, boards - 1) * ((size_t)hf.fk / 4) + g + (is_v ? hf.fk / 8 : 0);
+    size_t soff[HEADF_NS];
+#pragma unroll
+    for (int s = 0; s < HEADF_NS; s++) soff[s] = (size_t)min(s, nsub - 1) * 64;     // (subtiles past the end re-read the last real one)
+    floatx4 acc[HEADF_NS];
+#pragma unroll
+    for (int s = 0; s < HEADF_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    heads_fact_chains<HEADF_NS>([&](int ks) { return frow[(size_t)ks * 4]; }, is_v ? hf.wv + lane : hf.wp + (size_t)s0 * 64 + lane,
+                                is_v ? (size_t)64 : (size_t)hf.osp * 64, soff, min(kq * KQ, ksteps), min((kq + 1) * KQ, ksteps), acc);
+#pragma unroll
+    for (int s = 0; s < HEADF_NS; s++) red[kq][s][lane] = acc[s];
+    __syncthreads();
+    for (int s = kq; s < nsub; s += HEADF_Q) {                              // D[m = board g*4 + r][n = output i16]
+        const floatx4 sum = (red[0][s][lane] + red[1][s][lane]) + (red[2][s][lane] + red[3][s][lane]);
+        const int out = is_v ? hf.A + i16 : (s0 + s) * 16 + i16, lim = is_v ? hf.A + hf.NV : hf.A;
+        if (out < lim) {
+            const float bo = hf.bias[out];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int board = b0 + g * 4 + r; if (board < boards) logits[(size_t)board * opad + out] = sum[r] + bo; }
+        }
     }
 }
 

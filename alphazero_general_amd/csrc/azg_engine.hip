@@ -793,11 +793,11 @@ extern "C" int azg_policy_value_heads_fact_f16(void *stream, const void *feat, c
                                                int feat_k, int A, int NV, float *logits_ws, float *policy, float *value) {
     if (!feat || !wp_packed || !wv_packed || !head_b || !logits_ws || (!policy != !value)) return fail(AZG_E_INVALID_ARG, "null argument");
     if (boards <= 0 || feat_k <= 0 || (feat_k & 31) || A <= 0 || A > 1024 || NV <= 0 || NV > 16) return fail(AZG_E_INVALID_ARG, "boards > 0, feat_k a multiple of 32, 0 < A <= 1024, 0 < NV <= 16");
-    const int osp = (A + 15) / 16, osub = (A + NV + 15) / 16, ncp = (osp + HEAD_NS - 1) / HEAD_NS, groups = (boards + 15) / 16;
+    const int osp = (A + 15) / 16, osub = (A + NV + 15) / 16, nchunks = (osp + HEADF_NS - 1) / HEADF_NS + 1, groups = (boards + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     EvPair ep; const bool prof = netprof_begin(s, ep);
-    AZG_LAUNCH(k_heads_fact, dim3(groups * (ncp + 1)), dim3(HEAD_WAVES * 64), 0, s, (const _Float16 *)feat, (const half8 *)wp_packed, (const half8 *)wv_packed,
-                       head_b, logits_ws, boards, feat_k, osp, A, NV, osub * 16);
+    const HeadsFact hf{(const half8 *)wp_packed, (const half8 *)wv_packed, head_b, feat_k, osp, A, NV};
+    AZG_LAUNCH(k_heads_fact, dim3(groups * nchunks), dim3(HEADF_Q * 64), 0, s, (const _Float16 *)feat, hf, logits_ws, boards, osub * 16);
     netprof_end(s, 1, prof, ep);
     if (policy)
         AZG_LAUNCH(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
