@@ -104,6 +104,147 @@ static void tower_pixmap(int16_t *map /*[NSUB*16]*/) {
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
+// ---- collapsed heads for large action spaces (brandubh: A + NV = 591) ------------------------------------------------------
+// logits[b, o] = sum_k y[b, k] * Wh[k, o] + bias[o] over the tower's final stream y [boards, K = H*W*C] (fp16 rows), then the
+// two softmaxes of NNetArchitecture.py:112-118.  Too wide to fuse behind the tower (every tile would stream the whole 3.7 MB
+// matrix), so it is its own launch: workgroup = (16 boards) x (HEAD_NS output subtiles of 16); its eight waves split K, each
+// streaming activation fragments (A operand: 16 boards x 32 k) and pre-packed weight fragments (B operand: 32 k x 16 outputs,
+// [k-step][subtile][64 lanes][8 halves]) straight from L2 -- no reuse inside a workgroup, so no LDS staging.  With
+// blockIdx = group * nchunks + chunk and 8 chunks, the workgroups sharing a weight chunk sit on one XCD (blockIdx mod 8).
+// The job is L2->CU bandwidth bound: (HEAD_NS*16 + 16) * K * 2 bytes per workgroup.
+constexpr int HEAD_NS = 5, HEAD_WAVES = 8, HEAD_U = 4;   // (batches of 2-4 k-steps measured best; 7 is 2-6 % slower)
+
+// One workgroup of the heads GEMM: 16 boards x nsub <= HEAD_NS output subtiles over `ksteps` k-steps of 32.  yrow: this lane's A
+// operand stream (board i16, k offset g * 8); wl: this lane's B fragments of subtile 0 of the chunk, `wstride` fragments (64 lanes
+// each) from one k-step to the next.  The eight waves split K and work in batches of HEAD_U k-steps: all the fragment loads of a
+// batch are issued back to back (the job is L2 latency and bandwidth, not MFMA), branch-free: subtiles past the end re-read the
+// last real one (their accumulators are never stored), k-steps past the end re-read the last one with the A fragment zeroed.
+// logits[board][out0 + s * 16 + i] for s < nsub, columns below out_lim only.
+__device__ __forceinline__ void heads_chunk(float (*red)[HEAD_NS * 256], const half8 *yrow, const half8 *wl, size_t wstride, int ksteps, int nsub,
+                                            const float *bias, float *logits, int opad, int b0, int boards, int out0, int out_lim) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    floatx4 acc[HEAD_NS];
+#pragma unroll
+    for (int s = 0; s < HEAD_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    size_t soff[HEAD_NS];
+#pragma unroll
+    for (int s = 0; s < HEAD_NS; s++) soff[s] = (size_t)min(s, nsub - 1) * 64;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = wave; k0 < ksteps; k0 += HEAD_WAVES * HEAD_U) {
+        half8 a[HEAD_U], b[HEAD_U][HEAD_NS];
+#pragma unroll
+        for (int u = 0; u < HEAD_U; u++) {
+            const int ks = k0 + u * HEAD_WAVES, kc = min(ks, ksteps - 1);
+            a[u] = yrow[(size_t)kc * 4];
+            if (ks >= ksteps) a[u] = zero8;
+#pragma unroll
+            for (int s = 0; s < HEAD_NS; s++) b[u][s] = wl[(size_t)kc * wstride + soff[s]];
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // (left alone hipcc sinks every load next to its MFMA and waits)
+#pragma unroll
+        for (int u = 0; u < HEAD_U; u++)
+#pragma unroll
+            for (int s = 0; s < HEAD_NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][s], acc[s], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < HEAD_NS; s++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][(s * 4 + r) * 64 + lane] = acc[s][r];
+    __syncthreads();
+    for (int e = tid; e < HEAD_NS * 256; e += HEAD_WAVES * 64) {              // D[m = board g*4 + r][n = output i16]
+        const int s = e >> 8, r = (e >> 6) & 3, ln = e & 63, board = b0 + (ln >> 4) * 4 + r, out = out0 + s * 16 + (ln & 15);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < HEAD_WAVES; w++) sum += red[w][e];
+        if (board < boards && s < nsub && out < out_lim) logits[(size_t)board * opad + out] = sum + bias[out];
+    }
+}
+
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
+                                                          int ksteps, int osub) {
+    __shared__ float red[HEAD_WAVES][HEAD_NS * 256];
+    const int lane = threadIdx.x & 63, g = lane >> 4, i16 = lane & 15;
+    const int nchunks = (osub + HEAD_NS - 1) / HEAD_NS, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
+    const int b0 = grp * 16, s0 = chunk * HEAD_NS;
+    const half8 *yrow = reinterpret_cast<const half8 *>(y) + (size_t)min(b0 + i16, boards - 1) * ((size_t)ksteps * 4) + g;
+    heads_chunk(red, yrow, wp + (size_t)s0 * 64 + lane, (size_t)osub * 64, ksteps, min(HEAD_NS, osub - s0), bias, logits, osub * 16, b0, boards,
+                s0 * 16, osub * 16);
+}
+
+// Second stage of the factorised heads (NNetArchitecture.py:90-93,99-102, the Linear chains collapsed: they have no activation):
+// policy logits from the 16 policy channels of every pixel, value logits from the 16 value channels.  One output subtile (16
+// outputs) of 16 boards = FOUR MFMA accumulation chains, one per contiguous quarter of the k-steps, summed as
+// (q0 + q1) + (q2 + q3): a fixed association that the persistent search kernel reproduces (four accumulators per subtile), so
+// both paths give bit-identical logits.  `afrag(ks)` delivers the A operand (16 boards x 32 features: global feature rows here,
+// LDS there), wl this lane's weight fragments (`wstride` half8 from one k-step to the next).  The loads of a chain are issued in
+// batches of HEADF_U k-steps, branch-free (k-steps past the end re-read the last one with the A fragment zeroed).
+constexpr int HEADF_U = 7, HEADF_Q = 4, HEADF_NS = 5;            // k-steps per load batch, K quarters, subtiles per wavefront
+// NS chains at once (they share the A fragments): acc[s] += sum over k-steps [k_begin, k_end) of afrag(ks) x wl[ks * wstride + soff[s]]
+template <int NS, class AF>
+__device__ __forceinline__ void heads_fact_chains(AF &&afrag, const half8 *wl, size_t wstride, const size_t (&soff)[NS], int k_begin, int k_end,
+                                                  floatx4 (&acc)[NS]) {
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = k_begin; k0 < k_end; k0 += HEADF_U) {
+        half8 a[HEADF_U], b[HEADF_U][NS];
+#pragma unroll
+        for (int u = 0; u < HEADF_U; u++) {
+            const int ks = k0 + u, kc = min(ks, k_end - 1);
+            a[u] = afrag(kc);
+            if (ks >= k_end) a[u] = zero8;
+#pragma unroll
+            for (int s = 0; s < NS; s++) b[u][s] = wl[(size_t)kc * wstride + soff[s]];
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // (left alone hipcc sinks every load next to its MFMA and waits)
+#pragma unroll
+        for (int u = 0; u < HEADF_U; u++)
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][s], acc[s], 0, 0, 0);
+    }
+}
+// the factorised heads' parameters: subtile s < osp = policy outputs s*16.. from the policy half of the features (weights wp
+// [fk/32][osp][64]), subtile osp = the value outputs from the value half (weights wv [fk/32][64])
+struct HeadsFact { const half8 *wp, *wv; const float *bias; int fk, osp, A, NV; };
+__device__ __forceinline__ int heads_fact_kq(int ksteps) { return (ksteps + HEADF_Q - 1) / HEADF_Q; }      // k-steps per quarter
+
+// workgroup = 16 boards x one chunk of HEADF_NS policy subtiles (or the value subtile), wave = K quarter
+__global__ __launch_bounds__(HEADF_Q * 64) void k_heads_fact(const _Float16 *feat, HeadsFact hf, float *logits, int boards, int opad) {
+    __shared__ floatx4 red[HEADF_Q][HEADF_NS][64];
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, g = lane >> 4, i16 = lane & 15;
+    const int ncp = (hf.osp + HEADF_NS - 1) / HEADF_NS, nchunks = ncp + 1, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
+    const int b0 = grp * 16, ksteps = hf.fk / 32, KQ = heads_fact_kq(ksteps);
+    const bool is_v = chunk == ncp;
+    const int s0 = is_v ? hf.osp : chunk * HEADF_NS, nsub = is_v ? 1 : min(HEADF_NS, hf.osp - s0);
+    const half8 *frow = reinterpret_cast<const half8 *>(feat) + (size_t)min(b0 + i16, boards - 1) * ((size_t)hf.fk / 4) + g + (is_v ? hf.fk / 8 : 0);
+    size_t soff[HEADF_NS];
+#pragma unroll
+    for (int s = 0; s < HEADF_NS; s++) soff[s] = (size_t)min(s, nsub - 1) * 64;     // (subtiles past the end re-read the last real one)
+    floatx4 acc[HEADF_NS];
+#pragma unroll
+    for (int s = 0; s < HEADF_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    heads_fact_chains<HEADF_NS>([&](int ks) { return frow[(size_t)ks * 4]; }, is_v ? hf.wv + lane : hf.wp + (size_t)s0 * 64 + lane,
+                                is_v ? (size_t)64 : (size_t)hf.osp * 64, soff, min(kq * KQ, ksteps), min((kq + 1) * KQ, ksteps), acc);
+#pragma unroll
+    for (int s = 0; s < HEADF_NS; s++) red[kq][s][lane] = acc[s];
+    __syncthreads();
+    for (int s = kq; s < nsub; s += HEADF_Q) {                              // D[m = board g*4 + r][n = output i16]
+        const floatx4 sum = (red[0][s][lane] + red[1][s][lane]) + (red[2][s][lane] + red[3][s][lane]);
+        const int out = is_v ? hf.A + i16 : (s0 + s) * 16 + i16, lim = is_v ? hf.A + hf.NV : hf.A;
+        if (out < lim) {
+            const float bo = hf.bias[out];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int board = b0 + g * 4 + r; if (board < boards) logits[(size_t)board * opad + out] = sum[r] + bo; }
+        }
+    }
+}
+
+// one wave per board: softmax over the A policy logits (held in registers: up to 16 per lane, A <= 1024) and the NV value logits
+__global__ __launch_bounds__(256) void k_heads_softmax(const float *logits, float *policy, float *value, int boards, int opad, int A, int NV) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= boards) return;
+    heads_softmax_row(logits + (size_t)b * opad, lane, A, NV, policy + (size_t)b * A, value + (size_t)b * NV);
+}
+
+
 // ------------------------------------------------------------------------------------------------ k_tower2
 // Two workgroups per CU.  With the residual stream in registers only ONE LDS image is needed (t / u / final s take
 // turns in it), 81 KB per workgroup, so two workgroups (two tiles) are resident per CU and one runs its epilogue /
@@ -167,13 +308,37 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
 // times.  Workgroups never synchronise with each other.  (Measured: the same throughput as three launches per simulation --
 // the tower is bound by LDS-read issue and power, not by launch gaps; staggering the two workgroups of a CU changed nothing.)
 struct NoSearch {};
-template <class G> struct SearchArgs { View ev; int sims; using Game = G; };
+template <class G> struct SearchArgs { View ev; int sims; using Game = G; static constexpr bool WIDE = false; };
+// The same for networks with factorised heads (wide action spaces, any tower width): BOARDS games per workgroup, wave b walks game
+// b, wave BOARDS + b prepares its priors and shuffle (the two-wave scheme of k_backup_select2), the head convolutions leave their
+// features in LDS and the workgroup's waves -- one K quarter each, exactly k_heads_fact's chains -- turn them into logits in LDS.
+template <class G> struct SearchWide { View ev; int sims; HeadsFact hf; using Game = G; static constexpr bool WIDE = true; };
+
+// per-game LDS scratch of the wide search mode (behind the image)
+template <class G, int HW> struct WideScratch {
+    static constexpr int A = G::A, NV = G::P + 1, OPAD = (A + NV + 15) / 16 * 16, FK = (HW * 16 + 31) / 32 * 32;
+    static constexpr int LG = 0, PI = LG + OPAD * 4, M = PI + A * 4, SCR = M + (A < 8 ? 8 : A) * 4, ACT = SCR + 256,
+                         LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + 512, FEAT = FLAGS + 16, BYTES = (FEAT + 2 * FK * 2 + 15) / 16 * 16;
+};
+// all of the wide search mode's LDS behind the image: the per-game scratch, an error word, the heads' partial sums
+template <class G, int HW, int BOARDS> struct WideLds {
+    static constexpr int NSUBTOT = (G::A + 15) / 16 + 1;
+    static constexpr int BYTES = (BOARDS * WideScratch<G, HW>::BYTES + 16 + 4 * NSUBTOT * BOARDS * 16 * 4 + 15) / 16 * 16;
+};
+AZG_DEV void flag_set_gen(int *f, int gen, int lane) { if (lane == 0) __hip_atomic_store(f, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AZG_DEV void flag_wait_gen(int *f, int gen) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) __builtin_amdgcn_s_sleep(1); }
+
+// (the wide search mode keeps one workgroup per CU busy for a whole move and mixes three phases with different register needs:
+//  one wave per SIMD, the whole register file)
+template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else return SEARCH::WIDE ? 1 : 2; }
 
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
-__global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
+__global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
-    static_assert(!IS_SEARCH || (PSPLIT == 1 && C == 128 && BOARDS == C / 32), "search mode: one wave per game, fused heads");
+    constexpr bool IS_WIDE = []() { if constexpr (IS_SEARCH) return SEARCH::WIDE; else return false; }();
+    static_assert(!IS_SEARCH || IS_WIDE || (PSPLIT == 1 && C == 128 && BOARDS == C / 32), "search mode: one wave per game, fused heads");
+    static_assert(!IS_WIDE || (C / 32) * PSPLIT >= 2 * BOARDS, "wide search mode: a walker and a helper wavefront per game");
     TowerParams P = Pin;
     constexpr int NT = C * 2 * PSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
     constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
@@ -181,7 +346,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
     // LDS scratch in the zero rows above board 0 (restored to zero after use): [0, 4096) heads reduction, then 256 B of
     // probabilities + a flag word (search mode) -- all inside the pad line, which ends at (LEAD + PW) * RS
     constexpr int SCRATCH_PV = 4096;
-    static_assert(!IS_SEARCH || SCRATCH_PV + 1024 <= (GEO::LEAD + GEO::PW) * RS, "scratch must stay inside the pad rows");
+    static_assert(!IS_SEARCH || IS_WIDE || SCRATCH_PV + 1024 <= (GEO::LEAD + GEO::PW) * RS, "scratch must stay inside the pad rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
@@ -192,6 +357,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
         for (int m = 0; m < Pin.nmodels; m++) ntiles += (min(Pin.rows_per_model[m], Pin.boards) + BOARDS - 1) / BOARDS;
     }
     for (int c = tid; c < TILE / 16; c += NT) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
+    if constexpr (IS_WIDE) {                                     // (the feature rows' padding must read as zero)
+        constexpr int WB = WideLds<typename SEARCH::Game, HW, BOARDS>::BYTES;
+        for (int c = tid; c < WB / 16; c += NT) reinterpret_cast<uint4 *>(smem + TILE)[c] = make_uint4(0, 0, 0, 0);
+    }
     unsigned lb[NSUB];
     unsigned livemask = 0;
     const int ecol = (g & 1) ? (2 * cg + 1) * 16 + (g - 1) * 4 : (2 * cg) * 16 + g * 4;
@@ -242,9 +411,103 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
         const int row0 = tile * ROWS;
         const int rows_here = min(ROWS, P.boards * HW - row0);
         int nsims = 1;
-        if constexpr (IS_SEARCH) nsims = sa.sims;
+        if constexpr (IS_SEARCH) nsims = sa.sims + (IS_WIDE ? 1 : 0);  // (wide: the last iteration is the last backup, no tower)
         for (int sim = 0; sim < nsims; sim++) {
-        if constexpr (IS_SEARCH) {
+#ifdef AZG_TOWER_TIMING
+        unsigned long long wt_[6] = {0, 0, 0, 0, 0, 0};
+#define AZG_WPHASE(i) do { if (IS_WIDE) wt_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZG_WPHASE(i) do { } while (0)
+#endif
+        AZG_WPHASE(0);
+        if constexpr (IS_WIDE) {
+            // ---- tree phase of the wide search mode: process_results of simulation sim - 1 and find_leaf of simulation sim of the
+            // workgroup's games, two wavefronts per game exactly like k_backup_select2 (walker + helper, hand-offs through LDS
+            // generation flags); the logits of simulation sim - 1 are in LDS, the leaf planes go straight into the image
+            using G = typename SEARCH::Game;
+            using WS = WideScratch<G, HW>;
+            static_assert(G::CELLS == HW, "game / tower geometry mismatch");
+            constexpr int A = G::A, NV = G::P + 1;
+            const int bd = wave % BOARDS, role = wave / BOARDS;      // 0: walks the tree of game bd, 1: its helper, else idle
+            char *ws = smem + TILE + bd * WS::BYTES;
+            float *lg = reinterpret_cast<float *>(ws + WS::LG);
+            int *flags = reinterpret_cast<int *>(ws + WS::FLAGS);
+            int *errw = reinterpret_cast<int *>(smem + TILE + BOARDS * WS::BYTES);
+            if (sim == 0 && tid < 2 * BOARDS) reinterpret_cast<int *>(smem + TILE + (tid >> 1) * WS::BYTES + WS::FLAGS)[tid & 1] = 0;
+            if ((sim & 15) == 0) {                                   // sticky device error: stop, uniformly over the workgroup
+                if (tid == 0) *errw = sa.ev.gcount[GC_ERROR];
+                __syncthreads();
+                const int err = *errw;
+                if (err) break;
+            }
+            int slot = tile * BOARDS + bd;
+            asm volatile("" : "+v"(slot));                       // (opaque: nothing of the trees is hoisted out of the simulation loop)
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            const bool livegame = slot < sa.ev.B && role < 2;
+            int tree = 0; HdrR hr; uint64_t ctr0 = 0;
+            if (livegame) { tree = tree_of_slot(sa.ev, slot); load_hdr(sa.ev.hdr + tree, hr); ctr0 = sa.ev.tape_ctr[slot]; }
+            __syncthreads();                                     // both wavefronts of a game hold the header as the last launch / phase left it
+            const bool has_policy = livegame && sim > 0 && !hr.leaf_e && hr.leaf_fc >= 0;
+            const bool root_noise = has_policy && hr.leaf == LEAF_IS_ROOT && sa.ev.add_noise;
+            if (livegame && role == 0) {
+                typename G::S st = G::load(&sa.ev.states[slot], lane);
+                auto sink = [&](const typename G::S &ls, int ln) {   // leaf observation -> the image rows of board bd (32 stem channels)
+                    if (ln < HW) {
+                        char *row = img + GEO::qrow(bd * HW + ln) * RS;
+                        *reinterpret_cast<half8 *>(row) = G::obs8(ls, ln);
+                        const uint4 z = make_uint4(0, 0, 0, 0);
+                        *reinterpret_cast<uint4 *>(row + 16) = z; *reinterpret_cast<uint4 *>(row + 32) = z; *reinterpret_cast<uint4 *>(row + 48) = z;
+                    }
+                };
+                int *act = reinterpret_cast<int *>(ws + WS::ACT);
+                if (sim == 0) {
+                    select_tree<G>(sa.ev, slot, tree, hr, st, ctr0, lane, act, sink, NoGate{}, NoRanks{});
+                } else {
+                    Node *nodes = tree_nodes(sa.ev, tree, hr.base);
+                    float val[NV];
+                    const float pv = value_softmax(lg + A, lane, NV);
+#pragma unroll
+                    for (int j = 0; j < NV; j++) val[j] = rl(pv, j);
+                    const int prev_leaf = hr.leaf;
+                    backup_path<G>(sa.ev, slot, tree, hr, nodes, val, lane);
+                    if (sim < sa.sims) {
+                        wave_sync();
+                        bool waited = false;
+                        const unsigned long long *less = reinterpret_cast<const unsigned long long *>(ws + WS::LESS);
+                        select_tree<G>(sa.ev, slot, tree, hr, st, ctr0, lane, act, sink, [&](int node) {
+                            if (waited || node != prev_leaf) return false;
+                            flag_wait_gen(&flags[0], sim); waited = true;
+                            return root_noise;
+                        }, [&](int k, int ln, int &pos) {
+                            if (k > 64) return false;
+                            flag_wait_gen(&flags[1], sim);
+                            pos = __popcll(less[ln] & (k == 64 ? ~0ULL : ((1ULL << k) - 1ULL)));
+                            return true;
+                        });
+                    }
+                }
+            } else if (livegame && sim > 0) {                        // the helper: priors of the previous leaf, shuffle of the next expansion
+                if (has_policy) {
+                    Node *nodes = tree_nodes(sa.ev, tree, hr.base);
+                    float *pi = reinterpret_cast<float *>(ws + WS::PI);
+                    policy_softmax_row(lg, lane, A, pi);
+                    wave_sync();
+                    backup_policy<G>(sa.ev, slot, hr, nodes, pi, reinterpret_cast<float *>(ws + WS::M), reinterpret_cast<float *>(ws + WS::SCR), lane);
+                }
+                flag_set_gen(&flags[0], sim, lane);
+                if (sim < sa.sims) {
+                    reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+                    flag_set_gen(&flags[1], sim, lane);
+                }
+            } else if (role == 0 && lane < HW) {                     // no game behind this board: zero planes
+                char *row = img + GEO::qrow(bd * HW + lane) * RS;
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(row) = z; *reinterpret_cast<uint4 *>(row + 16) = z;
+                *reinterpret_cast<uint4 *>(row + 32) = z; *reinterpret_cast<uint4 *>(row + 48) = z;
+            }
+            if (sim == sa.sims) break;                           // the last backup is done: no evaluation follows
+            AZG_WPHASE(1);
+        } else if constexpr (IS_SEARCH) {
             using G = typename SEARCH::Game;
             static_assert(G::CELLS == HW && G::A < 8, "search mode needs a game whose tree functions use no LDS scratch");
             // a sticky device error (tree arena full) stops the trees; the decision must be uniform over the workgroup.  Looked at
@@ -384,9 +647,12 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
             AZG_STAMP2(4);
         }
         AZG_WGSTAMP(5);
+        AZG_WPHASE(2);
         if (P.head_w == nullptr && P.head1_w != nullptr) {
             // first stage of the factorised heads: 32 head channels per pixel, centre tap only; the waves of cout group 0
             // compute them for their own pixel subtiles straight out of the image (the final stream)
+            [[maybe_unused]] _Float16 *feat_lds = nullptr;       // wide search mode: the features stay in LDS
+            if constexpr (IS_WIDE) feat_lds = reinterpret_cast<_Float16 *>(smem + TILE + WideScratch<typename SEARCH::Game, HW>::FEAT);
             if (cg == 0) {
                 int opaque = 0;
                 asm volatile("" : "+s"(opaque));                 // (keeps these loop invariants from being hoisted across the layers)
@@ -417,6 +683,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
                     if (p >= 0 && p < rows_here) {
                         const int bd = p / HW, pos = p - bd * HW;
                         _Float16 *dst = fg + (size_t)(tile * BOARDS + bd) * 2 * P.feat_k + pos * 16 + g * 4;
+                        if constexpr (IS_WIDE)
+                            dst = reinterpret_cast<_Float16 *>(reinterpret_cast<char *>(feat_lds) + bd * WideScratch<typename SEARCH::Game, HW>::BYTES) + pos * 16 + g * 4;
 #pragma unroll
                         for (int m = 0; m < 2; m++) {
                             const half4 h = {(_Float16)hacc[m][ps][0], (_Float16)hacc[m][ps][1], (_Float16)hacc[m][ps][2], (_Float16)hacc[m][ps][3]};
@@ -424,6 +692,97 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
                         }
                     }
                 }
+            }
+            if constexpr (IS_WIDE) {
+                // second stage in-kernel: wave kq runs K quarter kq of every subtile chunk -- k_heads_fact's chains with the features
+                // read from LDS -- and the partial sums meet in LDS in the same association, (q0 + q1) + (q2 + q3) + bias
+                using G = typename SEARCH::Game;
+                using WS = WideScratch<G, HW>;
+                constexpr int A = G::A, NV = G::P + 1, OSP = (A + 15) / 16, NSUBTOT = OSP + 1;
+                static_assert((C / 32) * PSPLIT >= HEADF_Q, "one wavefront per K quarter");
+                __syncthreads();                                 // the features of every board are in LDS
+                AZG_WPHASE(3);
+                float *red = reinterpret_cast<float *>(smem + TILE + BOARDS * WS::BYTES + 16);      // [HEADF_Q][NSUBTOT][BOARDS][16]
+                const int ksteps = sa.hf.fk / 32, KQ = heads_fact_kq(ksteps);
+                if (wave < HEADF_Q) {
+                    const int kq = wave;
+                    const bool bvalid = i16 < BOARDS;
+                    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const _Float16 *fbase = reinterpret_cast<const _Float16 *>(smem + TILE + (bvalid ? i16 : 0) * WS::BYTES + WS::FEAT) + g * 8;
+                    const int kb = min(kq * KQ, ksteps), ke = min((kq + 1) * KQ, ksteps);
+                    // One load batch per chain (KQ <= HEADF_U, checked on the host).  The chunks are software-pipelined: the weight
+                    // fragments of chunk c + 1 are in flight while chunk c's MFMAs run -- a wave walks through all the chunks here,
+                    // where k_heads_fact has one workgroup per chunk, and would otherwise pay one L2 round trip per chunk
+                    // (the grouping of subtiles is free -- only a subtile's own chain order matters for the bits: groups of GN keep
+                    //  two buffers of weight fragments inside the register file)
+                    constexpr int GN = 3, NGP = (OSP + GN - 1) / GN;     // subtile groups: NGP policy groups, then the value subtile
+                    half8 wb[2][HEADF_U][GN];
+                    auto issue = [&](int grp, half8 (&b)[HEADF_U][GN]) {
+                        const bool is_v = grp == NGP;
+                        const int s0 = is_v ? OSP : grp * GN, nsub = is_v ? 1 : min(GN, OSP - s0);
+                        const half8 *wl = is_v ? sa.hf.wv + lane : sa.hf.wp + (size_t)s0 * 64 + lane;
+                        const size_t wstride = is_v ? (size_t)64 : (size_t)OSP * 64;
+#pragma unroll
+                        for (int u = 0; u < HEADF_U; u++) {
+                            const int kc = min(kb + u, ke - 1);
+#pragma unroll
+                            for (int q = 0; q < GN; q++) b[u][q] = wl[(size_t)kc * wstride + (size_t)min(q, nsub - 1) * 64];
+                        }
+                    };
+                    auto compute = [&](int grp, const half8 (&b)[HEADF_U][GN]) {
+                        const bool is_v = grp == NGP;
+                        const int s0 = is_v ? OSP : grp * GN, nsub = is_v ? 1 : min(GN, OSP - s0);
+                        const _Float16 *frow = fbase + (is_v ? sa.hf.fk : 0);
+                        floatx4 hacc2[GN];
+#pragma unroll
+                        for (int q = 0; q < GN; q++) hacc2[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int u = 0; u < HEADF_U; u++) {
+                            half8 av = *reinterpret_cast<const half8 *>(frow + min(kb + u, ke - 1) * 32);
+                            if (!bvalid || kb + u >= ke) av = zero8;
+#pragma unroll
+                            for (int q = 0; q < GN; q++) hacc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b[u][q], hacc2[q], 0, 0, 0);
+                        }
+                        if (g == 0) {                            // D[m = board g*4 + r][n = output i16]: the real boards are rows 0 .. BOARDS-1
+#pragma unroll
+                            for (int q = 0; q < GN; q++)
+                                if (q < nsub) {
+#pragma unroll
+                                    for (int r = 0; r < (BOARDS < 4 ? BOARDS : 4); r++) red[((kq * NSUBTOT + s0 + q) * BOARDS + r) * 16 + i16] = hacc2[q][r];
+                                }
+                        }
+                    };
+                    if (kb < ke) {
+                        issue(0, wb[0]);
+#pragma unroll 1
+                        for (int grp = 0; grp <= NGP; grp += 2) {
+                            if (grp + 1 <= NGP) issue(grp + 1, wb[1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            compute(grp, wb[0]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (grp + 2 <= NGP) issue(grp + 2, wb[0]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (grp + 1 <= NGP) compute(grp + 1, wb[1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else if (g == 0) {                         // (an empty quarter contributes zeros)
+                        for (int sq = 0; sq < NSUBTOT; sq++)
+                            for (int r = 0; r < (BOARDS < 4 ? BOARDS : 4); r++) red[((kq * NSUBTOT + sq) * BOARDS + r) * 16 + i16] = 0.f;
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < BOARDS * (A + NV); e += NT) {
+                    const int bdx = e / (A + NV), out = e - bdx * (A + NV);
+                    const int sq = out < A ? out / 16 : OSP, n = out < A ? out % 16 : out - A;
+                    const float r0 = red[((0 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n], r1 = red[((1 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n];
+                    const float r2 = red[((2 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n], r3 = red[((3 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n];
+                    reinterpret_cast<float *>(smem + TILE + bdx * WS::BYTES + WS::LG)[out] = ((r0 + r1) + (r2 + r3)) + sa.hf.bias[out];
+                }
+                AZG_WPHASE(4);
+#ifdef AZG_TOWER_TIMING
+                if (P.dbg && tid == 0 && blockIdx.x < 512 && sim >= 8)      // tree, tower, head conv, heads GEMM (cycles, summed over simulations)
+                    for (int i = 0; i < 4; i++) P.dbg[2048 + 4096 * 4 + (size_t)blockIdx.x * 4 + i] += wt_[i + 1] - wt_[i];
+#endif
             }
         } else if (P.head_w == nullptr) {
             uint4 *yg = reinterpret_cast<uint4 *>(P.y) + (size_t)row0 * CPR;
@@ -529,146 +888,6 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, 2) void k_tower2(TowerParams Pin, c
 #ifdef AZG_TOWER_TIMING
     if (P.dbg && tid == 0) P.dbg[2048 + (size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
 #endif
-}
-
-// ---- collapsed heads for large action spaces (brandubh: A + NV = 591) ------------------------------------------------------
-// logits[b, o] = sum_k y[b, k] * Wh[k, o] + bias[o] over the tower's final stream y [boards, K = H*W*C] (fp16 rows), then the
-// two softmaxes of NNetArchitecture.py:112-118.  Too wide to fuse behind the tower (every tile would stream the whole 3.7 MB
-// matrix), so it is its own launch: workgroup = (16 boards) x (HEAD_NS output subtiles of 16); its eight waves split K, each
-// streaming activation fragments (A operand: 16 boards x 32 k) and pre-packed weight fragments (B operand: 32 k x 16 outputs,
-// [k-step][subtile][64 lanes][8 halves]) straight from L2 -- no reuse inside a workgroup, so no LDS staging.  With
-// blockIdx = group * nchunks + chunk and 8 chunks, the workgroups sharing a weight chunk sit on one XCD (blockIdx mod 8).
-// The job is L2->CU bandwidth bound: (HEAD_NS*16 + 16) * K * 2 bytes per workgroup.
-constexpr int HEAD_NS = 5, HEAD_WAVES = 8, HEAD_U = 4;   // (batches of 2-4 k-steps measured best; 7 is 2-6 % slower)
-
-// One workgroup of the heads GEMM: 16 boards x nsub <= HEAD_NS output subtiles over `ksteps` k-steps of 32.  yrow: this lane's A
-// operand stream (board i16, k offset g * 8); wl: this lane's B fragments of subtile 0 of the chunk, `wstride` fragments (64 lanes
-// each) from one k-step to the next.  The eight waves split K and work in batches of HEAD_U k-steps: all the fragment loads of a
-// batch are issued back to back (the job is L2 latency and bandwidth, not MFMA), branch-free: subtiles past the end re-read the
-// last real one (their accumulators are never stored), k-steps past the end re-read the last one with the A fragment zeroed.
-// logits[board][out0 + s * 16 + i] for s < nsub, columns below out_lim only.
-__device__ __forceinline__ void heads_chunk(float (*red)[HEAD_NS * 256], const half8 *yrow, const half8 *wl, size_t wstride, int ksteps, int nsub,
-                                            const float *bias, float *logits, int opad, int b0, int boards, int out0, int out_lim) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    floatx4 acc[HEAD_NS];
-#pragma unroll
-    for (int s = 0; s < HEAD_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    size_t soff[HEAD_NS];
-#pragma unroll
-    for (int s = 0; s < HEAD_NS; s++) soff[s] = (size_t)min(s, nsub - 1) * 64;
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = wave; k0 < ksteps; k0 += HEAD_WAVES * HEAD_U) {
-        half8 a[HEAD_U], b[HEAD_U][HEAD_NS];
-#pragma unroll
-        for (int u = 0; u < HEAD_U; u++) {
-            const int ks = k0 + u * HEAD_WAVES, kc = min(ks, ksteps - 1);
-            a[u] = yrow[(size_t)kc * 4];
-            if (ks >= ksteps) a[u] = zero8;
-#pragma unroll
-            for (int s = 0; s < HEAD_NS; s++) b[u][s] = wl[(size_t)kc * wstride + soff[s]];
-        }
-        __builtin_amdgcn_sched_barrier(0);                      // (left alone hipcc sinks every load next to its MFMA and waits)
-#pragma unroll
-        for (int u = 0; u < HEAD_U; u++)
-#pragma unroll
-            for (int s = 0; s < HEAD_NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][s], acc[s], 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < HEAD_NS; s++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[wave][(s * 4 + r) * 64 + lane] = acc[s][r];
-    __syncthreads();
-    for (int e = tid; e < HEAD_NS * 256; e += HEAD_WAVES * 64) {              // D[m = board g*4 + r][n = output i16]
-        const int s = e >> 8, r = (e >> 6) & 3, ln = e & 63, board = b0 + (ln >> 4) * 4 + r, out = out0 + s * 16 + (ln & 15);
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < HEAD_WAVES; w++) sum += red[w][e];
-        if (board < boards && s < nsub && out < out_lim) logits[(size_t)board * opad + out] = sum + bias[out];
-    }
-}
-
-__global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, const half8 *wp, const float *bias, float *logits, int boards,
-                                                          int ksteps, int osub) {
-    __shared__ float red[HEAD_WAVES][HEAD_NS * 256];
-    const int lane = threadIdx.x & 63, g = lane >> 4, i16 = lane & 15;
-    const int nchunks = (osub + HEAD_NS - 1) / HEAD_NS, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
-    const int b0 = grp * 16, s0 = chunk * HEAD_NS;
-    const half8 *yrow = reinterpret_cast<const half8 *>(y) + (size_t)min(b0 + i16, boards - 1) * ((size_t)ksteps * 4) + g;
-    heads_chunk(red, yrow, wp + (size_t)s0 * 64 + lane, (size_t)osub * 64, ksteps, min(HEAD_NS, osub - s0), bias, logits, osub * 16, b0, boards,
-                s0 * 16, osub * 16);
-}
-
-// Second stage of the factorised heads (NNetArchitecture.py:90-93,99-102, the Linear chains collapsed: they have no activation):
-// policy logits from the 16 policy channels of every pixel, value logits from the 16 value channels.  One output subtile (16
-// outputs) of 16 boards = FOUR MFMA accumulation chains, one per contiguous quarter of the k-steps, summed as
-// (q0 + q1) + (q2 + q3): a fixed association that the persistent search kernel reproduces (four accumulators per subtile), so
-// both paths give bit-identical logits.  `afrag(ks)` delivers the A operand (16 boards x 32 features: global feature rows here,
-// LDS there), wl this lane's weight fragments (`wstride` half8 from one k-step to the next).  The loads of a chain are issued in
-// batches of HEADF_U k-steps, branch-free (k-steps past the end re-read the last one with the A fragment zeroed).
-constexpr int HEADF_U = 7, HEADF_Q = 4, HEADF_NS = 5;            // k-steps per load batch, K quarters, subtiles per wavefront
-// NS chains at once (they share the A fragments): acc[s] += sum over k-steps [k_begin, k_end) of afrag(ks) x wl[ks * wstride + soff[s]]
-template <int NS, class AF>
-__device__ __forceinline__ void heads_fact_chains(AF &&afrag, const half8 *wl, size_t wstride, const size_t (&soff)[NS], int k_begin, int k_end,
-                                                  floatx4 (&acc)[NS]) {
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = k_begin; k0 < k_end; k0 += HEADF_U) {
-        half8 a[HEADF_U], b[HEADF_U][NS];
-#pragma unroll
-        for (int u = 0; u < HEADF_U; u++) {
-            const int ks = k0 + u, kc = min(ks, k_end - 1);
-            a[u] = afrag(kc);
-            if (ks >= k_end) a[u] = zero8;
-#pragma unroll
-            for (int s = 0; s < NS; s++) b[u][s] = wl[(size_t)kc * wstride + soff[s]];
-        }
-        __builtin_amdgcn_sched_barrier(0);                      // (left alone hipcc sinks every load next to its MFMA and waits)
-#pragma unroll
-        for (int u = 0; u < HEADF_U; u++)
-#pragma unroll
-            for (int s = 0; s < NS; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][s], acc[s], 0, 0, 0);
-    }
-}
-// the factorised heads' parameters: subtile s < osp = policy outputs s*16.. from the policy half of the features (weights wp
-// [fk/32][osp][64]), subtile osp = the value outputs from the value half (weights wv [fk/32][64])
-struct HeadsFact { const half8 *wp, *wv; const float *bias; int fk, osp, A, NV; };
-__device__ __forceinline__ int heads_fact_kq(int ksteps) { return (ksteps + HEADF_Q - 1) / HEADF_Q; }      // k-steps per quarter
-
-// workgroup = 16 boards x one chunk of HEADF_NS policy subtiles (or the value subtile), wave = K quarter
-__global__ __launch_bounds__(HEADF_Q * 64) void k_heads_fact(const _Float16 *feat, HeadsFact hf, float *logits, int boards, int opad) {
-    __shared__ floatx4 red[HEADF_Q][HEADF_NS][64];
-    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, g = lane >> 4, i16 = lane & 15;
-    const int ncp = (hf.osp + HEADF_NS - 1) / HEADF_NS, nchunks = ncp + 1, grp = blockIdx.x / nchunks, chunk = blockIdx.x - grp * nchunks;
-    const int b0 = grp * 16, ksteps = hf.fk / 32, KQ = heads_fact_kq(ksteps);
-    const bool is_v = chunk == ncp;
-    const int s0 = is_v ? hf.osp : chunk * HEADF_NS, nsub = is_v ? 1 : min(HEADF_NS, hf.osp - s0);
-    const half8 *frow = reinterpret_cast<const half8 *>(feat) + (size_t)min(b0 + i16, boards - 1) * ((size_t)hf.fk / 4) + g + (is_v ? hf.fk / 8 : 0);
-    size_t soff[HEADF_NS];
-#pragma unroll
-    for (int s = 0; s < HEADF_NS; s++) soff[s] = (size_t)min(s, nsub - 1) * 64;     // (subtiles past the end re-read the last real one)
-    floatx4 acc[HEADF_NS];
-#pragma unroll
-    for (int s = 0; s < HEADF_NS; s++) acc[s] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    heads_fact_chains<HEADF_NS>([&](int ks) { return frow[(size_t)ks * 4]; }, is_v ? hf.wv + lane : hf.wp + (size_t)s0 * 64 + lane,
-                                is_v ? (size_t)64 : (size_t)hf.osp * 64, soff, min(kq * KQ, ksteps), min((kq + 1) * KQ, ksteps), acc);
-#pragma unroll
-    for (int s = 0; s < HEADF_NS; s++) red[kq][s][lane] = acc[s];
-    __syncthreads();
-    for (int s = kq; s < nsub; s += HEADF_Q) {                              // D[m = board g*4 + r][n = output i16]
-        const floatx4 sum = (red[0][s][lane] + red[1][s][lane]) + (red[2][s][lane] + red[3][s][lane]);
-        const int out = is_v ? hf.A + i16 : (s0 + s) * 16 + i16, lim = is_v ? hf.A + hf.NV : hf.A;
-        if (out < lim) {
-            const float bo = hf.bias[out];
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const int board = b0 + g * 4 + r; if (board < boards) logits[(size_t)board * opad + out] = sum[r] + bo; }
-        }
-    }
-}
-
-// one wave per board: softmax over the A policy logits (held in registers: up to 16 per lane, A <= 1024) and the NV value logits
-__global__ __launch_bounds__(256) void k_heads_softmax(const float *logits, float *policy, float *value, int boards, int opad, int A, int NV) {
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= boards) return;
-    heads_softmax_row(logits + (size_t)b * opad, lane, A, NV, policy + (size_t)b * A, value + (size_t)b * NV);
 }
 
 // leaf observation planes [B, C, H, W] (any of the engine's obs dtypes) are written by k_select directly as the stem's

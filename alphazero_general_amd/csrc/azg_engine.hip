@@ -557,6 +557,10 @@ template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSear
 static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}, bool init_only = false) {
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     using GEO = TowerGeom<H, W, BOARDS, C>;
+    constexpr size_t LDS_BYTES = []() {                        // the image (+ the wide search mode's scratch behind it)
+        if constexpr (IS_SEARCH) { if constexpr (SEARCH::WIDE) return (size_t)GEO::TILE + (size_t)WideLds<typename SEARCH::Game, H * W, BOARDS>::BYTES; }
+        return (size_t)GEO::TILE;
+    }();
     // per (instantiation, device): the pixel -> (subtile, lane) table, a few hundred bytes that live as long as the process
     // (the table is a pure function of the template arguments); first use is serialised
     static int16_t *d_map[16] = {nullptr};
@@ -572,7 +576,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
             int16_t *d = nullptr;
             HIPCHK(hipMalloc((void **)&d, sizeof(map)));
             HIPCHK(hipMemcpy(d, map, sizeof(map), hipMemcpyHostToDevice));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::TILE));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             d_map[dev] = d;
         }
     }
@@ -580,14 +584,24 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS + (P.rows_per_model ? P.nmodels - 1 : 0);
     {                                                        // one LDS image, residual stream in registers, >= 2 workgroups per CU
-        const int per_cu = (int)(160 * 1024 / GEO::TILE) > 0 ? (int)(160 * 1024 / GEO::TILE) : 1;
+        const int per_cu = (int)(160 * 1024 / LDS_BYTES) > 0 ? (int)(160 * 1024 / LDS_BYTES) : 1;
         // (search mode: every tile is its own workgroup for the whole launch -- they never synchronise, later ones just start later)
         const int grid = IS_SEARCH || ntiles < per_cu * cus ? ntiles : per_cu * cus;
 #ifdef AZG_TOWER_TIMING
         static unsigned long long *dbg = nullptr; static int calls = 0;
-        if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 8) * 8)); }
+        if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 8) * 8)); HIPCHK(hipMemset(dbg, 0, (2048 + 4096 * 8) * 8)); }
         TowerParams Q = P; Q.dbg = dbg;
-        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, Q, (const int16_t *)d_map[dev], sa);
+        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), LDS_BYTES, s, Q, (const int16_t *)d_map[dev], sa);
+        if constexpr (IS_SEARCH) if constexpr (SEARCH::WIDE) {
+            static unsigned long long w[512 * 4];
+            HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(w, dbg + 2048 + 4096 * 4, sizeof(unsigned long long) * 4 * (grid < 512 ? grid : 512), hipMemcpyDeviceToHost));
+            double ph[4] = {0, 0, 0, 0}; const int nb = grid < 512 ? grid : 512;
+            for (int b = 0; b < nb; b++) for (int i = 0; i < 4; i++) ph[i] += (double)w[b * 4 + i];
+            const double n = (double)nb * (sa.sims > 8 ? sa.sims - 8 : 1);
+            fprintf(stderr, "wide search, cycles per simulation (mean over %d workgroups): tree %.0f tower %.0f headconv %.0f heads %.0f\n", nb, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+            HIPCHK(hipMemset(dbg + 2048 + 4096 * 4, 0, sizeof(unsigned long long) * 4 * 512));
+            calls = 100;
+        }
         if (++calls == 8) {
             unsigned long long h[64 * 4 * 5];
             HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
@@ -604,7 +618,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
                                                    w[b * 8 + 4] - w[b * 8], w[b * 8 + 5] - w[b * 8 + 4], w[b * 8 + 6] - w[b * 8 + 5], w[b * 8 + 7] - w[b * 8 + 6], w[b * 8 + 1] - w[b * 8 + 7]);
         }
 #else
-        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), (size_t)GEO::TILE, s, P, (const int16_t *)d_map[dev], sa);
+        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), LDS_BYTES, s, P, (const int16_t *)d_map[dev], sa);
 #endif
     }
     HIPCHK(hipGetLastError());
@@ -770,6 +784,28 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     EvPair ep; const bool prof = sims > 0 && netprof_begin((hipStream_t)stream, ep);
     const int r = launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
     netprof_end((hipStream_t)stream, 2, prof, ep);
+    return r;
+}
+
+extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
+                                   int nblocks, int channels, const void *head1_w, const float *head1_b, const void *head2_wp, const void *head2_wv,
+                                   const float *head2_b, int feat_k, int sims) {
+    if (!e || !w || !bias || !head1_w || !head1_b || !head2_wp || !head2_wv || !head2_b || nblocks < 0 || sims < 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
+    if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
+    if (e->v.arena) return fail(AZG_E_UNSUPPORTED, "the persistent search launches are built for self-play engines");
+    const int A = e->gi.action_size, NV = e->gi.num_players + 1, hw = e->gi.obs_h * e->gi.obs_w;
+    if (feat_k != (hw * 16 + 31) / 32 * 32) return fail(AZG_E_INVALID_ARG, "feat_k must be H*W*16 rounded up to 32");
+    if (feat_k / 32 > HEADF_Q * HEADF_U) return fail(AZG_E_UNSUPPORTED, "feature rows too long for one load batch per K quarter");
+    TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, nullptr, nullptr, nullptr, nullptr, A, NV, nullptr, head1_w, head1_b, nullptr, feat_k,
+                  nullptr, 0, {}};
+    const HeadsFact hf{(const half8 *)head2_wp, (const half8 *)head2_wv, head2_b, feat_k, (A + 15) / 16, A, NV};
+    hipStream_t s = (hipStream_t)stream;
+    EvPair ep; const bool prof = sims > 0 && netprof_begin(s, ep);
+    int r = AZG_E_UNSUPPORTED;
+    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 2, 64, 2, SearchWide<BR>>(s, P, SearchWide<BR>{e->v, sims, hf}, sims == 0);
+    else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM>>(s, P, SearchWide<TM>{e->v, sims, hf}, sims == 0);
+    else { g_kev = nullptr; return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)"); }
+    netprof_end(s, 2, prof, ep);
     return r;
 }
 

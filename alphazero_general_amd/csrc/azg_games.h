@@ -298,14 +298,14 @@ struct BR {
             }
         }
     }
-    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
-        if (lane < CELLS) {
-            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-            const int c = s.cell;
-            h8 v = {(_Float16)(c == 2 ? 1.f : 0.f), (_Float16)(c == 1 ? 1.f : 0.f), (_Float16)(is_king(c) ? 1.f : 0.f),
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    static AZG_DEV h8 obs8(const S &s, int lane) {               // the five planes of cell `lane` (< CELLS: the lane's own cell)
+        const int c = s.cell; (void)lane;
+        return (h8){(_Float16)(c == 2 ? 1.f : 0.f), (_Float16)(c == 1 ? 1.f : 0.f), (_Float16)(is_king(c) ? 1.f : 0.f),
                     (_Float16)(float)(s.turns & 1), (_Float16)(float)(s.turns / 100), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            *reinterpret_cast<h8 *>(out + lane * 8) = v;
-        }
+    }
+    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
+        if (lane < CELLS) *reinterpret_cast<h8 *>(out + lane * 8) = obs8(s, lane);
     }
     // Game.symmetries (fastafl.pyx:213-256): k = (i-1)*2 + flip; state = fliplr^flip(rot90^i(state)); the policy index is
     // permuted by the reference's own coordinate loop (sym_action)
@@ -395,13 +395,13 @@ struct TM {
             }
         }
     }
-    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
-        if (lane < CELLS) {
-            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-            h8 v = {(_Float16)(float)((s.b[0] >> lane) & 1), (_Float16)(float)((s.b[1] >> lane) & 1), (_Float16)(float)((s.b[2] >> lane) & 1),
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    static AZG_DEV h8 obs8(const S &s, int lane) {               // the five planes of cell `lane` (< CELLS)
+        return (h8){(_Float16)(float)((s.b[0] >> lane) & 1), (_Float16)(float)((s.b[1] >> lane) & 1), (_Float16)(float)((s.b[2] >> lane) & 1),
                     (_Float16)(float)s.player, (_Float16)(float)((double)s.turns / 25.0), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            *reinterpret_cast<h8 *>(out + lane * 8) = v;
-        }
+    }
+    static AZG_DEV void write_obs_nhwc8(const S &s, _Float16 *out, int lane) {
+        if (lane < CELLS) *reinterpret_cast<h8 *>(out + lane * 8) = obs8(s, lane);
     }
     static AZG_DEV S symmetry(const S &s, int k) { (void)k; return s; }
     static AZG_DEV int sym_action(int a, int k) { (void)k; return a; }

@@ -364,17 +364,28 @@ class HipResNet:
                                                       null if logits_only else vp(val)))
         return ws if logits_only else (pol, val)
 
+    @property
+    def can_search(self):
+        """a persistent search launch exists for this network: connect4 x 128 channels with fused heads (azg_search_f16), or
+        factorised heads on brandubh x 64 / the 3-player env x 32 channels (azg_search_wide_f16)."""
+        return (self.fused_head and self.game == 0 and self.CH == 128) or (self.fact_head and (self.game, self.CH) in ((1, 64), (2, 32)))
+
     def search(self, engine, sims):
-        """`sims` whole simulations (select -> this network -> backup) on every slot of `engine` in one persistent launch
-        (azg_search_f16): the trees, the leaf batch and the probabilities never leave the GPU's LDS/HBM and nothing is
-        launched per simulation.  connect4 self-play with the fused 128-channel tower + heads only."""
-        if not self.fused_head:
-            raise NotImplementedError('the fused search kernel needs the fused tower + heads (128 channels, A + NV <= 16)')
+        """`sims` whole simulations (select -> this network -> backup) on every slot of `engine` in one persistent launch: the
+        trees, the leaf planes and the logits / probabilities never leave the GPU's LDS / HBM and nothing is launched per
+        simulation.  Self-play engines only."""
+        if not self.can_search:
+            raise NotImplementedError('no persistent search launch for this (game, network) -- use select / network / backup')
         import ctypes as C
         vp = lambda q: C.c_void_p(q.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        self._check(self.L.azg_search_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
-                                          len(self.blocks), vp(self.head_w_packed), vp(self.head_b16), int(sims)))
+        if self.fused_head:
+            self._check(self.L.azg_search_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
+                                              len(self.blocks), vp(self.head_w_packed), vp(self.head_b16), int(sims)))
+        else:
+            self._check(self.L.azg_search_wide_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
+                                                   len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head2_wp),
+                                                   vp(self.head2_wv), vp(self.head2_b), int(self.feat_k), int(sims)))
 
     @staticmethod
     def forward_models(nets, x_all, policy_all, value_all, rows_per_model):

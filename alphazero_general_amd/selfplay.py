@@ -88,10 +88,10 @@ class SelfPlayRunner:
         self.engine = self.lanes[0].engine                           # single-lane convenience (tests, smoke)
         self.device = self.engine.device
         self.sims_per_round = []
-        # connect4 + fused 128-channel tower: the whole simulation loop of a move can be ONE persistent launch (azg_search_f16)
+        # the whole simulation loop of a move as ONE persistent launch where the network has one (azg_search_f16 / azg_search_wide_f16)
         hip = getattr(nnet, '_hip', None) if nnet is not None else None
-        self.fused_search = (fused_search is None or bool(fused_search)) and self.round_graph and not self.warmup and self.game == 0 \
-            and hip is not None and hip.fused_head and hip.CH == 128
+        self.fused_search = (fused_search is None or bool(fused_search)) and self.round_graph and not self.warmup \
+            and hip is not None and hip.can_search and self.game == hip.game
 
     @property
     def obs(self):

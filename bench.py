@@ -330,8 +330,9 @@ def main():
                 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
                 'algorithmic_flops_per_launch': flops_leaf * units, 'traffic': traffic, 'traffic_source': src}
 
-    roof_search = mfma_roof('search', 'k_tower2<6,7,4,128,1,SearchArgs<C4>> (azg_search_f16: %d x [find_leaf, ResNet + heads, backup] on '
-                            'every game, one persistent launch per move)' % sims, 'SearchArgs', Bl * sims)
+    skind = ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else ('Wide', W['game'], 'azg_search_wide_f16')
+    roof_search = mfma_roof('search', 'k_tower2<...,Search%s<%s>> (%s: %d x [find_leaf, ResNet + heads, backup] on every game, one persistent launch '
+                            'per move)' % (skind + (sims,)), 'Search', Bl * sims)
     roof_net = mfma_roof('tower', 'k_tower2 (%s, one launch per simulation)' % ('both models on their row ranges' if arena else 'ResNet tower'
                                                                                      + ('' if net._hip is None or net._hip.wide_head else ' + heads')),
                          'NoSearch', Bl)

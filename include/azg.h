@@ -240,6 +240,18 @@ int  azg_resnet_policy_value_multi_f16(void *stream, int game, const void *x_dev
 int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const float *bias_dev, const float *pre_scale_dev,
                     const float *pre_shift_dev, int nblocks, const void *head_w_packed_dev, const float *head_b_dev, int sims);
 
+/* The same for networks with FACTORISED heads (wide action spaces): brandubh x 64 channels (two games per workgroup) and the
+ * 3-player env x 32 channels.  Per workgroup and simulation: wavefront b walks game b's tree and its partner wavefront prepares
+ * the priors and the shuffle (azg_backup_select_logits' code), the tower runs on the leaf planes left in LDS, the 1x1 head
+ * convolutions leave their features in LDS and the workgroup's wavefronts turn them into logits with
+ * azg_policy_value_heads_fact_f16's accumulation chains.  Results are identical to `sims` x [azg_select /
+ * azg_backup_select_logits, azg_resnet_tower_features_f16, azg_policy_value_heads_fact_f16 (logits only)] + a final
+ * azg_backup_select_logits without select.  Parameters as those two functions take them; sims == 0: one-time setup only. */
+int  azg_search_wide_f16(azg_engine *e, void *stream, const void *w_packed_dev, const float *bias_dev, const float *pre_scale_dev,
+                         const float *pre_shift_dev, int nblocks, int channels, const void *head1_w_packed_dev,
+                         const float *head1_b_dev, const void *head2_wp_packed_dev, const void *head2_wv_packed_dev,
+                         const float *head2_b_dev, int feat_k, int sims);
+
 /* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same
  * [k = H*W*C, A+NV] matrix applied to the final stream y [boards, k] fp16 that azg_resnet_tower_f16 stores, then the
  * two softmaxes.  head_w_packed: fragment order [k/32][OS = ceil((A+NV)/16)][64 lanes][8 halves], lane g*16+i, half j

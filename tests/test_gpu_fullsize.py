@@ -204,3 +204,44 @@ def test_brandubh_4096_games_fit_one_gpu():
     assert c['sims'] == 2 * 25 * B and 0 < c['max_nodes_used'] <= 8 * sims * 96 + 64
     assert all(t == 2 for (_, _, t) in eng.get_states(B - 4, 4))
     eng.close()
+
+
+@pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200)])
+def test_wide_search_launch_equals_phase_launches(game, B, sims):
+    """azg_search_wide_f16 (networks with factorised heads: tree walk by two wavefronts per game, tower, head convolutions and the
+    logits GEMM all inside one persistent launch) against the launch-per-phase path -- azg_select / azg_backup_select_logits,
+    azg_resnet_tower_features_f16, azg_policy_value_heads_fact_f16 -- on a twin engine: the logits are bit-identical by
+    construction (same accumulation chains), so trees, moves, tape counters and samples must be identical.  The last case is
+    BASELINE config 3's per-GPU size."""
+    import importlib
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.engine import DeviceEngine
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    torch.manual_seed(21)
+    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    net.refresh()
+    hip = net._hip
+    assert hip.fact_head and hip.can_search
+    gid = Game.AZG_GAME_ID
+    kw = dict(cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=4, games_per_iteration=1 << 30,
+              example_capacity=B * 16 * 8, sims_hint=sims)
+    ea, eb = DeviceEngine(gid, B, **kw), DeviceEngine(gid, B, **kw)
+    hw = Game.observation_size()[1] * Game.observation_size()[2]
+    obs = torch.zeros((B, hw, 8), dtype=torch.float16, device=ea.device)
+    moves = 3 if B >= 512 else 14
+    for move in range(moves):
+        hip.search(ea, sims)
+        eb.select(obs)
+        for s in range(sims):
+            eb.backup_select_logits(hip.forward_logits_nhwc8(obs), obs, select=s + 1 < sims)
+        assert torch.equal(ea.root_counts(), eb.root_counts()), move
+        assert torch.equal(ea.root_probs(1.0), eb.root_probs(1.0))
+        assert torch.equal(ea.root_value(True), eb.root_value(True))
+        ea.advance(True); eb.advance(True)
+        assert torch.equal(ea.last_actions(), eb.last_actions())
+        assert (ea.tape_counters() == eb.tape_counters()).all()
+    a, b = ea.counters(), eb.counters()
+    assert a == b and a['sims'] == B * sims * moves
+    for x, y in zip(ea.examples(), eb.examples()):
+        assert torch.equal(x, y)
