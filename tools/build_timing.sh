@@ -1,4 +1,8 @@
 #!/bin/sh
-# measurement build of the library with the tree kernels' phase stamps compiled in (never shipped: gpurun_out/ is scratch)
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
-    -DAZG_TREE_TIMING -o alphazero_general_amd/lib/libazg_timing.so alphazero_general_amd/csrc/azg_engine.hip
+# measurement builds of the library (never shipped as the product: AZG_LIB_PATH selects them):
+#   build_timing.sh tree   -> phase stamps of the tree kernels        (tools/time_tree.py)
+#   build_timing.sh tower  -> per-layer / per-phase stamps of k_tower2 (tools/tower_stamps.py, tools/wide_search_phases.py)
+cd "$(dirname "$0")/.." || exit 1
+case "${1:-tree}" in tower) D=-DAZG_TOWER_TIMING ;; *) D=-DAZG_TREE_TIMING ;; esac
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $D \
+    -o alphazero_general_amd/lib/libazg_timing.so alphazero_general_amd/csrc/azg_engine.hip
