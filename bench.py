@@ -332,7 +332,7 @@ def main():
 
     skind = ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else ('Wide', W['game'], 'azg_search_wide_f16')
     roof_search = mfma_roof('search', 'k_tower2<...,Search%s<%s>> (%s: %d x [find_leaf, ResNet + heads, backup] on every game, one persistent launch '
-                            'per move)' % (skind + (sims,)), 'Search', Bl * sims)
+                            'per move)' % (skind + (sims,)), 'Search' + skind[0] + '<', Bl * sims)
     roof_net = mfma_roof('tower', 'k_tower2 (%s, one launch per simulation)' % ('both models on their row ranges' if arena else 'ResNet tower'
                                                                                      + ('' if net._hip is None or net._hip.wide_head else ' + heads')),
                          'NoSearch', Bl)
