@@ -588,20 +588,28 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
             }
+            // the next block's pre-activation affine: big tiles fetch it after the main loop (registers are the scarce resource at
+            // 2 waves per SIMD, the co-resident wave hides the latency); small tiles run one wave per SIMD with registers to
+            // spare, so they fetch it BEFORE the main loop (after it the load's latency would be fully exposed: ~1 k cycles per block)
+            constexpr bool AFFINE_EARLY = NSUB <= 4;
+            half2v sc[4], sh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
+            auto fetch_affine = [&]() {
+                if (is_s && has_next) {
+                    const float *ps_ = P.pre_scale + (size_t)nb * C + ecol, *pt_ = P.pre_shift + (size_t)nb * C + ecol;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
+                        sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
+                    }
+                }
+            };
+            if constexpr (AFFINE_EARLY) fetch_affine();
             if (layer == 0) { conv_main2<GEO, 1, NSUB, 0, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
             else { conv_main2<GEO, KS, NSUB, 9 % WR, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
             AZG_STAMP2(1);
-            half2v sc[4], sh[4];                                // (fetched here, not under the main loop: registers are the
-#pragma unroll                                                  //  scarce resource at 2 waves per SIMD, the co-resident wave hides it)
-            for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
-            if (is_s && has_next) {
-                const float *ps_ = P.pre_scale + (size_t)nb * C + ecol, *pt_ = P.pre_shift + (size_t)nb * C + ecol;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
-                    sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
-                }
-            }
+            if constexpr (!AFFINE_EARLY) fetch_affine();
             __syncthreads();                                    // every wave is done reading the image
             AZG_STAMP2(2);
             int oz = 0;                                         // opaque zero: the store offsets lb + edelta are loop invariants that
