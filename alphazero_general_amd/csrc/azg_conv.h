@@ -325,8 +325,6 @@ template <class G, int HW, int BOARDS> struct WideLds {
     static constexpr int NSUBTOT = (G::A + 15) / 16 + 1;
     static constexpr int BYTES = (BOARDS * WideScratch<G, HW>::BYTES + 16 + 4 * NSUBTOT * BOARDS * 16 * 4 + 15) / 16 * 16;
 };
-AZG_DEV void flag_set_gen(int *f, int gen, int lane) { if (lane == 0) __hip_atomic_store(f, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-AZG_DEV void flag_wait_gen(int *f, int gen) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) __builtin_amdgcn_s_sleep(1); }
 
 // (the wide search mode keeps one workgroup per CU busy for a whole move and mixes three phases with different register needs:
 //  one wave per SIMD, the whole register file)
@@ -476,11 +474,11 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                         const unsigned long long *less = reinterpret_cast<const unsigned long long *>(ws + WS::LESS);
                         select_tree<G>(sa.ev, slot, tree, hr, st, ctr0, lane, act, sink, [&](int node) {
                             if (waited || node != prev_leaf) return false;
-                            flag_wait_gen(&flags[0], sim); waited = true;
+                            flag_wait_gen(sa.ev, &flags[0], sim); waited = true;
                             return root_noise;
                         }, [&](int k, int ln, int &pos) {
                             if (k > 64) return false;
-                            flag_wait_gen(&flags[1], sim);
+                            flag_wait_gen(sa.ev, &flags[1], sim);
                             pos = __popcll(less[ln] & (k == 64 ? ~0ULL : ((1ULL << k) - 1ULL)));
                             return true;
                         });

@@ -429,9 +429,18 @@ __global__ __launch_bounds__(64) void k_backup(View ev, const float *policy, con
     backup_slot<G>(ev, slot, threadIdx.x, policy + (size_t)row * G::A, value + (size_t)row * (G::P + 1), m_lds, scr);
 }
 
-// hand-off flags between the two wavefronts of a slot (LDS, workgroup-scope release / acquire)
-AZG_DEV void flag_set(int *f, int lane) { if (lane == 0) __hip_atomic_store(f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-AZG_DEV void flag_wait(int *f) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1); }
+// hand-off flags between the two wavefronts of a slot (LDS, workgroup-scope release / acquire).
+// Generation flags: the producer stores `gen`, the consumer waits for a value >= gen.  Every wait is BOUNDED (~10^7 polls, seconds):
+// a hand-off that never comes -- it cannot, both wavefronts run the same uniform control flow -- must not hang the GPU; it raises
+// the sticky AZG_E_INTERNAL instead.
+AZG_DEV void flag_set_gen(int *f, int gen, int lane) { if (lane == 0) __hip_atomic_store(f, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AZG_DEV void flag_wait_gen(const View &ev, int *f, int gen) {
+    for (int spin = 0; spin < (1 << 23); spin++) {
+        if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= gen) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    raise_error(ev, AZG_E_INTERNAL);
+}
 
 // backup of simulation k and find_leaf of simulation k + 1 of the same slot in one launch (they are consecutive in the lock-step
 // loop, SelfPlayAgent.pyx:87-92, and touch the same tree), by TWO wavefronts per slot.  Wave 0 walks the tree: path update of
@@ -445,17 +454,18 @@ AZG_DEV void flag_wait(int *f) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, _
 template <class G, typename OT, bool NHWC8, bool LOGITS>
 __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *policy, const float *value, int ld, OT *obs,
                                                         const int32_t *row_of_slot, int do_select) {
-    if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;   // sticky device error: stop touching the trees
     constexpr int A = G::A, NV = G::P + 1;
     __shared__ float m_lds[A < 8 ? 8 : A];
     __shared__ float scr[64];
     __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
     __shared__ float pi_lds[LOGITS ? A : 1];
     __shared__ unsigned long long less_lds[64];
-    __shared__ int flags[2];                                                 // 0: priors written, 1: shuffle masks ready
+    __shared__ int flags[3];                                                 // 0: priors written, 1: shuffle masks ready, 2: sticky error seen
     const int slot = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     AZG_TSTAMP(ev, slot, threadIdx.x, 8);
     if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+    if (threadIdx.x == 2) flags[2] = ev.gcount[GC_ERROR];                   // ONE read decides for both wavefronts (a wave that left
+                                                                             //  alone would leave its partner waiting for a flag)
     const int row = row_of_slot ? row_of_slot[slot] : slot;
     const int tree = tree_of_slot(ev, slot);
     HdrR hr; load_hdr(ev.hdr + tree, hr);
@@ -464,17 +474,18 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     const bool has_policy = !hr.leaf_e && hr.leaf_fc >= 0;
     const bool root_noise = has_policy && hr.leaf == LEAF_IS_ROOT && ev.add_noise;     // the backup draws one tape number
     __syncthreads();
+    if (flags[2] != 0) return;                                               // sticky device error: stop touching the trees
     if (wave == 1) {                                                         // ---- what the walk will need
         if (has_policy) {
             const float *pi = policy + (size_t)row * ld;
             if constexpr (LOGITS) { policy_softmax_row(pi, lane, A, pi_lds); wave_sync(); pi = pi_lds; }
             backup_policy<G>(ev, slot, hr, nodes, pi, m_lds, scr, lane);
         }
-        flag_set(&flags[0], lane);
+        flag_set_gen(&flags[0], 1, lane);
         AZG_TSTAMP(ev, slot, lane, 9);
         if (do_select) {
             less_lds[lane] = shuffle_less_mask(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
-            flag_set(&flags[1], lane);
+            flag_set_gen(&flags[1], 1, lane);
         }
         AZG_TSTAMP(ev, slot, lane, 0);
         return;
@@ -503,11 +514,11 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
         }
     }, [&](int node) {                                                       // before the child block of `node` is read
         if (waited || node != prev_leaf) return false;
-        flag_wait(&flags[0]); waited = true;                                 // the previous leaf's priors are complete from here on
+        flag_wait_gen(ev, &flags[0], 1); waited = true;                      // the previous leaf's priors are complete from here on
         return root_noise;                                                   // (the tape counter moved)
     }, [&](int k, int ln, int &pos) {                                        // ranks of the k new children
         if (k > 64) return false;
-        flag_wait(&flags[1]);
+        flag_wait_gen(ev, &flags[1], 1);
         pos = __popcll(less_lds[ln] & (k == 64 ? ~0ULL : ((1ULL << k) - 1ULL)));
         return true;
     });

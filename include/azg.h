@@ -35,7 +35,8 @@ typedef enum azg_status {
     AZG_E_INVALID_ACTION = -3,  /* update_root on an action that is not a child (MCTS.pyx:195)      */
     AZG_E_TREE_FULL = -4,       /* a tree's node arena overflowed (raise nodes_per_tree)            */
     AZG_E_EXAMPLES_FULL = -5,   /* the training-example buffer overflowed (raise example_capacity)  */
-    AZG_E_UNSUPPORTED = -6
+    AZG_E_UNSUPPORTED = -6,
+    AZG_E_INTERNAL = -7         /* a bounded device-side wait expired (never expected; reported instead of hanging) */
 } azg_status;
 
 /* games with device-side rules (Game plugin API, alphazero/Game.py:7-113) */
