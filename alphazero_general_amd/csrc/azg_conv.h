@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace azg {
 
@@ -81,25 +82,64 @@ struct TowerGeom {
         const int b = p / HW, pos = p - b * HW, y = pos / W, x = pos - y * W;
         return LEAD + b * BSTRIDE + (y + 1) * PW + x;
     }
+    // Border classes.  A pixel of the top row reads the zero pad row for the three dy = -1 taps (likewise bottom / left /
+    // right), so a subtile made ONLY of top-row pixels can drop those taps' MFMAs: every product in them is an exact zero.
+    // The subtiles are therefore filled class by class -- CLASSES == 5: interior, top row, bottom row, left column, right
+    // column (rows own the corners); CLASSES == 3: middle rows, top row, bottom row -- whenever that needs no more subtiles
+    // than the unclassed tiling (6x7 x 4 boards: 5+2+2+1+1 = 11 subtiles, 81 of 99 subtile-taps remain; 6x7 x 2, 7x7 x 2 and
+    // 5x5 x 2 fit the three-class form).  CLASSES == 1 otherwise.
+    static constexpr int sub16(int n) { return (n + 15) / 16; }
+    static constexpr int S5I = sub16(BOARDS * (H - 2) * (W - 2)), S5R = sub16(BOARDS * W), S5C = sub16(BOARDS * (H - 2));
+    static constexpr int S3M = sub16(BOARDS * (H - 2) * W);
+    static constexpr int CLASSES = (H > 2 && W > 2 && S5I + 2 * S5R + 2 * S5C == NSUB) ? 5 : (H > 2 && S3M + 2 * S5R == NSUB) ? 3 : 1;
+    static constexpr int SMAIN = CLASSES == 5 ? S5I : S3M;                   // subtiles of class 0
+    __host__ __device__ static constexpr int pixel_class(int p) {
+        const int pos = p % HW, y = pos / W, x = pos % W;
+        if (CLASSES == 1) return 0;
+        if (y == 0) return 1;
+        if (y == H - 1) return 2;
+        if (CLASSES == 3) return 0;
+        return x == 0 ? 3 : x == W - 1 ? 4 : 0;
+    }
+    __host__ __device__ static constexpr int class_first(int c) {           // first subtile of class c (class_first(CLASSES) == NSUB)
+        if (CLASSES == 1) return c == 0 ? 0 : NSUB;
+        return c == 0 ? 0 : c == 1 ? SMAIN : c == 2 ? SMAIN + S5R : c == 3 ? SMAIN + 2 * S5R : c == 4 ? SMAIN + 2 * S5R + S5C : NSUB;
+    }
+    __host__ __device__ static constexpr int subtile_class(int gs) {
+        int c = 0;
+        while (c + 1 < CLASSES && gs >= class_first(c + 1)) c++;
+        return c;
+    }
+    __host__ __device__ static constexpr bool tap_active(int tap, int gs) {  // false: every pixel of subtile gs is off-board for the tap
+        const int c = subtile_class(gs), dy = tap / 3 - 1, dx = tap % 3 - 1;
+        return !((c == 1 && dy < 0) || (c == 2 && dy > 0) || (c == 3 && dx < 0) || (c == 4 && dx > 0));
+    }
 };
 
-// host: pixel index for (subtile, lane&15), -1 = spare lane.  8-lane set k = k-th pixel of every residue class.
+// host: pixel index for (subtile, lane&15), -1 = spare lane.  Within a border class (see TowerGeom), 8-lane set k = k-th
+// pixel of every residue class.
 template <class GEO>
 static void tower_pixmap(int16_t *map /*[NSUB*16]*/) {
     static const int setA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, setB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
-    int cls[8][GEO::ROWS], cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = 0; p < GEO::ROWS; p++) { int r = GEO::qrow(p) & 7; cls[r][cnt[r]++] = p; }
     for (int i = 0; i < GEO::NSUB * 16; i++) map[i] = -1;
-    // deal the classes round-robin: 8-lane set k takes, for every residue r, the k-th pixel of class r if it exists;
-    // leftovers (classes of unequal size) go to the free lanes of the last sets
-    int nsets = GEO::NSUB * 2, used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < nsets; k++) {
-        const int *lanes = (k & 1) ? setB : setA; int ps = k >> 1, li = 0;
-        for (int r = 0; r < 8; r++) if (used[r] < cnt[r] && used[r] <= k) map[ps * 16 + lanes[li++]] = (int16_t)cls[r][used[r]++];
+    for (int c = 0; c < GEO::CLASSES; c++) {
+        const int s0 = GEO::class_first(c), s1 = GEO::class_first(c + 1);
+        int cls[8][GEO::ROWS], cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = 0; p < GEO::ROWS; p++) if (GEO::pixel_class(p) == c) { int r = GEO::qrow(p) & 7; cls[r][cnt[r]++] = p; }
+        // deal the residue classes round-robin: 8-lane set k takes, for every residue r, the k-th pixel of class r if it
+        // exists; leftovers (residue classes of unequal size) go to the free lanes of the class's subtiles
+        int nsets = (s1 - s0) * 2, used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < nsets; k++) {
+            const int *lanes = (k & 1) ? setB : setA; int ps = s0 + (k >> 1), li = 0;
+            for (int r = 0; r < 8; r++) if (used[r] < cnt[r] && used[r] <= k) map[ps * 16 + lanes[li++]] = (int16_t)cls[r][used[r]++];
+        }
+        for (int r = 0; r < 8; r++)
+            while (used[r] < cnt[r]) {
+                bool placed = false;
+                for (int i = s0 * 16; i < s1 * 16 && used[r] < cnt[r]; i++) if (map[i] < 0) { map[i] = (int16_t)cls[r][used[r]++]; placed = true; }
+                if (!placed) abort();                           // (CLASSES guarantees the room; unreachable)
+            }
     }
-    for (int r = 0; r < 8; r++)
-        while (used[r] < cnt[r])
-            for (int i = 0; i < GEO::NSUB * 16 && used[r] < cnt[r]; i++) if (map[i] < 0) map[i] = (int16_t)cls[r][used[r]++];
 }
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -264,39 +304,59 @@ struct FragOff {                                             // LDS immediate of
 // N = 9 for small tiles, 2 for even KS, 3 for odd KS (32 channels).
 template <int NSUB, int KS> struct WeightRing { static constexpr int N = NSUB <= 4 ? 9 : (KS % 2 ? 3 : 2); };
 
-template <class GEO, int KS, int NSUB, int RB, int WR>
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {            // f(integral_constant<int, I>) for I in [0, N): indices usable as
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }   // immediates and in if constexpr
+}
+
+template <class GEO, int KS, int NSUB, bool SKIP>
+struct TapPlan {                                             // which fragments t = kk * NSUB + ps the main loop touches
+    static constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB;
+    static constexpr bool act(int t) { return t < TOT && (!SKIP || GEO::tap_active((t / NSUB) / KS, t % NSUB)); }
+    static constexpr int mfmas(int kk) { int n = 0; for (int ps = 0; ps < NSUB; ps++) n += act(kk * NSUB + ps); return n; }
+    static constexpr int reads(int kk, int pf) { int n = 0; for (int ps = 0; ps < NSUB; ps++) n += act(kk * NSUB + ps + pf); return n; }
+};
+
+template <class GEO, int KS, int NSUB, int RB, int WR, bool SKIP>
 __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[WR][2],
                                            floatx4 (&acc)[2][NSUB]) {
     // fragment t = (kk, ps) is read PF fragments ahead into a register ring.  Large tiles index the ring by subtile (slot
     // ps % RING: collision-free with PF = 4 for NSUB = 11 at RING = 6, checked case by case; one slot per subtile otherwise);
-    // small tiles (NSUB <= 4, the low-latency shapes for small batches) by fragment number, RING = PF + 1
-    constexpr int NSTEP = 9 * KS, TOT = NSTEP * NSUB, PF = NSUB <= 4 ? 6 : 4;     // (small tiles run one wave per SIMD: nothing else
+    // small tiles (NSUB <= 4, the low-latency shapes for small batches) by fragment number, RING = PF + 1.
+    // SKIP: fragments whose subtile is wholly off-board for the tap (TowerGeom::tap_active) are neither read nor multiplied
+    using TP = TapPlan<GEO, KS, NSUB, SKIP>;
+    constexpr int NSTEP = 9 * KS, PF = NSUB <= 4 ? 6 : 4;                          // (small tiles run one wave per SIMD: nothing else
     constexpr bool TRING = NSUB <= 4;                                             //  hides the LDS latency; measured 78 -> 72 us at 256 boards)
     constexpr int RING = TRING ? PF + 1 : NSUB == 11 ? 6 : NSUB;
     using FO = FragOff<GEO, KS, NSUB>;
     half8 bb[RING];
-#pragma unroll
-    for (int t = 0; t < PF; t++) bb[(TRING ? t : t % NSUB) % RING] = *reinterpret_cast<const half8 *>(in + lb[t % NSUB] + FO::get(t));
-#pragma clang loop unroll(full)
-    for (int kk = 0; kk < NSTEP; kk++) {
-        const int an = (RB + kk + WR - 1) % WR, ac = (RB + kk) % WR;
+    static_for<0, PF>([&](auto ti) __attribute__((always_inline)) {
+        constexpr int t = decltype(ti)::value;
+        if constexpr (TP::act(t)) bb[(TRING ? t : t % NSUB) % RING] = *reinterpret_cast<const half8 *>(in + lb[t % NSUB] + FO::get(t));
+    });
+    static_for<0, NSTEP>([&](auto ki) __attribute__((always_inline)) {
+        constexpr int kk = decltype(ki)::value;
+        constexpr int an = (RB + kk + WR - 1) % WR, ac = (RB + kk) % WR;
         a[an][0] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP + 64];
-#pragma clang loop unroll(full)
-        for (int ps = 0; ps < NSUB; ps++) {
-            const int t = kk * NSUB + ps, psn = (ps + PF) % NSUB;
-            const int cur = (TRING ? t : ps) % RING, nxt = (TRING ? t + PF : psn) % RING;
-            if (t + PF < TOT) bb[nxt] = *reinterpret_cast<const half8 *>(in + lb[psn] + FO::get(t + PF));
-            acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur], acc[0][ps], 0, 0, 0);
-            acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur], acc[1][ps], 0, 0, 0);
-        }
+        static_for<0, NSUB>([&](auto pi) __attribute__((always_inline)) {
+            constexpr int ps = decltype(pi)::value;
+            constexpr int t = kk * NSUB + ps, psn = (ps + PF) % NSUB;
+            constexpr int cur = (TRING ? t : ps) % RING, nxt = (TRING ? t + PF : psn) % RING;
+            if constexpr (TP::act(t + PF)) bb[nxt] = *reinterpret_cast<const half8 *>(in + lb[psn] + FO::get(t + PF));
+            if constexpr (TP::act(t)) {
+                acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur], acc[0][ps], 0, 0, 0);
+                acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur], acc[1][ps], 0, 0, 0);
+            }
+        });
+        constexpr int NR = TP::reads(kk, PF), NM = TP::mfmas(kk);
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-#pragma unroll
-        for (int ps = 0; ps < NSUB; ps++) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
+        static_for<0, NSUB>([&](auto pi) __attribute__((always_inline)) {
+            constexpr int i = decltype(pi)::value;
+            if constexpr (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (i < NM) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        });
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
 // PSPLIT > 1 (narrow towers at small batches, where a workgroup of C/32 waves leaves SIMDs empty): the tile's pixel subtiles
@@ -340,6 +400,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
     TowerParams P = Pin;
     constexpr int NT = C * 2 * PSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
     constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
+    constexpr bool TAPSKIP = PSPLIT == 1 && GEO::CLASSES > 1;   // (a wave's subtile numbers must be compile-time constants)
     constexpr int HW = GEO::HW, ROWS = GEO::ROWS, TILE = GEO::TILE, RS = GEO::RSTRIDE;
     // LDS scratch in the zero rows above board 0 (restored to zero after use): [0, 4096) heads reduction, then 256 B of
     // probabilities + a flag word (search mode) -- all inside the pad line, which ends at (LEAD + PW) * RS
@@ -604,8 +665,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 }
             };
             if constexpr (AFFINE_EARLY) fetch_affine();
-            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
-            else { conv_main2<GEO, KS, NSUB, 9 % WR, WR>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
+            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0, WR, TAPSKIP>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
+            else { conv_main2<GEO, KS, NSUB, 9 % WR, WR, TAPSKIP>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
             AZG_STAMP2(1);
             if constexpr (!AFFINE_EARLY) fetch_affine();
             __syncthreads();                                    // every wave is done reading the image
