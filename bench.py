@@ -319,6 +319,16 @@ def main():
     # ---- roofline of the network launch (MFMA) and of the tree launch (HBM), from the eager rounds' events
     flops_leaf = net_flops_per_leaf(Game, net.args)
 
+    def issued_frac():
+        """MFMA work the 4-board connect4 tile actually issues / the algorithmic count: border-class subtiles drop the taps
+        that only read zero padding -- 81 of 99 subtile-taps, on 176 lanes for 168 pixels"""
+        if a.workload != 'connect4':
+            return None
+        _, H, Wd = Game.observation_size()
+        sub = lambda n: (n + 15) // 16
+        n5 = [sub(4 * (H - 2) * (Wd - 2)), sub(4 * Wd), sub(4 * (H - 2))]
+        return round((n5[0] * 9 + 2 * n5[1] * 6 + 2 * n5[2] * 6) * 16 / (9.0 * 4 * H * Wd), 4)
+
     def mfma_roof(fam, kname, kmatch, units):
         n = int(netprof.get(fam + '_n', 0))
         if not n:
@@ -328,7 +338,8 @@ def main():
         traffic, src = measured_traffic(a.workload, kmatch)
         return {'kernel': kname, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
-                'algorithmic_flops_per_launch': flops_leaf * units, 'traffic': traffic, 'traffic_source': src}
+                'algorithmic_flops_per_launch': flops_leaf * units, 'mfma_issued_over_algorithmic': issued_frac(),
+                'traffic': traffic, 'traffic_source': src}
 
     skind = ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else ('Wide', W['game'], 'azg_search_wide_f16')
     roof_search = mfma_roof('search', 'k_tower2<...,Search%s<%s>> (%s: %d x [find_leaf, ResNet + heads, backup] on every game, one persistent launch '

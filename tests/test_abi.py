@@ -114,4 +114,24 @@ def test_tower_lds_layout_invariants(game, bt, ch, H, W):
             res = [q[pm[s * 16 + l]] % 8 for l in lanes if pm[s * 16 + l] >= 0]
             doubled += len(res) - len(set(res))
     assert doubled <= nsub                                                   # conflict-free up to the leftovers of unequal classes
+    # border classes (TowerGeom::CLASSES): where the class-wise subtile count equals nsub, subtiles hold pixels of ONE class
+    # -- [interior | top row | bottom row | left column | right column] or [middle rows | top row | bottom row] -- which is
+    # what lets the main loop drop the taps that would only read the zero padding
+    sub = lambda n: (n + 15) // 16
+    five = [sub(bt * (H - 2) * (W - 2)), sub(bt * W), sub(bt * W), sub(bt * (H - 2)), sub(bt * (H - 2))]
+    three = [sub(bt * (H - 2) * W), sub(bt * W), sub(bt * W)]
+    counts = five if sum(five) == nsub else three if sum(three) == nsub else None
+    assert (counts is not None) == ((bt, H, W) in {(4, 6, 7), (2, 6, 7), (2, 7, 7), (2, 5, 5)})
+    if counts is not None:
+        def pclass(p):
+            y, x = divmod(p % (H * W), W)
+            if y == 0: return 1
+            if y == H - 1: return 2
+            if len(counts) == 3: return 0
+            return 3 if x == 0 else 4 if x == W - 1 else 0
+        first = np.cumsum([0] + counts)
+        for s in range(nsub):
+            c = int(np.searchsorted(first, s, side='right') - 1)
+            assert all(pclass(int(p)) == c for p in pm[s * 16:(s + 1) * 16] if p >= 0), (s, c)
+        assert doubled == 0 or (bt, H, W) != (4, 6, 7)                       # the headline tile stays conflict-free
     assert L.azg_tower_layout(game, 3, ch, None, None, info) == _abi.E_UNSUPPORTED

@@ -5,7 +5,8 @@
 Per workload: (1) `rocprofv3 --kernel-trace --stats` of the bench command -> profiles/r02_<workload>_kernel_stats.csv and the bench
 line printed under the profiler; (2) PMC passes of the same command, one counter set per pass as MI355X_MICROARCH.md prescribes
 (FETCH_SIZE and WRITE_SIZE cannot share a pass; never combined with --stats / trace domains other than the kernel trace):
-per-kernel averages -> profiles/r02_pmc_summary.csv, and HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; the
+(profiles/ does not travel back from the GPU box, gpurun_out/ does: re-run with --reuse in the build container to rebuild the
+profiles/r02_* files from the raw output)  per-kernel averages -> profiles/r02_pmc_summary.csv, and HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; the
 guide's gfx950 correction: FETCH_SIZE reports half the bytes of wide loads) -> profiles/r02_pmc.json, which bench.py reads for its
 `traffic` fields.  The connect4 run adds an MFMA / LDS / clock pass for the search launch."""
 import argparse
@@ -23,13 +24,23 @@ SCRATCH = os.path.join(ROOT, 'gpurun_out', 'r02_prof')
 KEEP = ('k_tower2', 'k_backup_select2', 'k_heads', 'k_select', 'k_backup', 'k_play', 'k_compact', 'k_emit', 'k_finalize', 'k_arena_rows')
 
 
+REUSE = False
+
+
 def rocprof(tag, extra, bench_args, timeout=600):
     out = os.path.join(SCRATCH, tag)
+    saved = os.path.join(out, 'bench_line.json')
+    if REUSE:                                                   # post-process the raw output of an earlier run (no GPU needed)
+        line = open(saved).read().strip() if os.path.exists(saved) else None
+        return out, line, 0 if os.path.isdir(out) else -1
     shutil.rmtree(out, ignore_errors=True)
     env = dict(os.environ, TMPDIR='/tmp')
     cmd = ['rocprofv3'] + extra + ['--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(ROOT, 'bench.py')] + bench_args
     r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     line = [l for l in r.stdout.decode(errors='replace').splitlines() if l.startswith('{"metric"')]
+    if line and os.path.isdir(out):
+        with open(saved, 'w') as fh:
+            fh.write(line[0] + '\n')
     return out, (line[0] if line else None), r.returncode
 
 
@@ -67,7 +78,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--git', default=os.environ.get('AZG_GIT', 'unknown'))
     ap.add_argument('--workloads', nargs='*', default=['connect4', 'brandubh', 'arena', 'trimok'])
+    ap.add_argument('--reuse', action='store_true', help='rebuild profiles/r02_* from the raw output already under gpurun_out/r02_prof')
     a = ap.parse_args()
+    global REUSE
+    REUSE = a.reuse
     os.makedirs(PROF, exist_ok=True); os.makedirs(SCRATCH, exist_ok=True)
     summary_rows, pmc = [], {'git': a.git, 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
     for w in a.workloads:
