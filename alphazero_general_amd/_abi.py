@@ -63,6 +63,7 @@ SYMBOLS = {
     'azg_backup': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     'azg_backup_select': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
     'azg_backup_select_logits': (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i]),
+    'azg_backup_select_features': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
     'azg_advance': (_i, [_vp, _vp, _i]),
     'azg_advance_begin': (_i, [_vp, _vp, _i, _i32p]),
     'azg_advance_commit': (_i, [_vp, _vp, _i32p]),
@@ -89,7 +90,7 @@ SYMBOLS = {
     'azg_tower_layout': (_i, [_i, _i, _i, _vp, _vp, _vp]),
     'azg_resnet_tower_features_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
     'azg_policy_value_heads_fact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'azg_search_wide_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i]),
+    'azg_search_wide_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_profile_net_enable': (_i, [_i]),
     'azg_profile_net_read': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'azg_profile_enable': (_i, [_vp, _i]),

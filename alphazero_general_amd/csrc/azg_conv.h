@@ -371,8 +371,9 @@ struct NoSearch {};
 template <class G> struct SearchArgs { View ev; int sims; using Game = G; static constexpr bool WIDE = false; };
 // The same for networks with factorised heads (wide action spaces, any tower width): BOARDS games per workgroup, wave b walks game
 // b, wave BOARDS + b prepares its priors and shuffle (the two-wave scheme of k_backup_select2), the head convolutions leave their
-// features in LDS and the workgroup's waves -- one K quarter each, exactly k_heads_fact's chains -- turn them into logits in LDS.
-template <class G> struct SearchWide { View ev; int sims; HeadsFact hf; using Game = G; static constexpr bool WIDE = true; };
+// features in LDS and the next tree phase computes the logits it needs from them (azg_kernels.h, sparse heads: the value
+// logits by the walker, the policy logits of the leaf's valid actions by the helper) -- the code of the launch-per-phase path.
+template <class G> struct SearchWide { View ev; int sims; HeadRows hd; using Game = G; static constexpr bool WIDE = true; };
 
 // per-game LDS scratch of the wide search mode (behind the image)
 template <class G, int HW> struct WideScratch {
@@ -380,10 +381,9 @@ template <class G, int HW> struct WideScratch {
     static constexpr int LG = 0, PI = LG + OPAD * 4, M = PI + A * 4, SCR = M + (A < 8 ? 8 : A) * 4, ACT = SCR + 256,
                          LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + 512, FEAT = FLAGS + 16, BYTES = (FEAT + 2 * FK * 2 + 15) / 16 * 16;
 };
-// all of the wide search mode's LDS behind the image: the per-game scratch, an error word, the heads' partial sums
+// all of the wide search mode's LDS behind the image: the per-game scratch and an error word
 template <class G, int HW, int BOARDS> struct WideLds {
-    static constexpr int NSUBTOT = (G::A + 15) / 16 + 1;
-    static constexpr int BYTES = (BOARDS * WideScratch<G, HW>::BYTES + 16 + 4 * NSUBTOT * BOARDS * 16 * 4 + 15) / 16 * 16;
+    static constexpr int BYTES = (BOARDS * WideScratch<G, HW>::BYTES + 16 + 15) / 16 * 16;
 };
 
 // (the wide search mode keeps one workgroup per CU busy for a whole move and mixes three phases with different register needs:
@@ -524,7 +524,12 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 } else {
                     Node *nodes = tree_nodes(sa.ev, tree, hr.base);
                     float val[NV];
-                    const float pv = value_softmax(lg + A, lane, NV);
+                    float pv = 0.f;
+                    if (!hr.leaf_e) {                                // (a terminal leaf backs its win state up, not the network)
+                        leaf_value_logits<G>(sa.hd, reinterpret_cast<const _Float16 *>(ws + WS::FEAT) + sa.hd.fk, lg + A, lane);
+                        wave_sync();
+                        pv = value_softmax(lg + A, lane, NV);
+                    }
 #pragma unroll
                     for (int j = 0; j < NV; j++) val[j] = rl(pv, j);
                     const int prev_leaf = hr.leaf;
@@ -549,6 +554,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 if (has_policy) {
                     Node *nodes = tree_nodes(sa.ev, tree, hr.base);
                     float *pi = reinterpret_cast<float *>(ws + WS::PI);
+                    leaf_policy_logits<G>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
+                    wave_sync();
                     policy_softmax_row(lg, lane, A, pi);
                     wave_sync();
                     backup_policy<G>(sa.ev, slot, hr, nodes, pi, reinterpret_cast<float *>(ws + WS::M), reinterpret_cast<float *>(ws + WS::SCR), lane);
@@ -761,93 +768,12 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 }
             }
             if constexpr (IS_WIDE) {
-                // second stage in-kernel: wave kq runs K quarter kq of every subtile chunk -- k_heads_fact's chains with the features
-                // read from LDS -- and the partial sums meet in LDS in the same association, (q0 + q1) + (q2 + q3) + bias
-                using G = typename SEARCH::Game;
-                using WS = WideScratch<G, HW>;
-                constexpr int A = G::A, NV = G::P + 1, OSP = (A + 15) / 16, NSUBTOT = OSP + 1;
-                static_assert((C / 32) * PSPLIT >= HEADF_Q, "one wavefront per K quarter");
+                // (second stage: the next tree phase turns the features into the logits it needs -- sparse heads, azg_kernels.h)
                 __syncthreads();                                 // the features of every board are in LDS
                 AZG_WPHASE(3);
-                float *red = reinterpret_cast<float *>(smem + TILE + BOARDS * WS::BYTES + 16);      // [HEADF_Q][NSUBTOT][BOARDS][16]
-                const int ksteps = sa.hf.fk / 32, KQ = heads_fact_kq(ksteps);
-                if (wave < HEADF_Q) {
-                    const int kq = wave;
-                    const bool bvalid = i16 < BOARDS;
-                    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const _Float16 *fbase = reinterpret_cast<const _Float16 *>(smem + TILE + (bvalid ? i16 : 0) * WS::BYTES + WS::FEAT) + g * 8;
-                    const int kb = min(kq * KQ, ksteps), ke = min((kq + 1) * KQ, ksteps);
-                    // One load batch per chain (KQ <= HEADF_U, checked on the host).  The chunks are software-pipelined: the weight
-                    // fragments of chunk c + 1 are in flight while chunk c's MFMAs run -- a wave walks through all the chunks here,
-                    // where k_heads_fact has one workgroup per chunk, and would otherwise pay one L2 round trip per chunk
-                    // (the grouping of subtiles is free -- only a subtile's own chain order matters for the bits: groups of GN keep
-                    //  two buffers of weight fragments inside the register file)
-                    constexpr int GN = 3, NGP = (OSP + GN - 1) / GN;     // subtile groups: NGP policy groups, then the value subtile
-                    half8 wb[2][HEADF_U][GN];
-                    auto issue = [&](int grp, half8 (&b)[HEADF_U][GN]) {
-                        const bool is_v = grp == NGP;
-                        const int s0 = is_v ? OSP : grp * GN, nsub = is_v ? 1 : min(GN, OSP - s0);
-                        const half8 *wl = is_v ? sa.hf.wv + lane : sa.hf.wp + (size_t)s0 * 64 + lane;
-                        const size_t wstride = is_v ? (size_t)64 : (size_t)OSP * 64;
-#pragma unroll
-                        for (int u = 0; u < HEADF_U; u++) {
-                            const int kc = min(kb + u, ke - 1);
-#pragma unroll
-                            for (int q = 0; q < GN; q++) b[u][q] = wl[(size_t)kc * wstride + (size_t)min(q, nsub - 1) * 64];
-                        }
-                    };
-                    auto compute = [&](int grp, const half8 (&b)[HEADF_U][GN]) {
-                        const bool is_v = grp == NGP;
-                        const int s0 = is_v ? OSP : grp * GN, nsub = is_v ? 1 : min(GN, OSP - s0);
-                        const _Float16 *frow = fbase + (is_v ? sa.hf.fk : 0);
-                        floatx4 hacc2[GN];
-#pragma unroll
-                        for (int q = 0; q < GN; q++) hacc2[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int u = 0; u < HEADF_U; u++) {
-                            half8 av = *reinterpret_cast<const half8 *>(frow + min(kb + u, ke - 1) * 32);
-                            if (!bvalid || kb + u >= ke) av = zero8;
-#pragma unroll
-                            for (int q = 0; q < GN; q++) hacc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b[u][q], hacc2[q], 0, 0, 0);
-                        }
-                        if (g == 0) {                            // D[m = board g*4 + r][n = output i16]: the real boards are rows 0 .. BOARDS-1
-#pragma unroll
-                            for (int q = 0; q < GN; q++)
-                                if (q < nsub) {
-#pragma unroll
-                                    for (int r = 0; r < (BOARDS < 4 ? BOARDS : 4); r++) red[((kq * NSUBTOT + s0 + q) * BOARDS + r) * 16 + i16] = hacc2[q][r];
-                                }
-                        }
-                    };
-                    if (kb < ke) {
-                        issue(0, wb[0]);
-#pragma unroll 1
-                        for (int grp = 0; grp <= NGP; grp += 2) {
-                            if (grp + 1 <= NGP) issue(grp + 1, wb[1]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            compute(grp, wb[0]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (grp + 2 <= NGP) issue(grp + 2, wb[0]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (grp + 1 <= NGP) compute(grp + 1, wb[1]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    } else if (g == 0) {                         // (an empty quarter contributes zeros)
-                        for (int sq = 0; sq < NSUBTOT; sq++)
-                            for (int r = 0; r < (BOARDS < 4 ? BOARDS : 4); r++) red[((kq * NSUBTOT + sq) * BOARDS + r) * 16 + i16] = 0.f;
-                    }
-                }
-                __syncthreads();
-                for (int e = tid; e < BOARDS * (A + NV); e += NT) {
-                    const int bdx = e / (A + NV), out = e - bdx * (A + NV);
-                    const int sq = out < A ? out / 16 : OSP, n = out < A ? out % 16 : out - A;
-                    const float r0 = red[((0 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n], r1 = red[((1 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n];
-                    const float r2 = red[((2 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n], r3 = red[((3 * NSUBTOT + sq) * BOARDS + bdx) * 16 + n];
-                    reinterpret_cast<float *>(smem + TILE + bdx * WS::BYTES + WS::LG)[out] = ((r0 + r1) + (r2 + r3)) + sa.hf.bias[out];
-                }
                 AZG_WPHASE(4);
 #ifdef AZG_TOWER_TIMING
-                if (P.dbg && tid == 0 && blockIdx.x < 512 && sim >= 8)      // tree, tower, head conv, heads GEMM (cycles, summed over simulations)
+                if (P.dbg && tid == 0 && blockIdx.x < 512 && sim >= 8)      // tree (incl. the sparse heads), tower, head conv (cycles, summed over simulations)
                     for (int i = 0; i < 4; i++) P.dbg[2048 + 4096 * 4 + (size_t)blockIdx.x * 4 + i] += wt_[i + 1] - wt_[i];
 #endif
             }

@@ -312,9 +312,9 @@ extern "C" int azg_backup_select(azg_engine *e, void *stream, const float *polic
     if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
     const int A = e->gi.action_size;
-    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, float, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (float *)obs, row_of_slot, 1)); }
-    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, false, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
-    else { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, true, false>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1)); }
+    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, float, false, IN_PROBS>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (float *)obs, row_of_slot, 1, HeadRows{})); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, false, IN_PROBS>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1, HeadRows{})); }
+    else { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, true, IN_PROBS>), dim3(v.B), dim3(128), 0, s, v, policy, value, A, (_Float16 *)obs, row_of_slot, 1, HeadRows{})); }
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -331,9 +331,31 @@ extern "C" int azg_backup_select_logits(azg_engine *e, void *stream, const float
     if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
     EvPair p; prof_begin(e, s, 1, p);
     const float *nov = nullptr;
-    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, float, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (float *)obs, row_of_slot, do_select)); }
-    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, false, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
-    else { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, true, true>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select)); }
+    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, float, false, IN_LOGITS>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (float *)obs, row_of_slot, do_select, HeadRows{})); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, false, IN_LOGITS>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select, HeadRows{})); }
+    else { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, true, IN_LOGITS>), dim3(v.B), dim3(128), 0, s, v, logits, nov, logits_stride, (_Float16 *)obs, row_of_slot, do_select, HeadRows{})); }
+    prof_end(e, s, 1, p);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_backup_select_features(azg_engine *e, void *stream, const void *feat, int feat_k, const void *head_rows, const float *head_b,
+                                          const int32_t *row_of_slot, int flags, void *obs, int obs_dtype, int do_select) {
+    if (!e || !feat || !head_rows || !head_b) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (obs_dtype < 0 || obs_dtype > 2) return fail(AZG_E_INVALID_ARG, "obs_dtype must be 0 (f32), 1 (f16) or 2 (f16 NHWC8)");
+    if (e->gi.action_size > 1024) return fail(AZG_E_INVALID_ARG, "A <= 1024");
+    hipStream_t s = (hipStream_t)stream;
+    View v = e->v;
+    if (flags >= 0) { v.add_noise = (flags & AZG_FLAG_NOISE) ? 1 : 0; v.add_temp = (flags & AZG_FLAG_TEMP) ? 1 : 0; }
+    const HeadRows hd{(const _Float16 *)head_rows, head_b, feat_k};
+    int want = 0;
+    GAME_SWITCH(e, want = head_fk<G>());
+    if (feat_k != want) return fail(AZG_E_INVALID_ARG, "feat_k must be cells x 16 rounded up to a multiple of 32 for this game");
+    EvPair p; prof_begin(e, s, 1, p);
+    const float *nov = nullptr, *f = (const float *)feat;
+    if (obs_dtype == 0) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, float, false, IN_FEATURES>), dim3(v.B), dim3(128), 0, s, v, f, nov, 0, (float *)obs, row_of_slot, do_select, hd)); }
+    else if (obs_dtype == 1) { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, false, IN_FEATURES>), dim3(v.B), dim3(128), 0, s, v, f, nov, 0, (_Float16 *)obs, row_of_slot, do_select, hd)); }
+    else { GAME_SWITCH(e, AZG_LAUNCH((k_backup_select2<G, _Float16, true, IN_FEATURES>), dim3(v.B), dim3(128), 0, s, v, f, nov, 0, (_Float16 *)obs, row_of_slot, do_select, hd)); }
     prof_end(e, s, 1, p);
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -788,22 +810,21 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
 }
 
 extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
-                                   int nblocks, int channels, const void *head1_w, const float *head1_b, const void *head2_wp, const void *head2_wv,
-                                   const float *head2_b, int feat_k, int sims) {
-    if (!e || !w || !bias || !head1_w || !head1_b || !head2_wp || !head2_wv || !head2_b || nblocks < 0 || sims < 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
+                                   int nblocks, int channels, const void *head1_w, const float *head1_b, const void *head_rows, const float *head_b,
+                                   int feat_k, int sims) {
+    if (!e || !w || !bias || !head1_w || !head1_b || !head_rows || !head_b || nblocks < 0 || sims < 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     if (e->v.arena) return fail(AZG_E_UNSUPPORTED, "the persistent search launches are built for self-play engines");
     const int A = e->gi.action_size, NV = e->gi.num_players + 1, hw = e->gi.obs_h * e->gi.obs_w;
     if (feat_k != (hw * 16 + 31) / 32 * 32) return fail(AZG_E_INVALID_ARG, "feat_k must be H*W*16 rounded up to 32");
-    if (feat_k / 32 > HEADF_Q * HEADF_U) return fail(AZG_E_UNSUPPORTED, "feature rows too long for one load batch per K quarter");
     TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, nullptr, nullptr, nullptr, nullptr, A, NV, nullptr, head1_w, head1_b, nullptr, feat_k,
                   nullptr, 0, {}};
-    const HeadsFact hf{(const half8 *)head2_wp, (const half8 *)head2_wv, head2_b, feat_k, (A + 15) / 16, A, NV};
+    const HeadRows hd{(const _Float16 *)head_rows, head_b, feat_k};
     hipStream_t s = (hipStream_t)stream;
     EvPair ep; const bool prof = sims > 0 && netprof_begin(s, ep);
     int r = AZG_E_UNSUPPORTED;
-    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 2, 64, 2, SearchWide<BR>>(s, P, SearchWide<BR>{e->v, sims, hf}, sims == 0);
-    else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM>>(s, P, SearchWide<TM>{e->v, sims, hf}, sims == 0);
+    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 2, 64, 2, SearchWide<BR>>(s, P, SearchWide<BR>{e->v, sims, hd}, sims == 0);
+    else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM>>(s, P, SearchWide<TM>{e->v, sims, hd}, sims == 0);
     else { g_kev = nullptr; return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)"); }
     netprof_end(s, 2, prof, ep);
     return r;

@@ -442,6 +442,102 @@ AZG_DEV void flag_wait_gen(const View &ev, int *f, int gen) {
     raise_error(ev, AZG_E_INTERNAL);
 }
 
+// ================================================================================================ sparse heads
+// A factorised head (NNetArchitecture.py:88-102: 1x1 conv -> BN -> flatten -> Linear chain, all linear) ends in one dot product per
+// output over the board's head features.  process_results only ever uses the logits of the leaf's VALID actions -- the policy is
+// masked and renormalised (MCTS.pyx:239-245) -- so the tree launch computes exactly those, k <= MAXK rows of the collapsed matrix
+// instead of all A (brandubh: ~40 of 588, 64 KB of weights per leaf instead of 0.93 MB), and leaves -inf everywhere else: the
+// softmax over the row then IS the softmax over the valid actions.  Against softmax-over-all-A followed by mask + renormalise
+// this differs only in rounding (the full normaliser cancels): priors agree to ~1e-7 relative, far inside the fp16 network's
+// own error; if every valid action underflowed in the full softmax the reference would leave zeros where this path still
+// normalises -- logit gaps > 87, never seen.
+//   rows: fp16 [A + P + 1][fk] row-major (o < A policy output o over the policy features, then the value outputs over the value
+//   features), bias f32 [A + P + 1]; a board's features: fp16 [2][fk] = policy half, value half, index pixel * 16 + channel.
+struct HeadRows { const _Float16 *rows; const float *bias; int fk; };
+template <class G> constexpr int head_fk() { return (G::CELLS * 16 + 31) / 32 * 32; }
+typedef _Float16 hrow8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hrow2 __attribute__((ext_vector_type(2)));
+
+// One output per DPP row of 16 lanes: lane j16 owns the 16-byte chunks j16, j16 + 16, ... of the row.  fp32 accumulation with
+// v_dot2_f32_f16 in chunk order, then a butterfly over the row: a fixed association, the same in every kernel that calls it.
+template <int FK>
+struct HeadDot {
+    static constexpr int NCH = FK / 8, IT = (NCH + 15) / 16;
+    static AZG_DEV void load(hrow8 (&w)[IT], const _Float16 *row, int j16, bool on) {
+        const hrow8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < IT; t++) {
+            const int c = j16 + 16 * t;
+            w[t] = (on && c < NCH) ? *reinterpret_cast<const hrow8 *>(row + c * 8) : zero;
+        }
+    }
+    static AZG_DEV float dot(const hrow8 (&w)[IT], const _Float16 *feat, int j16) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < IT; t++) {
+            const hrow8 f = *reinterpret_cast<const hrow8 *>(feat + min(j16 + 16 * t, NCH - 1) * 8);      // (past the end: w is zero)
+#pragma unroll
+            for (int h = 0; h < 4; h++)
+                acc = __builtin_amdgcn_fdot2((hrow2){w[t][2 * h], w[t][2 * h + 1]}, (hrow2){f[2 * h], f[2 * h + 1]}, acc, false);
+        }
+        acc += dpp_f<DPP_QUAD_XOR1>(acc); acc += dpp_f<DPP_QUAD_XOR2>(acc);
+        acc += dpp_f<DPP_ROW_HALF_MIRROR>(acc); acc += dpp_f<DPP_ROW_MIRROR>(acc);
+        return acc;
+    }
+};
+
+// policy logits of the last leaf's k children (one wavefront): lg[a] for their actions, -inf for every other a < A.  Four
+// children per pass (one per DPP row), the weight rows prefetched DEPTH passes ahead.  feat: the board's policy features.
+template <class G>
+AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, int k, const _Float16 *feat, float *lg, int lane) {
+    constexpr int A = G::A, FK = head_fk<G>(), DEPTH = 4;
+    using HD = HeadDot<FK>;
+    for (int a = lane; a < A; a += 64) lg[a] = -INFINITY;
+    int acts[(G::MAXK + 63) / 64];                                           // child i's action in lane i & 63 of acts[i >> 6]
+#pragma unroll
+    for (int c = 0; c < (G::MAXK + 63) / 64; c++) acts[c] = c * 64 + lane < k ? (int)nodes[fc + c * 64 + lane].a : 0;
+    wave_sync();
+    const int r = lane >> 4, j16 = lane & 15, npass = (k + 3) >> 2;
+    hrow8 w[DEPTH][HD::IT];
+    int act[DEPTH];
+    auto issue = [&](int d, int p) {
+        const int i = 4 * p + r;
+        int a = 0;
+#pragma unroll
+        for (int c = 0; c < (G::MAXK + 63) / 64; c++) {
+            const int v = __builtin_amdgcn_ds_bpermute((i & 63) << 2, acts[c]);
+            if ((i >> 6) == c) a = v;
+        }
+        act[d] = a;
+        HD::load(w[d], hd.rows + (size_t)a * hd.fk, j16, i < k);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) if (d < npass) issue(d, d);
+    for (int p0 = 0; p0 < npass; p0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int p = p0 + d;
+            if (p < npass) {
+                const float x = HD::dot(w[d], feat, j16);
+                if (j16 == 0 && 4 * p + r < k) lg[act[d]] = x + hd.bias[act[d]];
+                if (p + DEPTH < npass) issue(d, p + DEPTH);
+            }
+        }
+    }
+}
+// the P + 1 value logits of a board into lg[0 .. NV) (one wavefront, one pass).  feat: the board's value features.
+template <class G>
+AZG_DEV void leaf_value_logits(const HeadRows &hd, const _Float16 *feat, float *lg, int lane) {
+    constexpr int A = G::A, NV = G::P + 1, FK = head_fk<G>();
+    static_assert(NV <= 4, "one DPP row per value output");
+    using HD = HeadDot<FK>;
+    const int r = lane >> 4, j16 = lane & 15;
+    hrow8 w[HD::IT];
+    HD::load(w, hd.rows + (size_t)(A + min(r, NV - 1)) * hd.fk, j16, r < NV);
+    const float x = HD::dot(w, feat, j16);
+    if (j16 == 0 && r < NV) lg[r] = x + hd.bias[A + r];
+}
+
 // backup of simulation k and find_leaf of simulation k + 1 of the same slot in one launch (they are consecutive in the lock-step
 // loop, SelfPlayAgent.pyx:87-92, and touch the same tree), by TWO wavefronts per slot.  Wave 0 walks the tree: path update of
 // simulation k, then the descent and expansion of simulation k + 1.  Wave 1 prepares what the walk will need: (1) the priors of
@@ -449,16 +545,21 @@ AZG_DEV void flag_wait_gen(const View &ev, int *f, int gen) {
 // (2) the shuffle of the next expansion -- the all-pairs comparison of the next 64 tape keys, which does not depend on which
 // leaf gets expanded.  The walk waits for (1) only if the descent enters the previous leaf, and for (2) when it expands.
 // Same arithmetic as the one-wave functions, same results.
-//   LOGITS: `policy` holds rows of stride `ld` with A policy logits then P + 1 value logits (as azg_policy_value_heads_f16 leaves
-//   them) instead of probabilities -- one launch and one HBM round trip of the probabilities less per simulation.
-template <class G, typename OT, bool NHWC8, bool LOGITS>
+//   IN_LOGITS: `policy` holds rows of stride `ld` with A policy logits then P + 1 value logits (as azg_policy_value_heads_f16
+//   leaves them) instead of probabilities -- one launch and one HBM round trip of the probabilities less per simulation.
+//   IN_FEATURES: `policy` holds the boards' head features (fp16 [2][hd.fk] per row, as azg_resnet_tower_features_f16 leaves them)
+//   and the launch computes the logits it needs itself (sparse heads above) -- no heads launch at all.
+enum { IN_PROBS = 0, IN_LOGITS = 1, IN_FEATURES = 2 };
+template <class G, typename OT, bool NHWC8, int MODE>
 __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *policy, const float *value, int ld, OT *obs,
-                                                        const int32_t *row_of_slot, int do_select) {
+                                                        const int32_t *row_of_slot, int do_select, HeadRows hd) {
     constexpr int A = G::A, NV = G::P + 1;
+    constexpr bool LOGITS = MODE != IN_PROBS;
     __shared__ float m_lds[A < 8 ? 8 : A];
     __shared__ float scr[64];
     __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
     __shared__ float pi_lds[LOGITS ? A : 1];
+    __shared__ float lg_lds[MODE == IN_FEATURES ? A + 4 : 1];                // (features: the logits this launch computes itself)
     __shared__ unsigned long long less_lds[64];
     __shared__ int flags[3];                                                 // 0: priors written, 1: shuffle masks ready, 2: sticky error seen
     const int slot = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -478,6 +579,12 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     if (wave == 1) {                                                         // ---- what the walk will need
         if (has_policy) {
             const float *pi = policy + (size_t)row * ld;
+            if constexpr (MODE == IN_FEATURES) {
+                const _Float16 *feat = reinterpret_cast<const _Float16 *>(policy) + (size_t)row * 2 * hd.fk;
+                leaf_policy_logits<G>(hd, nodes, hr.leaf_fc, hr.leaf_k, feat, lg_lds, lane);
+                wave_sync();
+                pi = lg_lds;
+            }
             if constexpr (LOGITS) { policy_softmax_row(pi, lane, A, pi_lds); wave_sync(); pi = pi_lds; }
             backup_policy<G>(ev, slot, hr, nodes, pi, m_lds, scr, lane);
         }
@@ -492,7 +599,16 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     }
     typename G::S st = G::load(&ev.states[slot], lane);                      // ---- the walk
     float val[NV];
-    if constexpr (LOGITS) {
+    if constexpr (MODE == IN_FEATURES) {
+        float pv = 0.f;
+        if (!hr.leaf_e) {                                                    // (a terminal leaf backs its win state up, not the network)
+            leaf_value_logits<G>(hd, reinterpret_cast<const _Float16 *>(policy) + (size_t)row * 2 * hd.fk + hd.fk, lg_lds + A, lane);
+            wave_sync();
+            pv = value_softmax(lg_lds + A, lane, NV);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) val[j] = rl(pv, j);
+    } else if constexpr (LOGITS) {
         const float pv = value_softmax(policy + (size_t)row * ld + A, lane, NV);
 #pragma unroll
         for (int j = 0; j < NV; j++) val[j] = rl(pv, j);

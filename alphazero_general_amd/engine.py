@@ -180,6 +180,23 @@ class DeviceEngine:
         _abi.check(self.L.azg_backup_select_logits(self.h, _stream(), _ptr(logits), int(logits.shape[1]), _ptr(row_of_slot), flags,
                                                    _ptr(obs), dt, int(bool(select))))
 
+    def backup_select_features(self, feat, head_rows, head_b, obs=None, row_of_slot=None, select=True, add_root_noise=None,
+                               add_root_temp=None):
+        """backup fed with the head FEATURES of a factorised-heads network (rows [rows, 2 * feat_k] fp16): the launch computes the
+        value logits and the policy logits of every leaf's valid actions itself (head_rows fp16 [A + P + 1, feat_k], head_b f32),
+        optionally followed by the next simulation's select(obs)."""
+        assert feat.is_cuda and feat.dtype == torch.float16 and feat.is_contiguous() and feat.shape[1] % 2 == 0
+        fk = feat.shape[1] // 2
+        assert head_rows.is_cuda and head_rows.dtype == torch.float16 and head_rows.is_contiguous() and tuple(head_rows.shape) == (self.A + self.NV, fk)
+        assert head_b.is_cuda and head_b.dtype == torch.float32 and head_b.numel() >= self.A + self.NV
+        flags = -1 if add_root_noise is None and add_root_temp is None else (int(bool(add_root_noise)) | 2 * int(bool(add_root_temp)))
+        dt = 0
+        if obs is not None:
+            assert obs.is_cuda and obs.is_contiguous()
+            dt = 2 if obs.dim() == 3 else {torch.float32: 0, torch.float16: 1}[obs.dtype]
+        _abi.check(self.L.azg_backup_select_features(self.h, _stream(), _ptr(feat), int(fk), _ptr(head_rows), _ptr(head_b), _ptr(row_of_slot),
+                                                     flags, _ptr(obs), dt, int(bool(select))))
+
     def advance(self, record_history=True):
         _abi.check(self.L.azg_advance(self.h, _stream(), int(bool(record_history))))
 

@@ -298,6 +298,9 @@ class HipResNet:
                 self.head2_wp, self.head2_wv = frag(w2p, OSP), frag(w2v, 1)
                 self.head2_b = torch.zeros(OS * 16, **f32)
                 self.head2_b[:A] = bp; self.head2_b[A:A + NV] = bv
+                # the same chains one ROW per output (policy outputs over the policy features, then the value outputs over the
+                # value features): what the tree launch reads when it computes only the logits it needs (sparse heads)
+                self.head_rows = torch.cat([w2p[:, :A].t(), w2v[:, :NV].t()]).to(self.device, torch.float16).contiguous()
         self._bufs = {}
 
     @property
@@ -364,6 +367,21 @@ class HipResNet:
                                                       null if logits_only else vp(val)))
         return ws if logits_only else (pol, val)
 
+    def forward_features_nhwc8(self, x, key=0):
+        """Factorised-heads networks only: x [B, H*W, 8] fp16 -> head features [B, 2 * feat_k] fp16 (tower + the two 1x1 head
+        convolutions, ONE launch), for DeviceEngine.backup_select_features, which applies the collapsed Linear chains itself --
+        only to the valid actions of every leaf."""
+        assert self.fact_head
+        import ctypes as C
+        vp = lambda q: C.c_void_p(q.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B = x.shape[0]
+        feat = self._scratch('feat', key, B, lambda n: (torch.zeros((n, 2 * self.feat_k), dtype=torch.float16, device=self.device),))[0][:B]
+        self._check(self.L.azg_resnet_tower_features_f16(st, self.game, vp(x), vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps),
+                                                         vp(self.tower_pt), int(B), len(self.blocks), int(self.CH), vp(self.head1_w),
+                                                         vp(self.head1_b), vp(feat), int(self.feat_k)))
+        return feat
+
     @property
     def can_search(self):
         """a persistent search launch exists for this network: connect4 x 128 channels with fused heads (azg_search_f16), or
@@ -384,8 +402,8 @@ class HipResNet:
                                               len(self.blocks), vp(self.head_w_packed), vp(self.head_b16), int(sims)))
         else:
             self._check(self.L.azg_search_wide_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
-                                                   len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head2_wp),
-                                                   vp(self.head2_wv), vp(self.head2_b), int(self.feat_k), int(sims)))
+                                                   len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head_rows),
+                                                   vp(self.head2_b), int(self.feat_k), int(sims)))
 
     @staticmethod
     def forward_models(nets, x_all, policy_all, value_all, rows_per_model):
@@ -421,6 +439,7 @@ class CapturedNet:
     def __init__(self, graph, x, policy, value, run=None):
         self.graph, self.x, self.policy, self.value = graph, x, policy, value
         self.run_logits = None
+        self.run_features = None        # factorised heads: -> (features, head rows, head bias) for backup_select_features
         self.run = run                   # the same evaluation as plain launches on the current stream -> (policy, value); lets a
                                          # caller capture it inside a larger graph (selfplay: a whole round of simulations)
 
@@ -522,6 +541,8 @@ class NNetWrapper:
         cn = CapturedNet(g, x, p, v, run)
         if self._hip is not None and self._hip.wide_head:
             cn.run_logits = lambda: self._hip.forward_logits_nhwc8(x, key)   # stops at the logits (softmax inside the tree launch)
+            if self._hip.fact_head:                                  # stops at the head features (sparse heads inside the tree launch)
+                cn.run_features = lambda: (self._hip.forward_features_nhwc8(x, key), self._hip.head_rows, self._hip.head2_b)
         return cn
 
     @property

@@ -138,7 +138,12 @@ class SelfPlayRunner:
             return
         e.select(ln.obs)
         logits_path = not self.warmup and ln.net.run_logits is not None    # wide heads: softmax inside the tree launch
+        feat_path = not self.warmup and getattr(ln.net, 'run_features', None) is not None   # factorised: the heads too
         for i in range(sims):                                    # backup k and select k + 1 share a launch
+            if feat_path:
+                feat, rows, hb = ln.net.run_features()
+                e.backup_select_features(feat, rows, hb, ln.obs, select=i + 1 < sims)
+                continue
             if logits_path:
                 e.backup_select_logits(ln.net.run_logits(), ln.obs, select=i + 1 < sims)
                 continue

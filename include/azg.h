@@ -150,6 +150,17 @@ int  azg_backup_select(azg_engine *e, void *stream, const float *policy_dev, con
  * fills; the two softmaxes of NNetArchitecture.py:112-118 run inside this launch.  Same results as softmax + azg_backup. */
 int  azg_backup_select_logits(azg_engine *e, void *stream, const float *logits_dev, int logits_stride,
                               const int32_t *row_of_slot_dev, int flags, void *obs_dev, int obs_dtype, int do_select);
+/* The same fed with the head FEATURES of a factorised-heads network: row r of feat_dev holds fp16 [2][feat_k] -- the 16 policy-
+ * head and 16 value-head channels per pixel that azg_resnet_tower_features_f16 stores (index pixel * 16 + channel, zero padded
+ * to feat_k = ceil(H*W*16 / 32) * 32).  The launch applies the collapsed Linear chains (NNetArchitecture.py:92-102) itself, and
+ * only where process_results looks: the P+1 value logits and the policy logits of the leaf's VALID actions (the reference
+ * masks and renormalises the policy, MCTS.pyx:239-245, so the other A - k logits never reach the tree; brandubh: ~40 rows of
+ * the 588).  head_rows_dev: fp16 [A + P + 1][feat_k], row o = output o's weights over the policy (o < A) or value features;
+ * head_b_dev: f32 [A + P + 1].  Priors equal softmax-over-all-A + mask + renormalise up to rounding (the full normaliser
+ * cancels): ~1e-7 relative, not bit-identical to azg_backup_select_logits. */
+int  azg_backup_select_features(azg_engine *e, void *stream, const void *feat_dev, int feat_k, const void *head_rows_dev,
+                                const float *head_b_dev, const int32_t *row_of_slot_dev, int flags, void *obs_dev, int obs_dtype,
+                                int do_select);
 #define AZG_FLAGS_DEFAULT (-1)   /* use azg_config.add_root_noise / add_root_temp                          */
 #define AZG_FLAG_NOISE 1          /* process_results(..., add_root_noise, add_root_temp) per call (:230)    */
 #define AZG_FLAG_TEMP  2
@@ -243,15 +254,13 @@ int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const
 
 /* The same for networks with FACTORISED heads (wide action spaces): brandubh x 64 channels (two games per workgroup) and the
  * 3-player env x 32 channels.  Per workgroup and simulation: wavefront b walks game b's tree and its partner wavefront prepares
- * the priors and the shuffle (azg_backup_select_logits' code), the tower runs on the leaf planes left in LDS, the 1x1 head
- * convolutions leave their features in LDS and the workgroup's wavefronts turn them into logits with
- * azg_policy_value_heads_fact_f16's accumulation chains.  Results are identical to `sims` x [azg_select /
- * azg_backup_select_logits, azg_resnet_tower_features_f16, azg_policy_value_heads_fact_f16 (logits only)] + a final
- * azg_backup_select_logits without select.  Parameters as those two functions take them; sims == 0: one-time setup only. */
+ * the priors and the shuffle, the tower runs on the leaf planes left in LDS, the 1x1 head convolutions leave their features in
+ * LDS, and the next tree phase computes the logits it needs from them (azg_backup_select_features' code).  Results are
+ * identical to `sims` x [azg_select / azg_backup_select_features, azg_resnet_tower_features_f16] + a final
+ * azg_backup_select_features without select.  Parameters as those two functions take them; sims == 0: one-time setup only. */
 int  azg_search_wide_f16(azg_engine *e, void *stream, const void *w_packed_dev, const float *bias_dev, const float *pre_scale_dev,
                          const float *pre_shift_dev, int nblocks, int channels, const void *head1_w_packed_dev,
-                         const float *head1_b_dev, const void *head2_wp_packed_dev, const void *head2_wv_packed_dev,
-                         const float *head2_b_dev, int feat_k, int sims);
+                         const float *head1_b_dev, const void *head_rows_dev, const float *head_b_dev, int feat_k, int sims);
 
 /* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same
  * [k = H*W*C, A+NV] matrix applied to the final stream y [boards, k] fp16 that azg_resnet_tower_f16 stores, then the

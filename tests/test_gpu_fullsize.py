@@ -209,10 +209,10 @@ def test_brandubh_4096_games_fit_one_gpu():
 @pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200)])
 def test_wide_search_launch_equals_phase_launches(game, B, sims):
     """azg_search_wide_f16 (networks with factorised heads: tree walk by two wavefronts per game, tower, head convolutions and the
-    logits GEMM all inside one persistent launch) against the launch-per-phase path -- azg_select / azg_backup_select_logits,
-    azg_resnet_tower_features_f16, azg_policy_value_heads_fact_f16 -- on a twin engine: the logits are bit-identical by
-    construction (same accumulation chains), so trees, moves, tape counters and samples must be identical.  The last case is
-    BASELINE config 3's per-GPU size."""
+    sparse heads all inside one persistent launch) against the launch-per-phase path -- azg_select / azg_backup_select_features,
+    azg_resnet_tower_features_f16 -- on a twin engine: the logits are bit-identical by construction (the same dot products in the
+    same order), so trees, moves, tape counters and samples must be identical.  The last case is BASELINE config 3's per-GPU
+    size."""
     import importlib
     import torch
     from alphazero_general_amd import nnet as N
@@ -234,7 +234,7 @@ def test_wide_search_launch_equals_phase_launches(game, B, sims):
         hip.search(ea, sims)
         eb.select(obs)
         for s in range(sims):
-            eb.backup_select_logits(hip.forward_logits_nhwc8(obs), obs, select=s + 1 < sims)
+            eb.backup_select_features(hip.forward_features_nhwc8(obs), hip.head_rows, hip.head2_b, obs, select=s + 1 < sims)
         assert torch.equal(ea.root_counts(), eb.root_counts()), move
         assert torch.equal(ea.root_probs(1.0), eb.root_probs(1.0))
         assert torch.equal(ea.root_value(True), eb.root_value(True))
@@ -245,3 +245,51 @@ def test_wide_search_launch_equals_phase_launches(game, B, sims):
     assert a == b and a['sims'] == B * sims * moves
     for x, y in zip(ea.examples(), eb.examples()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('game,B', [('brandubh', 96), ('trimok', 64)])
+def test_sparse_heads_equal_full_heads_on_the_valid_actions(game, B):
+    """azg_backup_select_features computes, inside the tree launch, only the logits process_results uses: the value logits and
+    the policy logits of the leaf's valid actions.  Against the full-width path (azg_policy_value_heads_fact_f16 -> all A logits ->
+    azg_backup_select_logits: softmax over all A, mask, renormalise) on a twin engine fed the SAME leaves, the priors written
+    to the new children must agree to rounding (the full softmax's normaliser cancels in the renormalisation) and every value
+    backed up likewise; recorded beside the network errors in gpurun_out/nn_error.jsonl."""
+    import importlib
+    import json
+    import os
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.engine import DeviceEngine
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    torch.manual_seed(33)
+    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    net.refresh()
+    hip = net._hip
+    assert hip.fact_head
+    kw = dict(cpuct=1.25, fpu_reduction=0.2, add_root_noise=False, add_root_temp=False, seed=9, games_per_iteration=1 << 30, sims_hint=8)
+    ea, eb = DeviceEngine(Game.AZG_GAME_ID, B, **kw), DeviceEngine(Game.AZG_GAME_ID, B, **kw)
+    hw = Game.observation_size()[1] * Game.observation_size()[2]
+    oa = torch.zeros((B, hw, 8), dtype=torch.float16, device=ea.device); ob = torch.zeros_like(oa)
+    worst_p = worst_q = 0.0
+    same = np.ones(B, bool)              # slots whose two trees still see the same leaves (a prior that differs in the last bit can
+    for move in range(6):                #  flip a PUCT near-tie; such a slot is dropped from the comparison from then on)
+        ea.select(oa); eb.select(ob)
+        for s in range(8):
+            same &= (oa == ob).reshape(B, -1).all(1).cpu().numpy()
+            ea.backup_select_features(hip.forward_features_nhwc8(oa), hip.head_rows, hip.head2_b, oa, select=s < 7)
+            eb.backup_select_logits(hip.forward_logits_nhwc8(ob), ob, select=s < 7)
+            for slot in np.nonzero(same)[0][::5]:
+                ka, kb = ea.root_children(int(slot)), eb.root_children(int(slot))
+                if not ((ka['a'] == kb['a']).all() and (ka['n'] == kb['n']).all()):
+                    same[slot] = False
+                    continue
+                worst_p = max(worst_p, float(np.abs(ka['p'] - kb['p']).max())); worst_q = max(worst_q, float(np.abs(ka['q'] - kb['q']).max()))
+        same &= (ea.root_counts() == eb.root_counts()).all(1).cpu().numpy()
+        ea.advance(True); eb.advance(True)
+        same &= (ea.last_actions() == eb.last_actions()).cpu().numpy()
+    assert same.mean() > 0.9, same.mean()
+    assert worst_p < 2e-6 and worst_q < 2e-5, (worst_p, worst_q)
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/nn_error.jsonl', 'a') as fh:
+        fh.write(json.dumps({'test': 'sparse_vs_full_heads_' + game, 'boards': B, 'max_abs_prior': worst_p, 'max_abs_q': worst_q,
+                             'slots_never_diverged': float(same.mean()), 'tolerance': 2e-6}) + '\n')
