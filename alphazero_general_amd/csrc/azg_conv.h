@@ -550,21 +550,37 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                         });
                     }
                 }
-            } else if (livegame && sim > 0) {                        // the helper: priors of the previous leaf, shuffle of the next expansion
+            } else if (livegame && sim > 0) {                        // the helper: shuffle of the next expansion, priors of the previous leaf
+#ifdef AZG_TOWER_TIMING
+                unsigned long long ht_[6] = {wt_[0], 0, 0, 0, 0, 0};
+#define AZG_HSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ht_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZG_HSTAMP(i) do { } while (0)
+#endif
+                AZG_HSTAMP(1);
+                if (sim < sa.sims) {                                 // (masks first: every expansion waits for them, see k_backup_select2)
+                    reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+                    flag_set_gen(&flags[1], sim, lane);
+                }
+                AZG_HSTAMP(2);
                 if (has_policy) {
                     Node *nodes = tree_nodes(sa.ev, tree, hr.base);
                     float *pi = reinterpret_cast<float *>(ws + WS::PI);
                     leaf_policy_logits<G>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
                     wave_sync();
+                    AZG_HSTAMP(3);
                     policy_softmax_row(lg, lane, A, pi);
                     wave_sync();
+                    AZG_HSTAMP(4);
                     backup_policy<G>(sa.ev, slot, hr, nodes, pi, reinterpret_cast<float *>(ws + WS::M), reinterpret_cast<float *>(ws + WS::SCR), lane);
+                    AZG_HSTAMP(5);
                 }
                 flag_set_gen(&flags[0], sim, lane);
-                if (sim < sa.sims) {
-                    reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
-                    flag_set_gen(&flags[1], sim, lane);
-                }
+#ifdef AZG_TOWER_TIMING
+                if (P.dbg && wave == BOARDS && lane == 0 && blockIdx.x < 512 && sim >= 8 && has_policy)   // helper of board 0: header, masks, logits, softmax, priors
+                    for (int i = 0; i < 5; i++) P.dbg[2048 + 4096 * 5 + (size_t)blockIdx.x * 8 + i] += ht_[i + 1] - ht_[i];
+                if (P.dbg && wave == BOARDS && lane == 0 && blockIdx.x < 512 && sim >= 8 && has_policy) P.dbg[2048 + 4096 * 5 + (size_t)blockIdx.x * 8 + 5] += 1;
+#endif
             } else if (role == 0 && lane < HW) {                     // no game behind this board: zero planes
                 char *row = img + GEO::qrow(bd * HW + lane) * RS;
                 const uint4 z = make_uint4(0, 0, 0, 0);

@@ -55,11 +55,6 @@ enum { LEAF_IS_ROOT = -1 };
 // backup is pure stores.
 struct __attribute__((aligned(16))) PathEnt { uint32_t idx_mover; int32_t n; float q; uint32_t pad; };
 
-struct SumPlan {           // numpy float32 pairwise-sum structure for a length-n array (see np_sum_wave)
-    int32_t n, nleaves, nprog, pad;
-    int16_t leaf_off[64], leaf_len[64];
-    uint8_t prog[128];     // 0 = push next leaf sum, 1 = add top two
-};
 
 // Engine view passed by value to every kernel.
 struct View {
@@ -82,7 +77,7 @@ struct View {
     int32_t  *gcount;      // [8]: 0 games_played, 1 num_results, 2 num_examples, 3 error, 4 max_nodes, 5 max nodes kept by a compaction
     float    *ex_obs, *ex_pi, *ex_z;  // examples
     uint8_t  *res_ws; int32_t *res_turns, *res_slot;
-    const float *temp_table; const SumPlan *plan;
+    const float *temp_table;
     int32_t B, T, cap, maxd, arena, ex_cap, res_cap, temp_len, compact_reserve;
     int32_t add_noise, add_temp, symmetric, reset_thr, games_cap, max_hist;
     float cpuct, fpu_reduction, noise_frac, root_temp, arena_temp;
@@ -236,37 +231,59 @@ AZG_DEV float np_pow_f32(float x, double e) {
     return (float)pow((double)x, (double)(float)e);
 }
 
-// numpy float32 pairwise np.sum over m[0..n) held in LDS, evaluated cooperatively by one wave with exactly
-// numpy's association order (loops_utils.h.src @TYPE@_pairwise_sum, PW_BLOCKSIZE 128): 8 strided accumulators per
-// <=128-element block, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail sequential, blocks combined by the
-// recursion tree encoded in `plan`.  Every lane returns the sum.  `scr` = 64 floats of LDS scratch.
-AZG_DEV float np_sum_wave(const float *m, const SumPlan *plan, float *scr, int lane) {
-    const int n = plan->n;
-    if (n < 8) {
-        float res = 0.f;
-        for (int i = 0; i < n; i++) res += m[i];
-        return res;
+// numpy float32 pairwise np.sum over m[0..N) held in LDS, evaluated cooperatively by one wave with exactly numpy's association
+// order (loops_utils.h.src @TYPE@_pairwise_sum, PW_BLOCKSIZE 128): 8 strided accumulators per <=128-element block, combined
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail sequential, blocks combined by the recursion tree.  Every lane returns the sum.
+// `scr` = 64 floats of LDS scratch.  The plan (leaf offsets / lengths, combine program) is worked out at compile time from the
+// length -- every caller sums a policy-sized vector, N = A -- so the offsets are immediates, the up-to-16 strided reads of a
+// leaf are issued together and the combine program runs on registers (a plan read from HBM cost a chain of ~15 dependent scalar
+// loads: ~6 k cycles for N = 588).
+template <int N> struct NpPlan {
+    int nleaves = 0, nprog = 0, off[64] = {}, len[64] = {};
+    unsigned char prog[128] = {};
+    constexpr void rec(int o, int n) {
+        if (n <= 128) { off[nleaves] = o; len[nleaves] = n; nleaves++; prog[nprog++] = 0; return; }
+        int n2 = n / 2; n2 -= n2 % 8;
+        rec(o, n2); rec(o + n2, n - n2);
+        prog[nprog++] = 1;
     }
-    const int nl = plan->nleaves, g = lane >> 3, j = lane & 7;
-    for (int l0 = 0; l0 < nl; l0 += 8) {
-        int l = l0 + g;
-        float res = 0.f;
+    constexpr NpPlan() { rec(0, N); }
+};
+template <int N>
+AZG_DEV float np_sum_static(const float *m, float *scr, int lane) {
+    static_assert(N >= 8, "n < 8 is a sequential sum (callers handle it)");
+    constexpr NpPlan<N> PL{};
+    constexpr int NL = PL.nleaves;
+    static_assert(NL <= 64, "one scratch slot per leaf");
+    const int g = lane >> 3, j = lane & 7;
+#pragma unroll
+    for (int l0 = 0; l0 < NL; l0 += 8) {
         int off = 0, len = 8;
-        if (l < nl) { off = plan->leaf_off[l]; len = plan->leaf_len[l]; }
-        float r = m[off + j];
-        int lim = len - (len & 7);
-        for (int i = 8; i < lim; i += 8) r += m[off + i + j];
-        r = r + __shfl_xor(r, 1);
-        r = r + __shfl_xor(r, 2);
-        r = r + __shfl_xor(r, 4);
-        res = r;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (l0 + q < NL && g == q) { off = PL.off[l0 + q]; len = PL.len[l0 + q]; }
+        const int lim = len - (len & 7);
+        float v[16];                                                         // (a leaf has at most 128 elements: 16 per lane)
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = m[off + min(8 * i, lim - 8) + j];
+        float r = v[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) if (8 * i < lim) r += v[i];
+        r = r + dpp_f<DPP_QUAD_XOR1>(r);
+        r = r + dpp_f<DPP_QUAD_XOR2>(r);
+        r = r + dpp_f<DPP_ROW_HALF_MIRROR>(r);                               // lane j <-> 7 - j of its group of 8: the xor-4 partner's quad
+        float res = r;
         for (int i = lim; i < len; i++) res += m[off + i];
-        if (l < nl && j == 0) scr[l] = res;
+        if (l0 + g < NL && j == 0) scr[l0 + g] = res;
     }
     wave_sync();
-    float st[8]; int sp = 0, li = 0;
-    for (int i = 0; i < plan->nprog; i++) {
-        if (plan->prog[i] == 0) st[sp++] = scr[li++];
+    float lf[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) lf[l] = scr[l];
+    float st[8];
+    int sp = 0, li = 0;
+#pragma unroll
+    for (int i = 0; i < PL.nprog; i++) {
+        if (PL.prog[i] == 0) st[sp++] = lf[li++];
         else { st[sp - 2] = st[sp - 2] + st[sp - 1]; sp--; }
     }
     wave_sync();

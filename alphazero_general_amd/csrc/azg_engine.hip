@@ -69,14 +69,6 @@ extern "C" void azg_tape_shuffle_pos(uint64_t seed, uint64_t stream, uint64_t ct
     }
 }
 
-// numpy pairwise-sum structure for length n (see np_sum_wave)
-static void plan_rec(int off, int n, SumPlan &p) {
-    if (n <= 128) { p.leaf_off[p.nleaves] = (int16_t)off; p.leaf_len[p.nleaves] = (int16_t)n; p.nleaves++; p.prog[p.nprog++] = 0; return; }
-    int n2 = n / 2; n2 -= n2 % 8;
-    plan_rec(off, n2, p); plan_rec(off + n2, n - n2, p);
-    p.prog[p.nprog++] = 1;
-}
-
 template <typename T> static int dalloc(azg_engine *e, T **p, size_t count) {
     void *q = nullptr;
     size_t bytes = count * sizeof(T);
@@ -178,11 +170,6 @@ extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
     float *d_tt; DALLOC(d_tt, tt.size());
     HIPCHK(hipMemcpy(d_tt, tt.data(), tt.size() * sizeof(float), hipMemcpyHostToDevice));
     v.temp_table = d_tt; v.temp_len = (int)tt.size();
-    SumPlan plan; memset(&plan, 0, sizeof(plan)); plan.n = A;
-    if (A >= 8) plan_rec(0, A, plan);
-    SumPlan *d_plan; DALLOC(d_plan, 1);
-    HIPCHK(hipMemcpy(d_plan, &plan, sizeof(plan), hipMemcpyHostToDevice));
-    v.plan = d_plan;
     DALLOC(e->d_p2i, 8); DALLOC(e->d_ok, 4);
 #ifdef AZG_TREE_TIMING
     DALLOC(v.dbg, (size_t)v.B * 16);
@@ -622,6 +609,13 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
             const double n = (double)nb * (sa.sims > 8 ? sa.sims - 8 : 1);
             fprintf(stderr, "wide search, cycles per simulation (mean over %d workgroups): tree %.0f tower %.0f headconv %.0f heads %.0f\n", nb, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
             HIPCHK(hipMemset(dbg + 2048 + 4096 * 4, 0, sizeof(unsigned long long) * 4 * 512));
+            static unsigned long long hw_[512 * 8];
+            HIPCHK(hipMemcpy(hw_, dbg + 2048 + 4096 * 5, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost));
+            double hp[5] = {0, 0, 0, 0, 0}, hn = 0;
+            for (int b = 0; b < nb; b++) { for (int i = 0; i < 5; i++) hp[i] += (double)hw_[b * 8 + i]; hn += (double)hw_[b * 8 + 5]; }
+            if (hn > 0) fprintf(stderr, "  helper wavefront (cycles per simulation with a policy backup): header %.0f masks %.0f logits %.0f softmax %.0f priors %.0f\n",
+                                hp[0] / hn, hp[1] / hn, hp[2] / hn, hp[3] / hn, hp[4] / hn);
+            HIPCHK(hipMemset(dbg + 2048 + 4096 * 5, 0, sizeof(unsigned long long) * 8 * 512));
             calls = 100;
         }
         if (++calls == 8) {

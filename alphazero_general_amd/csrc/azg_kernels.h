@@ -287,7 +287,7 @@ AZG_DEV float masked_sum(const View &ev, const int (&ca)[NC], const float (&cp)[
 #pragma unroll
         for (int c = 0; c < NC; c++) if (ca[c] >= 0) m_lds[ca[c]] = cp[c];
         wave_sync();
-        return np_sum_wave(m_lds, ev.plan, scr, lane);
+        return np_sum_static<A>(m_lds, scr, lane);
     }
 }
 
@@ -466,9 +466,10 @@ struct HeadDot {
     static AZG_DEV void load(hrow8 (&w)[IT], const _Float16 *row, int j16, bool on) {
         const hrow8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < IT; t++) {
-            const int c = j16 + 16 * t;
-            w[t] = (on && c < NCH) ? *reinterpret_cast<const hrow8 *>(row + c * 8) : zero;
+        for (int t = 0; t < IT; t++) {                                      // (unconditional loads of clamped addresses + a select: a
+            const int c = j16 + 16 * t;                                     //  load under a lane predicate becomes a branch, and the
+            const hrow8 v = *reinterpret_cast<const hrow8 *>(row + min(c, NCH - 1) * 8);   // compiler then cannot count the loads in flight)
+            w[t] = (on && c < NCH) ? v : zero;
         }
     }
     static AZG_DEV float dot(const hrow8 (&w)[IT], const _Float16 *feat, int j16) {
@@ -487,7 +488,8 @@ struct HeadDot {
 };
 
 // policy logits of the last leaf's k children (one wavefront): lg[a] for their actions, -inf for every other a < A.  Four
-// children per pass (one per DPP row), the weight rows prefetched DEPTH passes ahead.  feat: the board's policy features.
+// children per pass (one per DPP row), the weight rows prefetched DEPTH passes ahead.  feat: the board's policy features, IN LDS
+// (a global read between the passes would drain the prefetches: vmcnt waits in order).
 template <class G>
 AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, int k, const _Float16 *feat, float *lg, int lane) {
     constexpr int A = G::A, FK = head_fk<G>(), DEPTH = 4;
@@ -500,7 +502,8 @@ AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, i
     const int r = lane >> 4, j16 = lane & 15, npass = (k + 3) >> 2;
     hrow8 w[DEPTH][HD::IT];
     int act[DEPTH];
-    auto issue = [&](int d, int p) {
+    float bias[DEPTH];                                                       // (fetched with the rows: a load issued at the point of use
+    auto issue = [&](int d, int p) {                                         //  would make the in-order vmcnt wait drain the prefetches)
         const int i = 4 * p + r;
         int a = 0;
 #pragma unroll
@@ -509,19 +512,20 @@ AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, i
             if ((i >> 6) == c) a = v;
         }
         act[d] = a;
+        bias[d] = hd.bias[a];
         HD::load(w[d], hd.rows + (size_t)a * hd.fk, j16, i < k);
     };
+    // branch-free body (passes past the end load nothing and store nothing: lane predicates only), so that the compiler can
+    // count the loads in flight and wait for exactly the oldest pass (vmcnt(n), not a drain)
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) if (d < npass) issue(d, d);
+    for (int d = 0; d < DEPTH; d++) issue(d, d);
     for (int p0 = 0; p0 < npass; p0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
             const int p = p0 + d;
-            if (p < npass) {
-                const float x = HD::dot(w[d], feat, j16);
-                if (j16 == 0 && 4 * p + r < k) lg[act[d]] = x + hd.bias[act[d]];
-                if (p + DEPTH < npass) issue(d, p + DEPTH);
-            }
+            const float x = HD::dot(w[d], feat, j16);
+            if (j16 == 0 && 4 * p + r < k) lg[act[d]] = x + bias[d];
+            issue(d, p + DEPTH);
         }
     }
 }
@@ -560,6 +564,7 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     __shared__ int act_lds[((G::MAXK + 63) / 64) * 64];
     __shared__ float pi_lds[LOGITS ? A : 1];
     __shared__ float lg_lds[MODE == IN_FEATURES ? A + 4 : 1];                // (features: the logits this launch computes itself)
+    __shared__ __attribute__((aligned(16))) _Float16 feat_lds[MODE == IN_FEATURES ? head_fk<G>() : 8];   // the board's policy features
     __shared__ unsigned long long less_lds[64];
     __shared__ int flags[3];                                                 // 0: priors written, 1: shuffle masks ready, 2: sticky error seen
     const int slot = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -577,11 +582,20 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     __syncthreads();
     if (flags[2] != 0) return;                                               // sticky device error: stop touching the trees
     if (wave == 1) {                                                         // ---- what the walk will need
+        // (computing the logits takes longer than a typical descent: in that mode the shuffle masks, which every expansion waits
+        //  for, go first, and the priors, which only a descent through the previous leaf waits for, second)
+        constexpr bool MASKS_FIRST = MODE == IN_FEATURES;
+        if (MASKS_FIRST && do_select) {
+            less_lds[lane] = shuffle_less_mask(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+            flag_set_gen(&flags[1], 1, lane);
+        }
         if (has_policy) {
             const float *pi = policy + (size_t)row * ld;
             if constexpr (MODE == IN_FEATURES) {
-                const _Float16 *feat = reinterpret_cast<const _Float16 *>(policy) + (size_t)row * 2 * hd.fk;
-                leaf_policy_logits<G>(hd, nodes, hr.leaf_fc, hr.leaf_k, feat, lg_lds, lane);
+                const uint4 *feat = reinterpret_cast<const uint4 *>(reinterpret_cast<const _Float16 *>(policy) + (size_t)row * 2 * hd.fk);
+                for (int c = lane; c < head_fk<G>() / 8; c += 64) reinterpret_cast<uint4 *>(feat_lds)[c] = feat[c];
+                wave_sync();
+                leaf_policy_logits<G>(hd, nodes, hr.leaf_fc, hr.leaf_k, feat_lds, lg_lds, lane);
                 wave_sync();
                 pi = lg_lds;
             }
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
         }
         flag_set_gen(&flags[0], 1, lane);
         AZG_TSTAMP(ev, slot, lane, 9);
-        if (do_select) {
+        if (!MASKS_FIRST && do_select) {
             less_lds[lane] = shuffle_less_mask(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
             flag_set_gen(&flags[1], 1, lane);
         }
@@ -658,13 +672,13 @@ AZG_DEV void root_probs(const View &ev, const Node *nodes, int root_fc, int root
     }
     float s;
     if constexpr (A < 8) { s = 0.f; for (int a = 0; a < A; a++) s += cnt[a]; }
-    else s = np_sum_wave(cnt, ev.plan, scr, lane);
+    else s = np_sum_static<A>(cnt, scr, lane);
     const double ex = 1.0 / (double)temp;
     for (int a = lane; a < A; a += 64) pr[a] = np_pow_f32(cnt[a] / s, ex);    // :320
     wave_sync();
     float s2;
     if constexpr (A < 8) { s2 = 0.f; for (int a = 0; a < A; a++) s2 += pr[a]; }
-    else s2 = np_sum_wave(pr, ev.plan, scr, lane);
+    else s2 = np_sum_static<A>(pr, scr, lane);
     for (int a = lane; a < A; a += 64) pr[a] = pr[a] / s2;                    // :321
     wave_sync();
 }
