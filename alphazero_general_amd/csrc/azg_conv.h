@@ -213,11 +213,11 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_heads(const _Float16 *y, co
 
 // Second stage of the factorised heads (NNetArchitecture.py:90-93,99-102, the Linear chains collapsed: they have no activation):
 // policy logits from the 16 policy channels of every pixel, value logits from the 16 value channels.  One output subtile (16
-// outputs) of 16 boards = FOUR MFMA accumulation chains, one per contiguous quarter of the k-steps, summed as
-// (q0 + q1) + (q2 + q3): a fixed association that the persistent search kernel reproduces (four accumulators per subtile), so
-// both paths give bit-identical logits.  `afrag(ks)` delivers the A operand (16 boards x 32 features: global feature rows here,
-// LDS there), wl this lane's weight fragments (`wstride` half8 from one k-step to the next).  The loads of a chain are issued in
-// batches of HEADF_U k-steps, branch-free (k-steps past the end re-read the last one with the A fragment zeroed).
+// outputs) of 16 boards = FOUR MFMA accumulation chains, one per contiguous quarter of the k-steps (one wavefront each),
+// summed as (q0 + q1) + (q2 + q3).  This is the full-width path behind NNetWrapper.process; the search loop computes only the
+// logits it uses (sparse heads, azg_kernels.h).  `afrag(ks)` delivers the A operand (16 boards x 32 features from the global
+// feature rows), wl this lane's weight fragments (`wstride` half8 from one k-step to the next).  The loads of a chain are issued
+// in batches of HEADF_U k-steps, branch-free (k-steps past the end re-read the last one with the A fragment zeroed).
 constexpr int HEADF_U = 7, HEADF_Q = 4, HEADF_NS = 5;            // k-steps per load batch, K quarters, subtiles per wavefront
 // NS chains at once (they share the A fragments): acc[s] += sum over k-steps [k_begin, k_end) of afrag(ks) x wl[ks * wstride + soff[s]]
 template <int NS, class AF>

@@ -72,17 +72,21 @@ def net_flops_per_leaf(game_cls, a):
     return float(f)
 
 
-def tree_bytes_per_sim(game_cls, W):
+def tree_bytes_per_sim(game_cls, W, feat_k=None):
     """Algorithmic bytes one simulation moves through the tree launch (SURVEY.md 8d formula with this build's 32-byte node records,
     64-byte tree header, 16-byte path entries): find_leaf = header + D child blocks read + one child block written + root and leaf
     state (2 x 80) + the fp16 NHWC8 observation + D path entries; process_results = header + policy and value row + k priors
-    written + D x (path entry read + (n, q) written)."""
+    written + D x (path entry read + (n, q) written).  feat_k: the launch is fed head features and computes its logits itself
+    (sparse heads): the row it reads is the board's fp16 [2][feat_k] features instead of A + P+1 logits; the head matrix
+    (A + P+1 rows of feat_k halves, shared by every board of the launch) is returned separately, counted once per launch."""
     k, Dp = W['kbar'], W['depth']
     C, H, Wd = game_cls.observation_size()
     A, NV = game_cls.action_size(), game_cls.num_players() + 1
     select = 64 + Dp * k * 32 + (32 + k * 32) + 2 * 80 + H * Wd * 16 + Dp * 16
-    backup = 64 + 4 * (A + NV) + 4 * k + k * 2 + Dp * (16 + 8) + 12
-    return select, backup
+    row = 4 * (A + NV) if feat_k is None else 2 * feat_k * 2
+    backup = 64 + row + 4 * k + k * 2 + Dp * (16 + 8) + 12
+    shared = 0 if feat_k is None else (A + NV) * (feat_k * 2 + 4)
+    return select, backup, shared
 
 
 def load_json(path):
@@ -351,13 +355,16 @@ def main():
         roof_net['heads_launch_us'] = round(netprof['heads_ms'] * 1e3 / netprof['heads_n'], 2)
     roof_tree = None
     if prof is not None and prof['backup_n'] > 0:
-        sel_b, bak_b = tree_bytes_per_sim(Game, W)
+        feat_k = net._hip.feat_k if (not arena and net._hip is not None and net._hip.fact_head) else None
+        sel_b, bak_b, shared_b = tree_bytes_per_sim(Game, W, feat_k)
         us = prof['backup_ms'] * 1e3 / prof['backup_n']              # backup k + select k + 1 share a launch
-        gbs = (sel_b + bak_b) * Bl / (us * 1e-6) / 1e9
+        gbs = ((sel_b + bak_b) * Bl + shared_b) / (us * 1e-6) / 1e9
         traffic, src = measured_traffic(a.workload, 'k_backup_select2')
-        roof_tree = {'kernel': 'k_backup_select2 (process_results of simulation k + find_leaf of k + 1, two wavefronts per tree)',
+        roof_tree = {'kernel': 'k_backup_select2 (process_results of simulation k + find_leaf of k + 1, two wavefronts per tree%s)'
+                               % (', sparse heads on the head features' if feat_k else ''),
                      'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 6),
-                     'avg_launch_us': round(us, 2), 'launches_timed': prof['backup_n'], 'algorithmic_bytes_per_launch': (sel_b + bak_b) * Bl,
+                     'avg_launch_us': round(us, 2), 'launches_timed': prof['backup_n'],
+                     'algorithmic_bytes_per_launch': (sel_b + bak_b) * Bl + shared_b,
                      'traffic': traffic, 'traffic_source': src,
                      'advance_us': round(prof['advance_ms'] * 1e3 / max(prof['advance_n'], 1), 1)}
     # the dominant kernel of a simulation step: the persistent search launch if that is what ran, else the longer of the two launches
