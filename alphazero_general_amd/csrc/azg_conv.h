@@ -119,7 +119,7 @@ struct TowerGeom {
 // host: pixel index for (subtile, lane&15), -1 = spare lane.  Within a border class (see TowerGeom), 8-lane set k = k-th
 // pixel of every residue class.
 template <class GEO>
-static void tower_pixmap(int16_t *map /*[NSUB*16]*/) {
+static bool tower_pixmap(int16_t *map /*[NSUB*16]*/) {          // false: a class did not fit its subtiles (cannot happen: CLASSES checks the counts)
     static const int setA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, setB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
     for (int i = 0; i < GEO::NSUB * 16; i++) map[i] = -1;
     for (int c = 0; c < GEO::CLASSES; c++) {
@@ -137,9 +137,10 @@ static void tower_pixmap(int16_t *map /*[NSUB*16]*/) {
             while (used[r] < cnt[r]) {
                 bool placed = false;
                 for (int i = s0 * 16; i < s1 * 16 && used[r] < cnt[r]; i++) if (map[i] < 0) { map[i] = (int16_t)cls[r][used[r]++]; placed = true; }
-                if (!placed) abort();                           // (CLASSES guarantees the room; unreachable)
+                if (!placed) return false;
             }
     }
+    return true;
 }
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));

@@ -581,7 +581,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
         std::lock_guard<std::mutex> lk(d_map_mu);
         if (!d_map[dev]) {
             int16_t map[GEO::NSUB * 16];
-            tower_pixmap<GEO>(map);
+            if (!tower_pixmap<GEO>(map)) return fail(AZG_E_INTERNAL, "tower pixel map does not fit its subtiles");
             int16_t *d = nullptr;
             HIPCHK(hipMalloc((void **)&d, sizeof(map)));
             HIPCHK(hipMemcpy(d, map, sizeof(map), hipMemcpyHostToDevice));
@@ -860,7 +860,7 @@ extern "C" int azg_policy_value_heads_fact_f16(void *stream, const void *feat, c
 template <int H, int W, int BOARDS, int C>
 static int tower_layout_of(int16_t *map, int32_t *qrow, int32_t *info) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
-    if (map) tower_pixmap<GEO>(map);
+    if (map && !tower_pixmap<GEO>(map)) return fail(AZG_E_INTERNAL, "tower pixel map does not fit its subtiles");
     if (qrow) for (int p = 0; p < GEO::ROWS; p++) qrow[p] = GEO::qrow(p);
     info[0] = GEO::NSUB; info[1] = GEO::ROWS; info[2] = GEO::RSTRIDE; info[3] = GEO::TROWS; info[4] = GEO::TILE; info[5] = GEO::PW;
     info[6] = GEO::LEAD; info[7] = GEO::BSTRIDE;
