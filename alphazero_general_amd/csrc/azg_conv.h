@@ -301,13 +301,60 @@ struct FragOff {                                             // LDS immediate of
 
 // weight ring depth: a k-step of a small tile (NSUB <= 4: 6-8 MFMAs) is far shorter than an L2 round trip, so the small
 // shapes fetch 8 k-steps ahead; the big ones (22 MFMAs per k-step, registers scarce) one or two.  Every layer after the stem
-// must advance the ring by whole turns (9 * KS k-steps), so that it always starts at slot 9 % N (the stem's 9 k-steps):
-// N = 9 for small tiles, 2 for even KS, 3 for odd KS (32 channels).
+// must advance the ring by whole turns (9 * KS k-steps), so that it always starts at slot STEM_KSTEPS % N (the stem's 3
+// k-steps): N = 9 for small tiles, 2 for even KS, 3 for odd KS (32 channels).
 template <int NSUB, int KS> struct WeightRing { static constexpr int N = NSUB <= 4 ? 9 : (KS % 2 ? 3 : 2); };
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {            // f(integral_constant<int, I>) for I in [0, N): indices usable as
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }   // immediates and in if constexpr
+}
+
+// The stem convolution.  Its input has 8 channels per pixel -- ONE 16-byte chunk of the row -- so a k-step of 32 holds FOUR taps:
+// lane group g reads chunk 0 of the row of tap 4 * kk + g (weights packed to match, nnet.pack_stem_weight; the three slots past
+// tap 8 carry zero weights and re-read the centre).  3 k-steps instead of 9 one-eighth-full ones.  The weight ring runs on as in
+// conv_main2 (slot kk, prefetch WR - 1 k-steps ahead into the next layer).
+constexpr int STEM_KSTEPS = 3;
+template <class GEO, int NSUB, int WR>
+__device__ __forceinline__ void conv_stem(const char *in, const unsigned (&lb)[NSUB], int g, const half8 *wfrag, half8 (&a)[WR][2],
+                                          floatx4 (&acc)[2][NSUB]) {
+    unsigned soff[STEM_KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < STEM_KSTEPS; kk++) {
+        const int t = 4 * kk + g, tap = t < 9 ? t : 4;
+        soff[kk] = (unsigned)(GEO::BIAS + ((tap / 3 - 1) * GEO::PW + (tap % 3 - 1)) * GEO::RSTRIDE - g * 16);   // (lb carries + g * 16)
+    }
+    if constexpr (NSUB <= 4) {                                  // small tiles (one wave per SIMD, registers to spare): every read first
+        half8 b[STEM_KSTEPS][NSUB];
+#pragma unroll
+        for (int kk = 0; kk < STEM_KSTEPS; kk++)
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) b[kk][ps] = *reinterpret_cast<const half8 *>(in + lb[ps] + soff[kk]);
+#pragma unroll
+        for (int kk = 0; kk < STEM_KSTEPS; kk++) {
+            const int an = (kk + WR - 1) % WR, ac = kk % WR;
+            a[an][0] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP + 64];
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) {
+                acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], b[kk][ps], acc[0][ps], 0, 0, 0);
+                acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], b[kk][ps], acc[1][ps], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < STEM_KSTEPS; kk++) {
+            const int an = (kk + WR - 1) % WR, ac = kk % WR;
+            a[an][0] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP + 64];
+            half8 b[NSUB];
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) b[ps] = *reinterpret_cast<const half8 *>(in + lb[ps] + soff[kk]);
+#pragma unroll
+            for (int ps = 0; ps < NSUB; ps++) {
+                acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], b[ps], acc[0][ps], 0, 0, 0);
+                acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], b[ps], acc[1][ps], 0, 0, 0);
+            }
+        }
+    }
 }
 
 template <class GEO, int KS, int NSUB, bool SKIP>
@@ -689,8 +736,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 }
             };
             if constexpr (AFFINE_EARLY) fetch_affine();
-            if (layer == 0) { conv_main2<GEO, 1, NSUB, 0, WR, TAPSKIP>(smem, lb, wt, a, acc); wt += (size_t)9 * GEO::WSTEP; }
-            else { conv_main2<GEO, KS, NSUB, 9 % WR, WR, TAPSKIP>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
+            if (layer == 0) { conv_stem<GEO, NSUB, WR>(smem, lb, g, wt, a, acc); wt += (size_t)STEM_KSTEPS * GEO::WSTEP; }
+            else { conv_main2<GEO, KS, NSUB, STEM_KSTEPS % WR, WR, TAPSKIP>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
             AZG_STAMP2(1);
             if constexpr (!AFFINE_EARLY) fetch_affine();
             __syncthreads();                                    // every wave is done reading the image

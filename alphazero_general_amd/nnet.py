@@ -144,6 +144,18 @@ def pack_conv_weight(w, ks):
     return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1).to(torch.float16)
 
 
+def pack_stem_weight(w):
+    """Stem [C, Cin <= 8, 3, 3] float -> fp16 A fragments [3 k-steps][C/16 cout-subtiles][64 lanes][8]: the stem's input is one
+    8-channel chunk per pixel, so a k-step of 32 holds FOUR taps -- lane = g*16 + i holds W[cout = ms*16 + i, cin = j,
+    tap = 4*ks + g] (zero for tap > 8): csrc/azg_conv.h conv_stem."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cout % 32 == 0 and cin <= 8
+    wk = torch.zeros((cout, 12, 8), dtype=torch.float32, device=w.device)                 # [cout, tap slot, channel]
+    wk[:, :9, :cin] = w.float().reshape(cout, cin, 9).permute(0, 2, 1)
+    t = wk.reshape(cout // 16, 16, 3, 4, 8)                                               # [ms, i, ks, g, j]
+    return t.permute(2, 0, 3, 1, 4).contiguous().reshape(-1).to(torch.float16)
+
+
 def _reference_pickle(trusted=False):
     """A pickle module for checkpoints the REFERENCE wrote: alphazero.utils.dotdict -> utils.dotdict.  By default only an
     allow-list of globals is resolved (tensor rebuild functions, storages, OrderedDict, dotdict); every other global becomes an
@@ -228,7 +240,7 @@ class HipResNet:
         assert CH in (32, 64, 128) and C <= 8, 'the MFMA tower is built for 32, 64 or 128 channels'
         f32 = dict(dtype=torch.float32, device=self.device)
         with torch.no_grad():
-            self.stem_w = pack_conv_weight(folded.stem_w.float(), 1).to(self.device)
+            self.stem_w = pack_stem_weight(folded.stem_w.float()).to(self.device)
             self.stem_b = folded.stem_b.float().to(**f32).contiguous()
             self.blocks = []
             for i in range(len(folded.w1)):

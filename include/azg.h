@@ -210,8 +210,9 @@ int  azg_last_actions_dev(azg_engine *e, int32_t **actions_dev);
 
 /* ---- network hot op: the policy/value ResNet on MFMA (csrc/azg_conv.h) --------------------------------------
  * alphazero/NNetArchitecture.py:36-120 in eval mode, BatchNorm folded.  Activations are fp16 NHWC rows; x: [boards*H*W, 8]
- * fp16 rows (the engine's obs_dtype 2); w_packed: MFMA fragment order [9 taps][KS][C/16][64 lanes][8 halves] per convolution
- * (KS = C/32, stem: 1), see nnet.pack_conv_weight; bias / pre_scale / pre_shift: f32 [C].  Board geometry from `game`. */
+ * fp16 rows (the engine's obs_dtype 2); w_packed: MFMA fragment order [9 taps][KS = C/32][C/16][64 lanes][8 halves] per
+ * convolution (nnet.pack_conv_weight), except the stem: [3 k-steps][C/16][64][8] with four taps of the 8 input channels per
+ * k-step (nnet.pack_stem_weight); bias / pre_scale / pre_shift: f32 [C].  Board geometry from `game`. */
 
 /* The whole residual tower (stem + 2*nblocks convolutions) in ONE persistent launch with activations resident in
  * LDS (csrc/azg_conv.h k_tower2), `channels` = 64 or 128 wide (C below).  x: [boards*H*W, 8] fp16; w_packed: stem fragments
