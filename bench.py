@@ -284,15 +284,17 @@ def main():
     D.barrier(); torch.cuda.synchronize()
     t0 = time.time()
     for k in range(a.steps):
-        timed = a.pipelines == 1 and (k == a.steps // 2 or (fused_search and k == a.steps // 2 + 1))
+        second = fused_search and k == a.steps // 2 + 1
+        # (a round of the persistent launch costs the same launched eagerly as replayed from its graph -- six launches -- so
+        #  every eighth one is launched eagerly with events around it: `launches_timed` persistent launches, not one)
+        timed = a.pipelines == 1 and (k == a.steps // 2 or second or (fused_search and k % 8 == 4))
         if not timed:
             runner.play_round()
             continue
         # an eagerly launched round with HIP events (on the launch stream) around every launch: the same launch sequence the
-        # graph replays.  With the persistent search launch: one such round, then one round of the two-launches-per-simulation
+        # graph replays.  With the persistent search launch: such rounds, plus one round of the two-launches-per-simulation
         # form of the same move loop, which shows the tree launch and the tower launch on their own
         torch.cuda.synchronize()
-        second = fused_search and k == a.steps // 2 + 1
         if second:
             runner.fused_search = False
         engines[0].profile(True); HipResNet.profile(True)
