@@ -206,7 +206,8 @@ def test_brandubh_4096_games_fit_one_gpu():
     eng.close()
 
 
-@pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200)])
+@pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200), ('brandubh', 1, 2),
+                                           ('trimok', 3, 2), ('trimok', 1, 5)])
 def test_wide_search_launch_equals_phase_launches(game, B, sims):
     """azg_search_wide_f16 (networks with factorised heads: tree walk by two wavefronts per game, tower, head convolutions and the
     sparse heads all inside one persistent launch) against the launch-per-phase path -- azg_select / azg_backup_select_features,

@@ -84,19 +84,21 @@ def test_selfplay_runner_launch_strategy_is_invisible(variant):
         assert sorted(zip(a[5].tolist(), a[4].tolist())) == sorted(zip(b[5].tolist(), b[4].tolist()))
 
 
-def test_fused_search_kernel_equals_three_kernel_path():
+@pytest.mark.parametrize('B,sims,moves', [(203, 17, 30), (1, 2, 44), (2, 3, 44), (5, 2, 12), (7, 4, 6)])
+def test_fused_search_kernel_equals_three_kernel_path(B, sims, moves):
     """azg_search_f16 (one persistent launch: tree walk, MFMA tower, backup for `sims` simulations) against the same number
-    of [azg_select, azg_resnet_policy_value_f16, azg_backup] rounds on a twin engine: identical trees, moves, samples."""
+    of [azg_select, azg_resnet_policy_value_f16, azg_backup] rounds on a twin engine: identical trees, moves, samples.
+    203: the last workgroup owns 3 games, not 4; the tiny cases: fewer games than a workgroup holds, two simulations per move
+    (the fewest that leave a visit count to sample from), games that end and restart inside the run."""
     import torch
     from alphazero_general_amd.engine import DeviceEngine
     net = _net(4); net.refresh()
     hip = net._hip
-    B, sims = 203, 17                                              # 203: the last workgroup owns 3 games, not 4
     kw = dict(cpuct=4.0, fpu_reduction=0.4, add_root_noise=True, add_root_temp=True, seed=12, games_per_iteration=1 << 30,
               example_capacity=B * 43 * 2 * 3, sims_hint=sims)
     ea, eb = DeviceEngine(0, B, **kw), DeviceEngine(0, B, **kw)
     obs = torch.zeros((B, 42, 8), dtype=torch.float16, device=ea.device)
-    for move in range(30):
+    for move in range(moves):
         hip.search(ea, sims)
         for _ in range(sims):
             eb.select(obs)
@@ -108,7 +110,7 @@ def test_fused_search_kernel_equals_three_kernel_path():
         ea.advance(True); eb.advance(True)
         assert torch.equal(ea.last_actions(), eb.last_actions())
     a, b = ea.counters(), eb.counters()
-    assert a == b and a['games_played'] > 0
+    assert a == b and (a['games_played'] > 0 or moves < 20)
     for x, y in zip(ea.examples(), eb.examples()):
         assert torch.equal(x, y)
 
