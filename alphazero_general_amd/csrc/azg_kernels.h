@@ -823,6 +823,11 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
     if (ev.arena) temp = ev.arena_temp;                                      // :158
     else { int t = st.turns < ev.temp_len ? st.turns : ev.temp_len - 1; temp = ev.temp_table[t]; }   // :156-157
     root_probs<G>(ev, nodes, fc, k, temp, cnt, pr, scr, lane);               // :159
+    {                                                                        // no visited child: counts / 0 (:320) -- the reference
+        bool nan = false;                                                    // raises (np.seterr(all='raise'), :23); so does this
+        for (int a = lane; a < A; a += 64) nan |= pr[a] != pr[a];
+        if (__ballot(nan)) { if (lane == 0) { raise_error(ev, AZG_E_NO_VISITS); ev.fin_flag[slot] = 0; } return; }
+    }
     // np.random.choice(A, p=policy) via the tape (:160): cdf in double, first index whose cdf/total > u
     uint64_t ctr = ev.tape_ctr[slot];
     const double u = u53(tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr));

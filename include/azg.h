@@ -36,7 +36,10 @@ typedef enum azg_status {
     AZG_E_TREE_FULL = -4,       /* a tree's node arena overflowed (raise nodes_per_tree)            */
     AZG_E_EXAMPLES_FULL = -5,   /* the training-example buffer overflowed (raise example_capacity)  */
     AZG_E_UNSUPPORTED = -6,
-    AZG_E_INTERNAL = -7         /* a bounded device-side wait expired (never expected; reported instead of hanging) */
+    AZG_E_INTERNAL = -7,        /* a bounded device-side wait expired (never expected; reported instead of hanging) */
+    AZG_E_NO_VISITS = -8        /* playMoves at a root none of whose children was visited (numMCTSSims < 2): MCTS.probs divides
+                                   0 by 0 (MCTS.pyx:320) and the reference, under np.seterr(all='raise') (:23), raises
+                                   FloatingPointError -- the Python layer does the same                                   */
 } azg_status;
 
 /* games with device-side rules (Game plugin API, alphazero/Game.py:7-113) */

@@ -272,6 +272,15 @@ def test_errors_surface(torch_mod):
             eng.select(obs); eng.backup(pol, val)
         eng.counters()                             # tree arena overflow is reported, not silently dropped
     eng.close()
+    # one simulation per move: no child of the root has a visit when playMoves asks for MCTS.probs, counts / 0.  The reference runs
+    # under np.seterr(all='raise') (MCTS.pyx:23) and dies with FloatingPointError at :320; the engine raises the same, not NaNs
+    eng = engine(B=4, sims_hint=1)
+    obs = eng.new_obs()
+    eng.select(obs); eng.backup(pol, val)
+    eng.advance(True)
+    with pytest.raises(FloatingPointError):
+        eng.counters()
+    eng.close()
 
 
 # ------------------------------------------------------------------ single-tree MCTS class (reference API surface)
