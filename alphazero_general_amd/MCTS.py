@@ -152,7 +152,10 @@ class MCTS:
         return int(np.argmax(self.counts(gs)))
 
     def probs(self, gs, temp=1.0):                                     # MCTS.pyx:308-329
-        return self._ensure(gs).root_probs(float(np.float32(temp)))[0].cpu().numpy()
+        p = self._ensure(gs).root_probs(float(np.float32(temp)))[0].cpu().numpy()
+        if np.isnan(p).any():                                          # no visited child: counts / 0 under np.seterr(all='raise') (:23)
+            raise FloatingPointError('invalid value encountered in divide')
+        return p
 
     def value(self, average=False):                                    # MCTS.pyx:331-344
         if self._engine is None:
