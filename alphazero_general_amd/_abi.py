@@ -10,9 +10,9 @@ LIB_PATH = os.environ.get('AZG_LIB_PATH') or os.path.join(HERE, 'lib', 'libazg_h
 ABI_VERSION = 2
 
 GAME_CONNECT4, GAME_BRANDUBH, GAME_TRIMOK = 0, 1, 2
-E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_TREE_FULL, E_EXAMPLES_FULL, E_UNSUPPORTED, E_INTERNAL, E_NO_VISITS = -1, -2, -3, -4, -5, -6, -7, -8
+E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_TREE_FULL, E_EXAMPLES_FULL, E_UNSUPPORTED, E_INTERNAL, E_FLOATING_POINT = -1, -2, -3, -4, -5, -6, -7, -8
 ERROR_NAMES = {-1: 'AZG_E_INVALID_ARG', -2: 'AZG_E_HIP', -3: 'AZG_E_INVALID_ACTION', -4: 'AZG_E_TREE_FULL',
-               -5: 'AZG_E_EXAMPLES_FULL', -6: 'AZG_E_UNSUPPORTED', -7: 'AZG_E_INTERNAL', -8: 'AZG_E_NO_VISITS'}
+               -5: 'AZG_E_EXAMPLES_FULL', -6: 'AZG_E_UNSUPPORTED', -7: 'AZG_E_INTERNAL', -8: 'AZG_E_FLOATING_POINT'}
 
 
 class State(C.Structure):

@@ -303,6 +303,7 @@ AZG_DEV void leaf_policy(const View &ev, int slot, Node *nodes, int fc, int k, b
         cp[c] = i < k ? pi[ca[c]] : 0.f;                                     // pi * valids: valid entries keep pi[a]
     }
     const float s = masked_sum<G, NC>(ev, ca, cp, m_lds, scr, lane, true);
+    if (!(s > 0.f) && lane == 0) raise_error(ev, AZG_E_FLOATING_POINT);      // x / 0: the reference raises (np.seterr(all='raise'), :23)
 #pragma unroll
     for (int c = 0; c < NC; c++) cp[c] = cp[c] / s;                          // :245
     if (at_root && ev.add_temp) {                                            // :249-252 root temperature
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
     {                                                                        // no visited child: counts / 0 (:320) -- the reference
         bool nan = false;                                                    // raises (np.seterr(all='raise'), :23); so does this
         for (int a = lane; a < A; a += 64) nan |= pr[a] != pr[a];
-        if (__ballot(nan)) { if (lane == 0) { raise_error(ev, AZG_E_NO_VISITS); ev.fin_flag[slot] = 0; } return; }
+        if (__ballot(nan)) { if (lane == 0) { raise_error(ev, AZG_E_FLOATING_POINT); ev.fin_flag[slot] = 0; } return; }
     }
     // np.random.choice(A, p=policy) via the tape (:160): cdf in double, first index whose cdf/total > u
     uint64_t ctr = ev.tape_ctr[slot];

@@ -264,8 +264,9 @@ class DeviceEngine:
     def counters(self):
         c = _abi.Counters()
         _abi.check(self.L.azg_read_counters(self.h, _stream(), C.byref(c)))
-        if c.error == _abi.E_NO_VISITS:                              # what numpy raises in the reference (MCTS.pyx:23,320)
-            raise FloatingPointError('invalid value encountered in divide: playMoves at a root without a visited child (numMCTSSims < 2)')
+        if c.error == _abi.E_FLOATING_POINT:                              # what numpy raises in the reference (MCTS.pyx:23,320)
+            raise FloatingPointError('invalid value encountered in divide: playMoves at a root without a visited child (numMCTSSims < 2) '
+                                     'or a policy whose valid entries sum to 0')
         if c.error:
             raise _abi.AzgError(c.error, 'raised on device (tree arena or example buffer overflow / invalid action)')
         return dict(sims=c.sims, expansions=c.expansions, games_played=c.games_played, num_results=c.num_results,

@@ -37,9 +37,9 @@ typedef enum azg_status {
     AZG_E_EXAMPLES_FULL = -5,   /* the training-example buffer overflowed (raise example_capacity)  */
     AZG_E_UNSUPPORTED = -6,
     AZG_E_INTERNAL = -7,        /* a bounded device-side wait expired (never expected; reported instead of hanging) */
-    AZG_E_NO_VISITS = -8        /* playMoves at a root none of whose children was visited (numMCTSSims < 2): MCTS.probs divides
-                                   0 by 0 (MCTS.pyx:320) and the reference, under np.seterr(all='raise') (:23), raises
-                                   FloatingPointError -- the Python layer does the same                                   */
+    AZG_E_FLOATING_POINT = -8   /* a division the reference turns into FloatingPointError (np.seterr(all='raise'), MCTS.pyx:23):
+                                   MCTS.probs at a root without a visited child (counts / 0, :320; numMCTSSims < 2), or a policy
+                                   whose valid entries sum to 0 (:245).  The Python layer raises FloatingPointError too        */
 } azg_status;
 
 /* games with device-side rules (Game plugin API, alphazero/Game.py:7-113) */

@@ -281,6 +281,13 @@ def test_errors_surface(torch_mod):
     with pytest.raises(FloatingPointError):
         eng.counters()
     eng.close()
+    # a policy whose valid entries sum to 0: policy /= np.sum(policy) (MCTS.pyx:245) is x / 0 -> FloatingPointError there and here
+    eng = engine(B=4, sims_hint=4)
+    obs = eng.new_obs()
+    eng.select(obs); eng.backup(torch.zeros((4, 7), device=eng.device), val)
+    with pytest.raises(FloatingPointError):
+        eng.counters()
+    eng.close()
 
 
 # ------------------------------------------------------------------ single-tree MCTS class (reference API surface)
