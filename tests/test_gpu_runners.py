@@ -269,3 +269,26 @@ def test_fused_search_kernel_tree_arena_overflow_is_reported():
     e2 = DeviceEngine(0, 37, cpuct=4.0, fpu_reduction=0.4, seed=1, sims_hint=60)      # the device is fine afterwards
     net._hip.search(e2, 60)
     assert e2.counters()['sims'] == 37 * 60
+
+
+@pytest.mark.parametrize('game', ['brandubh', 'trimok'])
+def test_wide_search_kernel_tree_arena_overflow_is_reported(game):
+    """the same for the two-wavefront persistent launch (azg_search_wide_f16): walker and helper of a game must both stop on the
+    sticky error -- neither may be left waiting for the other's flag -- and the launch must end."""
+    import importlib
+    import torch
+    from alphazero_general_amd import _abi, nnet as N
+    from alphazero_general_amd.engine import DeviceEngine
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    torch.manual_seed(3)
+    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    net.refresh()
+    e = DeviceEngine(Game.AZG_GAME_ID, 21, cpuct=1.25, fpu_reduction=0.2, seed=1, sims_hint=2, nodes_per_tree=200)
+    net._hip.search(e, 80)
+    with pytest.raises(_abi.AzgError) as ei:
+        e.counters()
+    assert ei.value.code == _abi.E_TREE_FULL
+    e.close()
+    e2 = DeviceEngine(Game.AZG_GAME_ID, 21, cpuct=1.25, fpu_reduction=0.2, seed=1, sims_hint=80)     # the device is fine afterwards
+    net._hip.search(e2, 80)
+    assert e2.counters()['sims'] == 21 * 80
