@@ -64,8 +64,13 @@ def all_gather_examples(obs, pi, z, group=None):
     for t in (obs, pi, z):
         pad = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[:t.shape[0]] = t
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad, group=group)
+        if dist.get_backend(group) == 'nccl':                # RCCL: ONE output buffer, no per-rank staging copies
+            allb = torch.empty((world,) + tuple(pad.shape), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(allb, pad, group=group)
+            bufs = list(allb.unbind(0))
+        else:
+            bufs = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(bufs, pad, group=group)
         out.append(torch.cat([b[:c] for b, c in zip(bufs, counts)]))
     return tuple(out)
 
