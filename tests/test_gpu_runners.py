@@ -292,3 +292,32 @@ def test_wide_search_kernel_tree_arena_overflow_is_reported(game):
     e2 = DeviceEngine(Game.AZG_GAME_ID, 21, cpuct=1.25, fpu_reduction=0.2, seed=1, sims_hint=80)     # the device is fine afterwards
     net._hip.search(e2, 80)
     assert e2.counters()['sims'] == 21 * 80
+
+
+def test_exchange_step_on_rccl_world_of_one():
+    """distributed.all_gather_examples through the RCCL branch (all_gather_into_tensor) -- a one-rank nccl group is all a
+    single-GPU box can host; the multi-rank layout is covered by the gloo tests on CPU."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import os, sys, torch
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+import torch.distributed as dist
+from alphazero_general_amd import distributed as D
+dist.init_process_group('nccl', rank=0, world_size=1)
+torch.cuda.set_device(0)
+g = torch.Generator(device='cuda').manual_seed(1)
+obs = torch.rand((37, 4, 6, 7), device='cuda', generator=g); pi = torch.rand((37, 7), device='cuda', generator=g); z = torch.rand((37, 3), device='cuda', generator=g)
+o, p, v = D.all_gather_examples(obs, pi, z)
+assert torch.equal(o, obs) and torch.equal(p, pi) and torch.equal(v, z)
+o, p, v = D.all_gather_examples(obs[:0], pi[:0], z[:0])
+assert o.shape[0] == 0 and p.shape == (0, 7)
+assert D.max_over_ranks(2.5) == 2.5 and D.all_reduce_tallies([3, 4]).tolist() == [3, 4]
+D.barrier(); D.shutdown()
+print('RCCL_OK')
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert r.returncode == 0 and b'RCCL_OK' in r.stdout, r.stdout.decode(errors='replace')[-2000:]
