@@ -34,7 +34,13 @@ class SelfPlayRunner:
 
     def __init__(self, game_cls, nnet, args, *, num_slots, seed=0, slot_base=0, device=None, example_capacity=None,
                  use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None, result_capacity=None,
-                 fused_search=None):
+                 fused_search=None, heads=None, nodes_per_tree=0):
+        """heads: what the tree launch is fed when the search is launched per phase -- None picks the cheapest form the network
+        offers ('features' for factorised heads: the launch computes the logits of the valid actions itself; 'logits' for other
+        wide heads: softmax inside the launch; else 'probs'); tests pin each form against the oracle.  nodes_per_tree: node
+        store of a tree (0 = the library's default, include/azg.h)."""
+        assert heads in (None, 'probs', 'logits', 'features')
+        self.heads = heads
         self.game_cls, self.nnet, self.args = game_cls, nnet, args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -71,7 +77,7 @@ class SelfPlayRunner:
                 arena_temp=args.get('arenaTemp', 0.25), temp_fn=args.get('temp_scaling_fn', default_temp_scaling),
                 seed=seed, slot_base=self.slot_base + li * Bl, device=device,
                 example_capacity=example_capacity // self.pipelines + 1, result_capacity=int(result_capacity) // self.pipelines + 1,
-                sims_hint=sims)
+                sims_hint=sims, nodes_per_tree=nodes_per_tree)
             dev = eng.device
             with torch.cuda.device(dev):
                 lane = _Lane(eng, torch.cuda.Stream(device=dev) if self.pipelines > 1 else torch.cuda.current_stream(dev))
@@ -139,6 +145,10 @@ class SelfPlayRunner:
         e.select(ln.obs)
         logits_path = not self.warmup and ln.net.run_logits is not None    # wide heads: softmax inside the tree launch
         feat_path = not self.warmup and getattr(ln.net, 'run_features', None) is not None   # factorised: the heads too
+        if self.heads is not None and not self.warmup:
+            if (self.heads == 'features' and not feat_path) or (self.heads == 'logits' and not logits_path):
+                raise NotImplementedError('this network has no %s hand-over to the tree launch' % self.heads)
+            feat_path, logits_path = self.heads == 'features', self.heads == 'logits'
         for i in range(sims):                                    # backup k and select k + 1 share a launch
             if feat_path:
                 feat, rows, hb = ln.net.run_features()

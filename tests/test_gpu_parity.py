@@ -117,7 +117,10 @@ AGENT_ROUND = {'fastmix': dict(prob_fast=0.5, fast_sims=6), 'warmup': dict(warmu
 
 
 def run_engine_agent(torch, eng, seed, slot_base, sims, games, prob_fast=0.0, fast_sims=20, warmup=False, warmup_sims=5,
-                     max_rounds=500):
+                     max_rounds=500, launch='phase'):
+    """SelfPlayAgent.run (SelfPlayAgent.pyx:79-101) on the engine.  launch = 'phase': generateBatch / processBatch as azg_select /
+    azg_backup; 'fused': backup k and select k + 1 share a launch (azg_backup_select: k_backup_select2, two wavefronts per tree) --
+    the form every runner and bench line uses."""
     from alphazero_general_amd.utils import AGENT_STREAM
     from alphazero_general_amd import _abi
     L = _abi.lib()
@@ -135,14 +138,20 @@ def run_engine_agent(torch, eng, seed, slot_base, sims, games, prob_fast=0.0, fa
         actr += 1
         ns = fast_sims if fast else (warmup_sims if warmup else sims)
         rec['sims'].append(ns)
-        for s in range(ns):
+        if launch == 'fused':
             eng.select(None if warmup else obs)
+        for s in range(ns):
+            if launch == 'phase':
+                eng.select(None if warmup else obs)
             if warmup:
-                eng.backup(wp, wv)
+                pol, val = wp, wv
             else:
                 o = obs.cpu().numpy()
                 rec['obs_crc'].append([crc(o[i]) for i in range(B)])
                 pol, val = fake_batch(torch, seed, [slot_base + i for i in range(B)], step, A, NV, eng.device)
+            if launch == 'fused' and s + 1 < ns:
+                eng.backup_select(pol, val, None if warmup else obs)
+            else:
                 eng.backup(pol, val)
             step += 1
         rec['counts'].append(eng.root_counts().cpu().numpy())
@@ -153,15 +162,19 @@ def run_engine_agent(torch, eng, seed, slot_base, sims, games, prob_fast=0.0, fa
     return rec
 
 
+LAUNCHES = ['phase', 'fused']
+
+
+@pytest.mark.parametrize('launch', LAUNCHES)
 @pytest.mark.parametrize('cname', list(AGENT_CFGS))
-def test_c4_agent_vs_reference_goldens(torch_mod, cname):
+def test_c4_agent_vs_reference_goldens(torch_mod, cname, launch):
     torch = torch_mod
     d = dict(np.load(os.path.join(G, 'c4_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
     seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
     eng = engine(B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=16384, sims_hint=sims,
                  **AGENT_CFGS[cname])
-    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games, **AGENT_ROUND.get(cname, {}))
+    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games, launch=launch, **AGENT_ROUND.get(cname, {}))
     assert (np.array(rec['sims']) == d[cname + '_round_sims']).all()
     assert (np.array(rec['counts']) == d[cname + '_counts']).all()
     assert (np.array(rec['actions']) == d[cname + '_actions']).all()
@@ -179,11 +192,12 @@ def test_c4_agent_vs_reference_goldens(torch_mod, cname):
 
 
 # ----------------------------------------------------------------------------------- live oracle, larger sizes
+@pytest.mark.parametrize('launch', LAUNCHES)
 @pytest.mark.parametrize('B,sims,games,kw', [
     (256, 40, 300, dict(cpuct=4.0, fpu_reduction=0.4)),
     (96, 30, 120, dict(add_root_noise=True, cpuct=1.25)),
 ])
-def test_c4_selfplay_vs_oracle_live(torch_mod, B, sims, games, kw):
+def test_c4_selfplay_vs_oracle_live(torch_mod, B, sims, games, kw, launch):
     torch = torch_mod
     seed = 4242
     okw = dict(kw)
@@ -194,16 +208,23 @@ def test_c4_selfplay_vs_oracle_live(torch_mod, B, sims, games, kw):
     step = 0
     while ag.games_played < games:
         ag.begin_round()
+        if launch == 'fused':
+            eng.select(obs)
         for s in range(sims):
             oobs, rg, rm = ag.generate_batch()
-            eng.select(obs)
+            if launch == 'phase':
+                eng.select(obs)
             if step % 7 == 0:
                 assert (obs.cpu().numpy() == oobs).all(), step
             pol = np.zeros((B, A), np.float32); val = np.zeros((B, NV), np.float32)
             for i in range(B):
                 pol[i], val[i] = ol.fake_eval(seed, i, step, A, NV)
             ag.process_batch(pol, val)
-            eng.backup(torch.from_numpy(pol).to(eng.device), torch.from_numpy(val).to(eng.device))
+            tp, tv = torch.from_numpy(pol).to(eng.device), torch.from_numpy(val).to(eng.device)
+            if launch == 'fused' and s + 1 < sims:
+                eng.backup_select(tp, tv, obs)
+            else:
+                eng.backup(tp, tv)
             step += 1
         ag.play_moves()
         eng.advance(True)
@@ -500,14 +521,15 @@ def test_br_tree_vs_reference_goldens(torch_mod, cname):
     eng.close()
 
 
+@pytest.mark.parametrize('launch', LAUNCHES)
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
-def test_br_agent_vs_reference_goldens(torch_mod, cname, kw):
+def test_br_agent_vs_reference_goldens(torch_mod, cname, kw, launch):
     torch = torch_mod
     d = dict(np.load(os.path.join(G, 'br_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
     seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
     eng = engine(game=BR, B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=20000, sims_hint=sims, **kw)
-    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games)
+    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games, launch=launch)
     assert (np.array(rec['counts']) == d[cname + '_counts']).all()
     assert (np.array(rec['actions']) == d[cname + '_actions']).all()
     assert (np.array(rec['games_played']) == d[cname + '_games_played']).all()
@@ -563,14 +585,15 @@ def test_tm_tree_vs_reference_goldens(torch_mod, cname):
     eng.close()
 
 
+@pytest.mark.parametrize('launch', LAUNCHES)
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
-def test_tm_agent_vs_reference_goldens(torch_mod, cname, kw):
+def test_tm_agent_vs_reference_goldens(torch_mod, cname, kw, launch):
     torch = torch_mod
     d = dict(np.load(os.path.join(G, 'tm_agent.npz')))              # (NpzFile decompresses an array on EVERY d[key])
     B, sims, games = int(d[cname + '_B']), int(d[cname + '_sims']), int(d[cname + '_games'])
     seed, slot_base = int(d[cname + '_seed']), int(d[cname + '_slot_base'])
     eng = engine(game=TM, B=B, seed=seed, slot_base=slot_base, games_per_iteration=games, example_capacity=8000, sims_hint=sims, **kw)
-    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games)
+    rec = run_engine_agent(torch, eng, seed, slot_base, sims, games, launch=launch)
     assert (np.array(rec['counts']) == d[cname + '_counts']).all()
     assert (np.array(rec['actions']) == d[cname + '_actions']).all()
     assert (np.array(rec['games_played']) == d[cname + '_games_played']).all()

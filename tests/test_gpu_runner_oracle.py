@@ -1,0 +1,156 @@
+"""The native self-play runner (selfplay.SelfPlayRunner: whole rounds replayed as one hipGraph) against the CPU oracle, both fed by
+the SAME real network, for every hand-over form between the network and the tree launch that a bench line or a runner uses:
+
+  probs     azg_backup_select            (k_backup_select2<G, IN_PROBS>: probabilities from the network launch)
+  logits    azg_backup_select_logits     (k_backup_select2<G, IN_LOGITS>: both softmaxes inside the tree launch -- the same
+                                          heads_softmax_row arithmetic as the network's own softmax launch, so bit-identical)
+  features  azg_backup_select_features   (sparse heads: logits of the valid actions only, equal to rounding -- see below)
+  search    azg_search_wide_f16 / azg_search_f16 (one persistent launch per move)
+
+The oracle (oracle/azg_mcts_ref.c, pinned to the reference's goldens) plays SelfPlayAgent.generateBatch / processBatch / playMoves
+(SelfPlayAgent.pyx:103-202, MCTS.pyx:208-289) with the probabilities NNetWrapper.process returns for ITS leaf observations.  For
+probs / logits every action, sample, result and counter must be identical until every slot has finished a game and restarted.
+The sparse-heads forms (features, wide search) renormalise over the valid actions only: priors agree to ~1e-8, so a PUCT
+near-tie can flip; those tests follow every slot until it diverges and require the committed seed to never diverge."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(game, seed_net):
+    import torch
+    from alphazero_general_amd import nnet as N
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    net_args = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[game]
+    torch.manual_seed(seed_net)
+    net = N.NNetWrapper(Game, net_args, device='cuda:0', dtype=torch.float16)
+    net.refresh()
+    assert net._hip is not None
+    return Game, net
+
+
+def _args(sims, games, **kw):
+    from alphazero_general_amd.utils import dotdict, default_temp_scaling
+    a = dotdict(numMCTSSims=sims, numFastSims=20, probFastSim=0.0, gamesPerIteration=games, cpuct=1.25, fpu_reduction=0.2,
+                root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0, add_root_noise=True, add_root_temp=True,
+                symmetricSamples=True, mctsResetThreshold=0, startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
+    a.update(kw)
+    return a
+
+
+def _oracle_round(ag, net, sims):
+    import torch
+    ag.begin_round()
+    for _ in range(sims):
+        oobs, _, _ = ag.generate_batch()
+        p, v = net.process(torch.from_numpy(oobs))
+        ag.process_batch(p.cpu().numpy(), v.cpu().numpy())
+    ag.play_moves()
+
+
+@pytest.mark.parametrize('game,heads,B,sims', [
+    ('brandubh', 'probs', 48, 24), ('brandubh', 'logits', 48, 40),
+    ('trimok', 'probs', 64, 16), ('trimok', 'logits', 64, 24),
+    ('connect4', 'probs', 64, 24),
+])
+def test_runner_phase_launches_vs_oracle_with_real_net(game, heads, B, sims):
+    """bit-exact forms: actions every round, then samples (x symmetries), results and counters, until every slot has restarted."""
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    Game, net = _setup(game, 5)
+    seed, games = 23, 3 * B
+    kw = dict(cpuct=4.0, fpu_reduction=0.4) if game == 'connect4' else {}
+    r = SelfPlayRunner(Game, net, _args(sims, games, **kw), num_slots=B, seed=seed, fused_search=False, heads=heads)
+    assert r.round_graph and not r.fused_search
+    ag = ol.OAgent(Game.AZG_GAME_ID, B, sims=sims, games_per_iteration=games, seed=seed, add_root_noise=True, add_root_temp=True,
+                   cpuct=kw.get('cpuct', 1.25), fpu_reduction=kw.get('fpu_reduction', 0.2))
+    rounds = 0
+    while ag.games_played < games and len(set(ag.results()[2].tolist())) < B:
+        _oracle_round(ag, net, sims)
+        r.play_round()
+        assert (r.engine.last_actions().cpu().numpy() == ag.last_actions()).all(), rounds
+        rounds += 1
+    c = r.engine.counters()
+    assert c['games_played'] == ag.games_played and c['sims'] == ag.sims_done and c['expansions'] == ag.expansions
+    assert len(set(ag.results()[2].tolist())) == B or ag.games_played >= games
+    oo, op, oz = ag.samples()
+    eo, ep, ez = [t.cpu().numpy() for t in r.engine.examples()]
+    assert eo.shape == oo.shape and eo.shape[0] > 0
+    assert (eo == oo).all() and (ep == op).all() and (ez == oz).all()
+    for x, y in zip(r.engine.results(), ag.results()):
+        assert (x == y).all()
+
+
+@pytest.mark.parametrize('game,form,B,sims,rounds', [
+    ('brandubh', 'search', 48, 200, 60), ('brandubh', 'features', 48, 40, 110),
+    ('trimok', 'search', 64, 50, 60), ('trimok', 'features', 64, 24, 60),
+    ('connect4', 'search', 64, 100, 50),
+])
+def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, rounds):
+    """The launches bench.py times (--workload brandubh | trimok: azg_search_wide_f16 with sparse heads at 200 / 50 simulations per
+    move; connect4: azg_search_f16) and the launch-per-phase sparse-heads form, against the oracle fed by NNetWrapper.process
+    (full-width heads: softmax over all A, mask, renormalise -- what the reference computes, MCTS.pyx:239-245).  connect4's fused
+    heads hand over exact probabilities: bit-identical, asserted.  The sparse heads agree to rounding only: a slot is followed
+    until its first differing move; the fraction that never diverged is recorded (gpurun_out/nn_error.jsonl) and must be 1.0 on
+    this seed -- counts and pi(T=1) of every agreeing slot are compared every round."""
+    import torch
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    Game, net = _setup(game, 7)
+    seed, games = 29, 1 << 30
+    kw = dict(cpuct=4.0, fpu_reduction=0.4) if game == 'connect4' else {}
+    gi = ol.game_info(Game.AZG_GAME_ID)
+    cap = B * (rounds + 1) * gi.num_symmetries
+    r = SelfPlayRunner(Game, net, _args(sims, games, **kw), num_slots=B, seed=seed, example_capacity=cap,
+                       fused_search=(form == 'search'), heads=(None if form == 'search' else form))
+    assert r.fused_search == (form == 'search')
+    ag = ol.OAgent(Game.AZG_GAME_ID, B, sims=sims, games_per_iteration=games, seed=seed, add_root_noise=True, add_root_temp=True,
+                   cpuct=kw.get('cpuct', 1.25), fpu_reduction=kw.get('fpu_reduction', 0.2))
+    same = np.ones(B, bool)
+    first_div = None
+    A = gi.action_size
+    for rnd in range(rounds):
+        ag.begin_round()
+        for _ in range(sims):
+            oobs, _, _ = ag.generate_batch()
+            p, v = net.process(torch.from_numpy(oobs))
+            ag.process_batch(p.cpu().numpy(), v.cpu().numpy())
+        # one round of the runner WITHOUT its advance: the root statistics are compared before the move is played
+        e = r.engine
+        if form == 'search':
+            net._hip.search(e, sims)
+        else:
+            e.select(r.lanes[0].obs)
+            for i in range(sims):
+                feat, rows, hb = r.lanes[0].net.run_features()
+                e.backup_select_features(feat, rows, hb, r.lanes[0].obs, select=i + 1 < sims)
+        cnt = e.root_counts().cpu().numpy()
+        ocnt = np.zeros((B, A), np.int32)
+        for i in range(B):
+            ch = ag.root_children(i)
+            ocnt[i, ch['a']] = ch['n']
+        same &= (cnt == ocnt).all(1)
+        ag.play_moves()
+        e.advance(True)
+        same &= e.last_actions().cpu().numpy() == ag.last_actions()
+        if first_div is None and not same.all():
+            first_div = rnd
+    frac = float(same.mean())
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/nn_error.jsonl', 'a') as fh:
+        fh.write(json.dumps({'test': 'runner_%s_vs_oracle_%s' % (form, game), 'slots': B, 'sims': sims, 'rounds': rounds,
+                             'slots_never_diverged': frac, 'first_divergence_round': first_div,
+                             'games_finished': int(ag.games_played)}) + '\n')
+    assert ag.games_played > 0
+    assert frac == 1.0, (frac, first_div)
+    c = r.engine.counters()
+    assert c['games_played'] == ag.games_played and c['sims'] == ag.sims_done and c['expansions'] == ag.expansions
+    oo, op, oz = ag.samples()
+    eo, ep, ez = [t.cpu().numpy() for t in r.engine.examples()]
+    assert eo.shape == oo.shape and (eo == oo).all() and (ez == oz).all()
+    assert (ep == op).all()                                     # pi(T=1) is counts / sum: identical counts, identical pi

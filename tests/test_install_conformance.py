@@ -1,0 +1,111 @@
+"""Row (b) of SURVEY.md section 8, pinned against drift: after `alphazero_general_amd.install()` the reference's own callers resolve
+to this package's classes, and those classes keep the reference's call signatures.
+
+Runs only where the reference is present (the build container; /root/reference does not exist on the GPU box): a subprocess
+imports the real `alphazero` package (pyximport, tensorboardX stubbed -- the recipe of tests/golden/refharness.py) AFTER install()
+and reports what `alphazero.Coach.SelfPlayAgent`, `alphazero.Arena.SelfPlayAgent` and `alphazero.GenericPlayers.MCTS` are bound to
+(import sites Coach.py:5, Arena.pyx:4, GenericPlayers.py:1).  The signatures are read from the reference's SOURCE TEXT
+(SelfPlayAgent.pyx:14-16, MCTS.pyx:133-344: `cpdef` methods of a `cdef class` carry no introspectable signature)."""
+import inspect
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+REF = '/root/reference'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'alphazero')), reason='needs the reference checkout (build container only)')
+
+C_TYPES = {'object', 'int', 'bint', 'float', 'double', 'Py_ssize_t', 'float[:]', 'int[:]', 'np.ndarray'}
+
+
+def _ref_signatures(path, cls):
+    """{method: [(name, default or None), ...]} of class `cls` from .pyx source: def / cpdef lines, C types and annotations dropped."""
+    src = open(path).read()
+    m = re.search(r'^(?:cdef )?class %s\b.*?:\n(.*?)(?=^\S|\Z)' % cls, src, re.S | re.M)
+    assert m, cls
+    out = {}
+    for fm in re.finditer(r'^    (?:def|cpdef)\s+(?:[\w\.\[\]:]+\s+)?(\w+)\((.*?)\)\s*(?:->.*?)?:', m.group(1), re.S | re.M):
+        params = []
+        for raw in fm.group(2).replace('\n', ' ').split(','):
+            raw = raw.strip()
+            if not raw:
+                continue
+            default = None
+            if '=' in raw:
+                raw, default = [x.strip() for x in raw.split('=', 1)]
+            raw = raw.split(':')[0].strip() if not any(raw.startswith(t + ' ') for t in ('float[:]', 'int[:]')) else raw
+            toks = raw.split()
+            params.append((toks[-1], default))
+        out[fm.group(1)] = params
+    return out
+
+
+def _our_signature(fn):
+    out = []
+    for name, p in inspect.signature(fn).parameters.items():
+        assert p.kind in (p.POSITIONAL_OR_KEYWORD,), (fn, name)
+        out.append((name, None if p.default is p.empty else repr(p.default)))
+    return out
+
+
+def test_signatures_match_the_reference_source():
+    from alphazero_general_amd.MCTS import MCTS
+    from alphazero_general_amd.SelfPlayAgent import SelfPlayAgent
+    ref_agent = _ref_signatures(os.path.join(REF, 'alphazero', 'SelfPlayAgent.pyx'), 'SelfPlayAgent')
+    assert _our_signature(SelfPlayAgent.__init__) == ref_agent['__init__']                      # SelfPlayAgent.pyx:14-16
+    for meth in ('run', 'generateBatch', 'processBatch', 'playMoves'):                          # :79,103,137,153
+        assert _our_signature(getattr(SelfPlayAgent, meth)) == ref_agent[meth], meth
+    ref_mcts = _ref_signatures(os.path.join(REF, 'alphazero', 'MCTS.pyx'), 'MCTS')
+    public = ['__init__', 'reset', 'search', 'raw_search', 'update_root', 'find_leaf', 'process_results', 'counts', 'best_action',
+              'probs', 'value']                                                                  # MCTS.pyx:133-344
+    for meth in public:
+        ours = _our_signature(getattr(MCTS, meth))
+        ref = [(n, None if d is None else repr(eval(d))) for n, d in ref_mcts[meth]]
+        assert ours == ref, (meth, ours, ref)
+    for attr in ('_root', 'max_depth', 'depth'):                                                 # utils.py:57-83, SelfPlayAgent.pyx, GUI
+        assert hasattr(MCTS, attr) or attr in MCTS(_mcts_args()).__dict__ or hasattr(MCTS(_mcts_args()), attr), attr
+
+
+def _mcts_args():
+    from alphazero_general_amd.utils import dotdict
+    return dotdict(root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1, fpu_reduction=0.2, cpuct=1.25, _num_players=3, numMCTSSims=10)
+
+
+_PROBE = r'''
+import os, sys, types, json
+sys.dont_write_bytecode = True
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(ref)r)
+import numpy as np
+tbx = types.ModuleType('tensorboardX')
+class _W:
+    def __init__(self, *a, **k): pass
+    def __getattr__(self, n): return lambda *a, **k: None
+tbx.SummaryWriter = _W
+sys.modules.setdefault('tensorboardX', tbx)
+import pyximport
+os.makedirs('/tmp/pyxbld', exist_ok=True)
+pyximport.install(setup_args={'include_dirs': np.get_include()}, build_dir='/tmp/pyxbld', language_level=3)
+import alphazero_general_amd as azg
+azg.install()                                   # BEFORE the reference's callers are imported (INTEGRATION.md)
+import alphazero.Coach, alphazero.Arena, alphazero.GenericPlayers
+from alphazero_general_amd.MCTS import MCTS
+from alphazero_general_amd.SelfPlayAgent import SelfPlayAgent
+print(json.dumps(dict(
+    coach=alphazero.Coach.SelfPlayAgent is SelfPlayAgent,
+    arena=alphazero.Arena.SelfPlayAgent is SelfPlayAgent,
+    players=alphazero.GenericPlayers.MCTS is MCTS,
+    coach_file=os.path.realpath(alphazero.Coach.__file__), arena_mod=alphazero.Arena.__name__)))
+'''
+
+
+def test_install_rebinds_the_reference_callers():
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, '-c', _PROBE % dict(root=ROOT, ref=REF)], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['coach'] and d['arena'] and d['players'], d
+    assert d['coach_file'].startswith(REF), d                   # it really is the reference's Coach that was rebound
