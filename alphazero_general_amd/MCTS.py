@@ -83,9 +83,19 @@ class MCTS:
         gid = azg_game_id(gs)
         if self._engine is None:
             self._game = gid
+            # ONE tree: memory is no concern, so its node store holds a whole game's worth of expansions (max_turns moves x the
+            # simulations per move x max_children: connect4 2.4 MB, brandubh 123 MB at 200 simulations) -- more than a search
+            # that drops nothing could fill; a caller that keeps searching at ONE root (pondering, sims far above
+            # args.numMCTSSims) is served by the forced compaction in find_leaf until the LIVE subtree itself exceeds the store
+            # (AZG_E_TREE_FULL; the reference's limit there is host memory)
+            from . import _abi
+            gi = _abi.game_info(gid)
+            sims = max(self._sims_hint, 200)
+            cap = min(max(gi.max_turns, 16) * sims * gi.max_children + 64, (1 << 28) - 1)
             self._engine = DeviceEngine(gid, 1, cpuct=self.cpuct, fpu_reduction=self.fpu_reduction,
                                         root_noise_frac=self.root_noise_frac, root_policy_temp=self.root_temp,
-                                        min_discount=self.min_discount, seed=self._seed, sims_hint=max(self._sims_hint, 200))
+                                        min_discount=self.min_discount, seed=self._seed, sims_hint=sims, nodes_per_tree=cap)
+            self._max_children = gi.max_children
         elif gid != self._game:
             raise ValueError('this MCTS object was created for another game')
         return self._engine
@@ -129,9 +139,12 @@ class MCTS:
     def find_leaf(self, gs):                                           # MCTS.pyx:208-228
         e = self._ensure(gs)
         self._sync_root_state(gs)
+        if getattr(self, '_nodes_used', 0) + 2 * self._max_children > e.nodes_per_tree:
+            e.compact(0, force=True)                                   # the store is nearly full: drop what the root no longer reaches
         e.select(None)
         st = e.get_leaf_states(0, 1, full=True)[0]
         info = e.tree_info(0)
+        self._nodes_used = info['nodes_used']
         self.depth, self.max_depth = info['depth'], info['max_depth']
         return decode_state(gs, *st)
 

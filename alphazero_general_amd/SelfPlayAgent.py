@@ -110,7 +110,10 @@ class SelfPlayAgent(mp.Process):
         self._worker = subprocess.Popen([sys.executable, '-m', 'alphazero_general_amd._engine_worker', listener.address], env=env)
         # accept with a liveness check: a worker that dies before connecting (bad PYTHONPATH, exec failure) must not leave the
         # agent -- and the Coach polling complete_count -- waiting forever
-        listener._listener._socket.settimeout(1.0)
+        try:
+            listener._listener._socket.settimeout(1.0)             # (CPython's Listener keeps its socket here; without it the accept
+        except AttributeError:                                     #  below simply blocks until the worker connects)
+            pass
         deadline = time.time() + float(os.environ.get('AZG_WORKER_START_TIMEOUT', '300'))
         while True:
             try:

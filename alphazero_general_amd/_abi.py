@@ -64,6 +64,8 @@ SYMBOLS = {
     'azg_backup_select': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
     'azg_backup_select_logits': (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i]),
     'azg_backup_select_features': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
+    'azg_leaf_heads_sparse_f16': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    'azg_heads_softmax': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'azg_advance': (_i, [_vp, _vp, _i]),
     'azg_advance_begin': (_i, [_vp, _vp, _i, _i32p]),
     'azg_advance_commit': (_i, [_vp, _vp, _i32p]),
@@ -71,6 +73,7 @@ SYMBOLS = {
     'azg_root_probs': (_i, [_vp, _vp, _f, _vp]),
     'azg_root_value': (_i, [_vp, _vp, _i, _vp]),
     'azg_update_root': (_i, [_vp, _vp, _i, _i]),
+    'azg_compact': (_i, [_vp, _vp, _i, _i]),
     'azg_root_children': (_i, [_vp, _vp, _i, _i, _i, _i32p, _i32p, _f32p, _f32p, _f32p]),
     'azg_node_children': (_i, [_vp, _vp, _i, _i, _i, _i, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p]),
     'azg_reset_max_depth': (_i, [_vp, _vp]),

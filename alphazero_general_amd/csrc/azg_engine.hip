@@ -131,12 +131,14 @@ extern "C" int azg_engine_create(const azg_config *cfg, azg_engine **out) {
     memset(&v, 0, sizeof(v));
     v.B = cfg->num_slots; v.arena = cfg->arena ? 1 : 0; v.T = v.arena ? gi.num_players : 1;
     // node store: two semi-spaces of `cap` nodes per tree (k_compact).  A move adds at most sims_per_move * max_children nodes to
-    // the live space; the default capacity holds eight such moves (the subtree kept across moves is typically one to two moves'
-    // worth; the worst case, a game that never drops a sibling, needs max_turns), and the space is compacted after a move once
-    // fewer than one move's worth of free nodes is left.  Overflow is loud: the sticky AZG_E_TREE_FULL
+    // the live space, and the space is compacted after a move once fewer than one move's worth of free nodes is left.  A search
+    // that carries a fraction f of its visits into the played move keeps about f / (1 - f) moves' worth of nodes across moves:
+    // the default capacity holds min(max_turns, 16) moves' worth (f up to 0.94 sustained; random-init nets keep 0.2-0.5 of ONE
+    // move's worth), the worst case -- a game that never drops a sibling -- needs max_turns, which nodes_per_tree can ask for.
+    // Overflow is loud: the sticky AZG_E_TREE_FULL
     const int sims = cfg->sims_per_move > 0 ? cfg->sims_per_move : 100;
     const long long per_move = (long long)sims * gi.max_children;
-    const long long cap = cfg->nodes_per_tree > 0 ? cfg->nodes_per_tree : 8 * per_move + 64;
+    const long long cap = cfg->nodes_per_tree > 0 ? cfg->nodes_per_tree : (long long)(gi.max_turns < 16 ? gi.max_turns : 16) * per_move + 64;
     if (cap >= (1 << 28)) { delete e; return fail(AZG_E_INVALID_ARG, "nodes_per_tree must be < 2^28"); }
     v.cap = (int)cap;
     v.compact_reserve = (int)(per_move < cap / 2 ? per_move : cap / 2);
@@ -348,6 +350,21 @@ extern "C" int azg_backup_select_features(azg_engine *e, void *stream, const voi
     return AZG_OK;
 }
 
+extern "C" int azg_leaf_heads_sparse_f16(azg_engine *e, void *stream, const void *feat, int feat_k, const void *head_rows, const float *head_b,
+                                         const int32_t *row_of_slot, float *logits, int logits_stride) {
+    if (!e || !feat || !head_rows || !head_b || !logits) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (logits_stride < e->gi.action_size + e->gi.num_players + 1 || e->gi.action_size > 1024)
+        return fail(AZG_E_INVALID_ARG, "logits_stride must hold A + P + 1 logits (A <= 1024)");
+    int want = 0;
+    GAME_SWITCH(e, want = head_fk<G>());
+    if (feat_k != want) return fail(AZG_E_INVALID_ARG, "feat_k must be cells x 16 rounded up to a multiple of 32 for this game");
+    const HeadRows hd{(const _Float16 *)head_rows, head_b, feat_k};
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_leaf_heads_sparse<G>), dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, (const _Float16 *)feat, hd,
+                                      row_of_slot, logits, logits_stride));
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
 extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
     if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
     hipStream_t s = (hipStream_t)stream;
@@ -357,7 +374,7 @@ extern "C" int azg_advance(azg_engine *e, void *stream, int record_history) {
         hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)nullptr);
         hipLaunchKernelGGL((k_emit_samples<G>), dim3(e->v.B, G::NSYM), dim3(64), 0, s, e->v);
         hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
-        hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0);
+        hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0, 0);
     });
     prof_end(e, s, 2, p);
     HIPCHK(hipGetLastError());
@@ -382,7 +399,7 @@ extern "C" int azg_advance_commit(azg_engine *e, void *stream, const int32_t *co
         hipLaunchKernelGGL((k_finalize<G>), dim3(1), dim3(64), 0, s, e->v, (const int32_t *)e->v.fin_counted);
         hipLaunchKernelGGL((k_emit_samples<G>), dim3(e->v.B, G::NSYM), dim3(64), 0, s, e->v);
         hipLaunchKernelGGL((k_emit<G>), dim3(e->v.B), dim3(64), 0, s, e->v);
-        hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0);
+        hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0, 0);
     });
     HIPCHK(hipGetLastError());
     return AZG_OK;
@@ -414,11 +431,23 @@ extern "C" int azg_update_root(azg_engine *e, void *stream, int slot, int action
     int r = check_range(e, slot, 1); if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     GAME_SWITCH(e, hipLaunchKernelGGL((k_update_root<G>), dim3(1), dim3(64), 0, s, e->v, slot, action, e->d_ok));
-    GAME_SWITCH(e, hipLaunchKernelGGL((k_compact<G>), dim3(e->v.B * e->v.T), dim3(64), 0, s, e->v, 0));
+    // (only this slot's trees: a compaction voids the tree's pending find_leaf, and another slot of a per-slot driven engine may
+    //  sit between azg_select and azg_backup)
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_compact<G>), dim3(e->v.T), dim3(64), 0, s, e->v, 0, slot * e->v.T));
     int32_t ok = 0;
     HIPCHK(hipMemcpyAsync(&ok, e->d_ok, sizeof(ok), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (!ok) return fail(AZG_E_INVALID_ACTION, "Invalid action encountered while updating root: " + std::to_string(action));
+    return AZG_OK;
+}
+
+extern "C" int azg_compact(azg_engine *e, void *stream, int slot, int force) {
+    if (!e) return fail(AZG_E_INVALID_ARG, "null engine");
+    if (slot >= e->v.B) return fail(AZG_E_INVALID_ARG, "slot out of range");
+    hipStream_t s = (hipStream_t)stream;
+    const int first = slot < 0 ? 0 : slot * e->v.T, count = slot < 0 ? e->v.B * e->v.T : e->v.T;
+    GAME_SWITCH(e, hipLaunchKernelGGL((k_compact<G>), dim3(count), dim3(64), 0, s, e->v, force ? 1 : 0, first));
+    HIPCHK(hipGetLastError());
     return AZG_OK;
 }
 
@@ -688,10 +717,15 @@ extern "C" int azg_profile_net_read(double *ms3, int64_t *launches3) {
 }
 
 // Boards per workgroup tile: the big tile has the least MFMA padding, small ones fill the chip at small batches (the arena,
-// the single-tree API, brandubh's 512 games per GPU).  AZG_TOWER_BOARDS overrides the choice (measurement knob).
+// the single-tree API, brandubh's 512 games per GPU).  Tuning builds (hipcc -DAZG_TUNING, tools/sweep_small.py) let the
+// environment override the choice: AZG_TOWER_BOARDS, AZG_TOWER_PSPLIT; the product library reads no environment.
 static int dispatch_tower(hipStream_t s, int game, int channels, const TowerParams &P) {
+#ifdef AZG_TUNING
     static const int forced = getenv("AZG_TOWER_BOARDS") ? atoi(getenv("AZG_TOWER_BOARDS")) : 0;
-    static const int psplit = getenv("AZG_TOWER_PSPLIT") ? atoi(getenv("AZG_TOWER_PSPLIT")) : 0;   // measurement knob
+    static const int psplit = getenv("AZG_TOWER_PSPLIT") ? atoi(getenv("AZG_TOWER_PSPLIT")) : 0;
+#else
+    constexpr int forced = 0, psplit = 0;
+#endif
     const int n = P.boards;
     if (game == AZG_GAME_CONNECT4 && channels == 128) {
         const int bt = forced ? forced : n <= 640 ? 1 : n <= 1280 ? 2 : 4;
@@ -852,6 +886,14 @@ extern "C" int azg_policy_value_heads_fact_f16(void *stream, const void *feat, c
     netprof_end(s, 1, prof, ep);
     if (policy)
         AZG_LAUNCH(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, s, (const float *)logits_ws, policy, value, boards, osub * 16, A, NV);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_heads_softmax(void *stream, const float *logits, int boards, int logits_stride, int A, int NV, float *policy, float *value) {
+    if (!logits || !policy || !value) return fail(AZG_E_INVALID_ARG, "null argument");
+    if (boards <= 0 || A <= 0 || A > 1024 || NV <= 0 || NV > 64 || logits_stride < A + NV) return fail(AZG_E_INVALID_ARG, "boards > 0, 0 < A <= 1024, 0 < NV <= 64, stride >= A + NV");
+    hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, policy, value, boards, logits_stride, A, NV);
     HIPCHK(hipGetLastError());
     return AZG_OK;
 }

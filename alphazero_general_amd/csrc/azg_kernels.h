@@ -655,6 +655,30 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
     });
 }
 
+// The sparse heads on their own (one wavefront per slot): the row the IN_FEATURES launch computes for a slot's last leaf -- policy
+// logits of the leaf's children (-inf for every other action), then the P + 1 value logits -- written to logits[row][ld].  The
+// same leaf_policy_logits / leaf_value_logits calls, so softmax + azg_backup_select_logits on this row is bit-identical to
+// azg_backup_select_features; a leaf that takes no evaluation (terminal) gets a row of zeros.
+template <class G>
+__global__ __launch_bounds__(64) void k_leaf_heads_sparse(View ev, const _Float16 *feat, HeadRows hd, const int32_t *row_of_slot, float *logits, int ld) {
+    constexpr int A = G::A, NV = G::P + 1;
+    __shared__ float lg_lds[A + 4];
+    __shared__ __attribute__((aligned(16))) _Float16 feat_lds[head_fk<G>()];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int row = row_of_slot ? row_of_slot[slot] : slot;
+    const int tree = tree_of_slot(ev, slot);
+    HdrR hr; load_hdr(ev.hdr + tree, hr);
+    float *out = logits + (size_t)row * ld;
+    if (hr.leaf_e || hr.leaf_fc < 0) { for (int a = lane; a < A + NV; a += 64) out[a] = 0.f; return; }
+    const _Float16 *frow = feat + (size_t)row * 2 * hd.fk;
+    for (int c = lane; c < head_fk<G>() / 8; c += 64) reinterpret_cast<uint4 *>(feat_lds)[c] = reinterpret_cast<const uint4 *>(frow)[c];
+    wave_sync();
+    leaf_policy_logits<G>(hd, tree_nodes(ev, tree, hr.base), hr.leaf_fc, hr.leaf_k, feat_lds, lg_lds, lane);
+    leaf_value_logits<G>(hd, frow + hd.fk, lg_lds + A, lane);
+    wave_sync();
+    for (int a = lane; a < A + NV; a += 64) out[a] = lg_lds[a];
+}
+
 // ================================================================================================ root stats
 // MCTS.probs (:308-329) of a tree's root into LDS pr[A]; every lane returns.  cnt = LDS float counts.
 template <class G>
@@ -761,9 +785,9 @@ __global__ __launch_bounds__(64) void k_update_root(View ev, int slot, int actio
 // other space -- child blocks stay contiguous and keep their list order, so no result changes -- and the spaces swap roles.
 // One wavefront per tree; 64 nodes of the copy frontier per step (their child blocks are sized with a wave scan).
 template <class G>
-__global__ __launch_bounds__(64) void k_compact(View ev, int force) {
+__global__ __launch_bounds__(64) void k_compact(View ev, int force, int first_tree) {
     if (__builtin_amdgcn_readfirstlane(ev.gcount[GC_ERROR]) != 0) return;
-    const int tree = blockIdx.x, lane = threadIdx.x;
+    const int tree = first_tree + blockIdx.x, lane = threadIdx.x;      // (grid = the trees to look at: all of them, or one slot's)
     TreeHdr *h = ev.hdr + tree;
     HdrR hr; load_hdr(h, hr);
     if (!force && hr.alloc + ev.compact_reserve <= ev.cap) return;

@@ -62,6 +62,8 @@ class DeviceEngine:
             _abi.check(self.L.azg_engine_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self._row_of_slot = None
+        per_move = cfg.sims_per_move * gi.max_children
+        self._nodes_cap = int(nodes_per_tree) if nodes_per_tree > 0 else min(gi.max_turns, 16) * per_move + 64
 
     def close(self):
         if getattr(self, 'h', None):
@@ -197,6 +199,26 @@ class DeviceEngine:
         _abi.check(self.L.azg_backup_select_features(self.h, _stream(), _ptr(feat), int(fk), _ptr(head_rows), _ptr(head_b), _ptr(row_of_slot),
                                                      flags, _ptr(obs), dt, int(bool(select))))
 
+    def leaf_heads_sparse(self, feat, head_rows, head_b, row_of_slot=None, out=None):
+        """The sparse heads as their own launch: logits [rows, ld] f32 of every slot's last leaf -- A policy logits (-inf off the
+        leaf's valid actions) then P + 1 value logits -- exactly what backup_select_features computes internally."""
+        assert feat.is_cuda and feat.dtype == torch.float16 and feat.is_contiguous() and feat.shape[1] % 2 == 0
+        fk = feat.shape[1] // 2
+        assert head_rows.is_cuda and head_rows.dtype == torch.float16 and head_rows.is_contiguous() and tuple(head_rows.shape) == (self.A + self.NV, fk)
+        ld = (self.A + self.NV + 15) // 16 * 16
+        if out is None:
+            out = torch.zeros((feat.shape[0], ld), dtype=torch.float32, device=self.device)
+        _abi.check(self.L.azg_leaf_heads_sparse_f16(self.h, _stream(), _ptr(feat), int(fk), _ptr(head_rows), _ptr(head_b), _ptr(row_of_slot),
+                                                    _ptr(out), int(out.shape[1])))
+        return out
+
+    def heads_softmax(self, logits):
+        """(policy [rows, A], value [rows, P + 1]) probabilities of logits rows (azg_heads_softmax: the network's own softmax launch)."""
+        pol = torch.empty((logits.shape[0], self.A), dtype=torch.float32, device=self.device)
+        val = torch.empty((logits.shape[0], self.NV), dtype=torch.float32, device=self.device)
+        _abi.check(self.L.azg_heads_softmax(_stream(), _ptr(logits), int(logits.shape[0]), int(logits.shape[1]), self.A, self.NV, _ptr(pol), _ptr(val)))
+        return pol, val
+
     def advance(self, record_history=True):
         _abi.check(self.L.azg_advance(self.h, _stream(), int(bool(record_history))))
 
@@ -229,6 +251,14 @@ class DeviceEngine:
 
     def update_root(self, slot, action):
         _abi.check(self.L.azg_update_root(self.h, _stream(), int(slot), int(action)))
+
+    def compact(self, slot=-1, force=True):
+        """reclaim the nodes outside the subtree under the root (slot -1: every slot).  Never between select and backup."""
+        _abi.check(self.L.azg_compact(self.h, _stream(), int(slot), int(bool(force))))
+
+    @property
+    def nodes_per_tree(self):
+        return int(self._nodes_cap)
 
     def root_children(self, slot, tree=0):
         K = max(self.gi.max_children, 1)

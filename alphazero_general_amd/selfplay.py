@@ -230,6 +230,9 @@ class SelfPlayRunner:
     def run(self, games=None, max_rounds=None, poll_every=1):
         """Play rounds until `games` (default args.gamesPerIteration) games have finished.  Returns counters."""
         games = int(self.args.get('gamesPerIteration') if games is None else games)
+        cap = int(self.args.get('gamesPerIteration', 1 << 30))
+        if games > cap:                                              # the lanes' quotas sum to gamesPerIteration: more can never be counted
+            raise ValueError('run(games=%d) exceeds args.gamesPerIteration=%d, the cap the engines were created with' % (games, cap))
         t0 = time.time()
         rounds = 0
         while True:
@@ -295,7 +298,7 @@ class ArenaRunner:
     (wins, draws, winrates) contract of Arena.play_games (:376) via get_game_results semantics (utils.py:34-54)."""
 
     def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None, use_graph=True, result_capacity=None,
-                 seats='agent'):
+                 seats='agent', nodes_per_tree=0):
         self.game_cls, self.nnets, self.args = game_cls, list(nnets), args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -313,7 +316,7 @@ class ArenaRunner:
                                    fpu_reduction=args.get('fpu_reduction', 0.2), arena_temp=args.get('arenaTemp', 0.25),
                                    games_per_iteration=int(args.get('gamesPerIteration', 1 << 30)), seed=seed,
                                    slot_base=slot_base, device=device, sims_hint=int(args.get('numMCTSSims', 100)),
-                                   result_capacity=int(result_capacity if result_capacity is not None else
+                                   nodes_per_tree=nodes_per_tree, result_capacity=int(result_capacity if result_capacity is not None else
                                                        min(int(args.get('gamesPerIteration', 1 << 30)), 1 << 20) + 4 * self.B + 1024))
         e = self.engine
         # seats = 'agent': the one permutation above for every game (the reference, SelfPlayAgent.pyx:44-47);

@@ -38,7 +38,8 @@ from alphazero_general_amd.selfplay import ArenaRunner, SelfPlayRunner  # noqa: 
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
+PMC_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc.json' % r) for r in (3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, 'profiles', 'r03_pmc.json'))
 CALIBRATION_FILE = os.path.join(ROOT, 'profiles', 'cpu_oracle_vs_reference.json')
 
 # name: game module, net args, games / GPU, sims / move, cpuct, fpu reduction, typical (children, depth) of the tree bytes model
@@ -102,11 +103,12 @@ def measured_traffic(workload, kernel_substr):
     MI355X_MICROARCH.md 'HBM': FETCH_SIZE counts half the bytes of wide loads on gfx950).  None when no profile is committed."""
     pmc = load_json(PMC_FILE)
     if not pmc:
-        return None, None
+        return None, None, None
     for name, rec in pmc.get('workloads', {}).get(workload, {}).items():
         if kernel_substr in name:
-            return int(rec['traffic_bytes']), 'profiles/r02_pmc.json @%s (%d dispatches)' % (pmc.get('git', '?'), rec.get('dispatches', 0))
-    return None, None
+            return (int(rec['traffic_bytes']), 'profiles/%s @%s (%d dispatches)' % (os.path.basename(PMC_FILE), pmc.get('git', '?'), rec.get('dispatches', 0)),
+                    rec.get('mfma_busy_cycles'))
+    return None, None, None
 
 
 def library_gemm_tflops(dev, n=8192, reps=10):
@@ -217,121 +219,121 @@ def self_launch(n):
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=45)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--slots', type=int, default=0)
-    ap.add_argument('--workload', default='connect4', choices=sorted(WORKLOADS))
-    ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--pipelines', type=int, default=1)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-library-gemm', action='store_true', help='skip the hipBLASLt context GEMM (keeps profiler traces to our own kernels)')
-    ap.add_argument('--no-fused-search', action='store_true',
-                    help='2 launches per simulation (tower, backup+select) instead of one persistent launch per move (azg_search_f16)')
-    a = ap.parse_args()
+class Ctx:
+    """one workload set up on this rank's GPU: runner, network(s), engines"""
 
-    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        return self_launch(a.gpus)                                    # one rank per GPU under torch.distributed.run
-    rank, local_rank, world = D.init_from_env()
-    assert world == a.gpus, '--gpus %d but %d rank(s) were launched (torch.distributed.run --nproc-per-node must equal --gpus)' % (a.gpus, world)
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device (there is no CPU fallback)'
-    if not os.environ.get('AZG_SINGLE_DEVICE'):
-        assert torch.cuda.device_count() >= world, '%d ranks but only %d visible GPU(s)' % (world, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
 
+def build(workload, a, rank, local_rank, dev, rounds):
     import importlib
-    W = dict(WORKLOADS[a.workload])
-    B = W['B'] = a.slots or W['B']
-    sims = W['sims']
-    Game = importlib.import_module('alphazero_general_amd.envs.' + W['game']).Game
+    c = Ctx()
+    c.name = workload
+    c.W = W = dict(WORKLOADS[workload])
+    c.B = W['B'] = (a.slots if workload == a.workload else 0) or W['B']
+    c.sims = W['sims']
+    c.Game = Game = importlib.import_module('alphazero_general_amd.envs.' + W['game']).Game
     netargs = getattr(nn_mod, W['net'])
-    arena = a.workload == 'arena'
+    c.arena = workload == 'arena'
     args = selfplay_args(W)
     nsym = len(Game().symmetries(np.zeros(Game.action_size(), np.float32)))
-    rounds = a.steps + a.warmup + 8
-    if arena:
-        nets = []
+    c.pipelines = a.pipelines if workload == a.workload else 1
+    if c.arena:
+        c.nets = []
         for sd in (0, 1):                                            # two differently seeded random-init nets (SURVEY.md 8d config 4)
             torch.manual_seed(sd)
-            nets.append(NNetWrapper(Game, netargs, device=dev, dtype=torch.float16))
-        net = nets[0]
-        runner = ArenaRunner(Game, nets, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
-                             use_graph=not a.no_graph, result_capacity=B * rounds // 5 + 2 * B)
-        engines = [runner.engine]
-        counters = runner.engine.counters
-        fused_search = False
+            c.nets.append(NNetWrapper(Game, netargs, device=dev, dtype=torch.float16))
+        c.net = c.nets[0]
+        c.runner = ArenaRunner(Game, c.nets, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
+                               use_graph=not a.no_graph, result_capacity=c.B * rounds // 5 + 2 * c.B)
+        c.engines = [c.runner.engine]
+        c.counters = c.runner.engine.counters
+        c.fused_search = False
     else:
         torch.manual_seed(0)                                         # same random-init weights on every rank
-        net = NNetWrapper(Game, netargs, device=dev, dtype=torch.float16)
+        c.net = NNetWrapper(Game, netargs, device=dev, dtype=torch.float16)
+        c.nets = [c.net]
         per_game = (Game.max_turns() + 1) * nsym
-        runner = SelfPlayRunner(Game, net, args, num_slots=B, seed=0, slot_base=D.slot_base(rank, B), device=local_rank,
-                                use_graph=not a.no_graph, pipelines=a.pipelines,
-                                fused_search=False if (a.no_fused_search or a.pipelines > 1) else None,
-                                example_capacity=int(B * rounds / 5.0 + 2 * B) * per_game)
-        engines = [ln.engine for ln in runner.lanes]
-        counters = runner.counters
-        fused_search = bool(runner.fused_search)
-        runner.prepare()                                             # graph capture stays out of the timed region even at --warmup 0
-    hipnet = net._hip is not None
-    for _ in range(a.warmup):
-        runner.play_round()
-    c0 = counters()
-    ex0 = [e.counters()['num_examples'] for e in engines] if not arena else None
-    netprof, prof = {}, None
-    if world > 1 and not arena:                                      # (the collectives' one-time set-up stays out of the timed region)
-        o_, p_, z_ = runner.samples(ex0)
+        c.runner = SelfPlayRunner(Game, c.net, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
+                                  use_graph=not a.no_graph, pipelines=c.pipelines,
+                                  fused_search=False if (a.no_fused_search or c.pipelines > 1) else None,
+                                  example_capacity=int(c.B * rounds / 5.0 + 2 * c.B) * per_game)
+        c.engines = [ln.engine for ln in c.runner.lanes]
+        c.counters = c.runner.counters
+        c.fused_search = bool(c.runner.fused_search)
+        c.runner.prepare()                                           # graph capture stays out of the timed region even at --warmup 0
+    return c
+
+
+def timed_region(c, steps, warmup, world, rank):
+    """W warm-up rounds, then EXACTLY `steps` rounds -- every one the product's launch form (a replayed hipGraph unless --no-graph)
+    -- and the iteration's exchange step, bracketed by barrier + synchronize; nothing else runs inside."""
+    for _ in range(warmup):
+        c.runner.play_round()
+    c0 = c.counters()
+    ex0 = [e.counters()['num_examples'] for e in c.engines] if not c.arena else None
+    if world > 1 and not c.arena:                                    # (the collectives' one-time set-up stays out of the timed region)
+        o_, p_, z_ = c.runner.samples(ex0)
         D.all_gather_examples(o_[:1], p_[:1], z_[:1])
     D.barrier(); torch.cuda.synchronize()
     t0 = time.time()
-    for k in range(a.steps):
-        second = fused_search and k == a.steps // 2 + 1
-        # (a round of the persistent launch costs the same launched eagerly as replayed from its graph -- six launches -- so
-        #  every eighth one is launched eagerly with events around it: `launches_timed` persistent launches, not one)
-        timed = a.pipelines == 1 and (k == a.steps // 2 or second or (fused_search and k % 8 == 4))
-        if not timed:
-            runner.play_round()
-            continue
-        # an eagerly launched round with HIP events (on the launch stream) around every launch: the same launch sequence the
-        # graph replays.  With the persistent search launch: such rounds, plus one round of the two-launches-per-simulation
-        # form of the same move loop, which shows the tree launch and the tower launch on their own
+    for _ in range(steps):
+        c.runner.play_round()
+    torch.cuda.synchronize()
+    t_search = time.time() - t0                                      # this rank's own rounds (before it waits for anybody)
+    c1 = c.counters()
+    nsamples = 0
+    if not c.arena:                                                  # the exchange step of an iteration: all-gather the example shards
+        obs, pi, z = c.runner.samples(ex0)
+        gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
+        nsamples = gobs.shape[0]
+    tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'],
+                                 c1['games_played'] - c0['games_played'], nsamples if rank == 0 else 0])
+    torch.cuda.synchronize()
+    t_exchange = time.time() - t0 - t_search
+    D.barrier()
+    dt = D.max_over_ranks(time.time() - t0)
+    r = dict(dt=dt, steps=steps, rank_ms_per_step_max=D.max_over_ranks(t_search) * 1e3 / steps,
+             rank_ms_per_step_min=-D.max_over_ranks(-t_search) * 1e3 / steps, exchange_ms=D.max_over_ranks(t_exchange) * 1e3)
+    r['expansions'], r['sims'], r['games'], r['samples'] = [int(x) for x in tall]
+    return r
+
+
+def profile_rounds(c, persistent_rounds=3):
+    """OUTSIDE the timed region: rounds launched eagerly with the library's profile hooks on (single kernels go through
+    hipExtLaunchKernelGGL, whose events carry the dispatch's own begin / end timestamps).  With a persistent search launch:
+    `persistent_rounds` rounds of it, then ONE round of the launch-per-phase form of the same move loop, which shows the tree
+    launch and the tower launch on their own; otherwise one round."""
+    netprof, prof = {}, None
+    if c.pipelines != 1:
+        return netprof, prof
+    kinds = ['search'] * persistent_rounds + ['phase'] if c.fused_search else ['phase']
+    for kind in kinds:
         torch.cuda.synchronize()
-        if second:
-            runner.fused_search = False
-        engines[0].profile(True); HipResNet.profile(True)
-        runner.play_round(eager=True)
+        if c.fused_search and kind == 'phase':
+            c.runner.fused_search = False
+        c.engines[0].profile(True); HipResNet.profile(True)
+        c.runner.play_round(eager=True)
         for kk, vv in HipResNet.profile_read().items():             # (GPU ms and launch counts per family: tower, wide heads, search)
             netprof[kk] = netprof.get(kk, 0) + vv
         HipResNet.profile(False)
-        if second or not fused_search:
-            prof = engines[0].profile_read()
-        engines[0].profile(False)
-        if second:
-            runner.fused_search = True
-    c1 = counters()
-    nsamples = 0
-    if not arena:                                                    # the exchange step of an iteration: all-gather the example shards
-        obs, pi, z = runner.samples(ex0)
-        gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
-        nsamples = gobs.shape[0]
-    torch.cuda.synchronize(); D.barrier()
-    dt = D.max_over_ranks(time.time() - t0)
-    tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'],
-                                 c1['games_played'] - c0['games_played'], nsamples if rank == 0 else 0])
-    if rank != 0:
-        return 0
-    expansions, nsims, games_done, nsamples = [int(x) for x in tall]
-    Bl = B // a.pipelines                                            # slots per launch
+        if kind == 'phase':
+            prof = c.engines[0].profile_read()
+        c.engines[0].profile(False)
+        if c.fused_search and kind == 'phase':
+            c.runner.fused_search = True
+    torch.cuda.synchronize()
+    return netprof, prof
 
-    # ---- roofline of the network launch (MFMA) and of the tree launch (HBM), from the eager rounds' events
+
+def rooflines(c, netprof, prof):
+    """roofline of the network launch (MFMA) and of the tree launch (HBM) from the profile rounds' events"""
+    W, Game, net, arena, sims = c.W, c.Game, c.net, c.arena, c.sims
+    Bl = c.B // c.pipelines                                          # slots per launch
     flops_leaf = net_flops_per_leaf(Game, net.args)
 
     def issued_frac():
         """MFMA work the 4-board connect4 tile actually issues / the algorithmic count: border-class subtiles drop the taps
-        that only read zero padding -- 81 of 99 subtile-taps, on 176 lanes for 168 pixels"""
-        if a.workload != 'connect4':
+        that only read zero padding, on 176 lanes for 168 pixels"""
+        if c.name != 'connect4':
             return None
         _, H, Wd = Game.observation_size()
         sub = lambda n: (n + 15) // 16
@@ -344,11 +346,18 @@ def main():
             return None
         us = netprof[fam + '_ms'] * 1e3 / n
         tf = flops_leaf * units / (us * 1e-6) / 1e12
-        traffic, src = measured_traffic(a.workload, kmatch)
-        return {'kernel': kname, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
-                'algorithmic_flops_per_launch': flops_leaf * units, 'mfma_issued_over_algorithmic': issued_frac(),
-                'traffic': traffic, 'traffic_source': src}
+        traffic, src, busy = measured_traffic(c.name, kmatch)
+        r = {'kernel': kname, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+             'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
+             'algorithmic_flops_per_launch': flops_leaf * units, 'mfma_issued_over_algorithmic': issued_frac(),
+             'traffic': traffic, 'traffic_source': src}
+        if busy:
+            # FLOPs the MFMA pipes really executed in the profiled launch (SQ_VALU_MFMA_BUSY_CYCLES / 16 cycles per v_mfma_f32_16x16x32_f16
+            # x 16 384 FLOP) over THIS run's launch time: what `frac` would be without credit for the skipped zero products
+            ex = busy / 16.0 * 16384.0
+            r['executed_flops_per_launch'] = ex
+            r['executed_frac'] = round(ex / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+        return r
 
     skind = ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else ('Wide', W['game'], 'azg_search_wide_f16')
     roof_search = mfma_roof('search', 'k_tower2<...,Search%s<%s>> (%s: %d x [find_leaf, ResNet + heads, backup] on every game, one persistent launch '
@@ -364,7 +373,7 @@ def main():
         sel_b, bak_b, shared_b = tree_bytes_per_sim(Game, W, feat_k)
         us = prof['backup_ms'] * 1e3 / prof['backup_n']              # backup k + select k + 1 share a launch
         gbs = ((sel_b + bak_b) * Bl + shared_b) / (us * 1e-6) / 1e9
-        traffic, src = measured_traffic(a.workload, 'k_backup_select2')
+        traffic, src, _ = measured_traffic(c.name, 'k_backup_select2')
         roof_tree = {'kernel': 'k_backup_select2 (process_results of simulation k + find_leaf of k + 1, two wavefronts per tree%s)'
                                % (', sparse heads on the head features' if feat_k else ''),
                      'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 6),
@@ -379,18 +388,72 @@ def main():
         roofline = roof_net if roof_net['avg_launch_us'] >= roof_tree['avg_launch_us'] else roof_tree
     else:
         roofline = roof_net or roof_tree
+    return roofline, roof_tree, roof_net
+
+
+def workload_label(c):
+    return '%s %s, %d games/GPU x %d sims/move, fp16 ResNet %dch x %d, random-init, %s' % (
+        c.W['game'], 'arena (two nets)' if c.arena else 'self-play', c.B, c.sims, c.net.args.num_channels, c.net.args.depth,
+        'arenaTemp 0.25' if c.arena else 'noise+temp on')
+
+
+def release(c):
+    for e in c.engines:
+        e.close()
+    c.runner = c.engines = c.net = c.nets = None
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=45)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--slots', type=int, default=0)
+    ap.add_argument('--workload', default='connect4', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--pipelines', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-library-gemm', action='store_true', help='skip the hipBLASLt context GEMM (keeps profiler traces to our own kernels)')
+    ap.add_argument('--no-fused-search', action='store_true',
+                    help='2 launches per simulation (tower, backup+select) instead of one persistent launch per move (azg_search_f16)')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='skip the short runs of BASELINE configs 3-5 that the default (connect4, 1 GPU) line carries as other_workloads')
+    ap.add_argument('--profile-rounds', type=int, default=3, help='eager rounds of the persistent launch timed after the timed region')
+    a = ap.parse_args()
+
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(a.gpus)                                    # one rank per GPU under torch.distributed.run
+    rank, local_rank, world = D.init_from_env()
+    assert world == a.gpus, '--gpus %d but %d rank(s) were launched (torch.distributed.run --nproc-per-node must equal --gpus)' % (a.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (there is no CPU fallback)'
+    if not os.environ.get('AZG_SINGLE_DEVICE'):
+        assert torch.cuda.device_count() >= world, '%d ranks but only %d visible GPU(s)' % (world, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    c = build(a.workload, a, rank, local_rank, dev, a.steps + a.warmup + a.profile_rounds + 8)
+    t = timed_region(c, a.steps, a.warmup, world, rank)
+    netprof, prof = profile_rounds(c, a.profile_rounds)              # after the timed region
+    if rank != 0:
+        return 0
+    roofline, roof_tree, roof_net = rooflines(c, netprof, prof)
+    dt = t['dt']
     out = {
-        'metric': 'mcts_node_expansions_per_sec', 'value': round(expansions / dt, 1), 'unit': 'expansions/s',
+        'metric': 'mcts_node_expansions_per_sec', 'value': round(t['expansions'] / dt, 1), 'unit': 'expansions/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt * 1e3 / a.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net', 'data': 'synthetic',
-        'config': {'workload': '%s %s, %d games/GPU x %d sims/move, fp16 ResNet %dch x %d, random-init, %s'
-                               % (W['game'], 'arena (two nets)' if arena else 'self-play', B, sims, net.args.num_channels, net.args.depth,
-                                  'arenaTemp 0.25' if arena else 'noise+temp on'),
-                   'games_per_gpu': B, 'sims_per_move': sims, 'hipgraph_rounds': not a.no_graph, 'stream_pipelines': a.pipelines,
-                   'fused_search_launch': fused_search, 'mfma_tower': hipnet, 'ranks': world,
+        'config': {'workload': workload_label(c),
+                   'games_per_gpu': c.B, 'sims_per_move': c.sims, 'hipgraph_rounds': not a.no_graph, 'stream_pipelines': a.pipelines,
+                   'fused_search_launch': c.fused_search, 'mfma_tower': c.net._hip is not None, 'ranks': world,
                    'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
-        'games_per_sec': round(games_done / dt, 2), 'simulations_per_sec': round(nsims / dt, 1),
-        'games_finished': games_done, 'samples_gathered': nsamples,
+        'games_per_sec': round(t['games'] / dt, 2), 'simulations_per_sec': round(t['sims'] / dt, 1),
+        'games_finished': t['games'], 'samples_gathered': t['samples'],
+        # where the step time of an N-rank run goes: the slowest / fastest rank's own rounds, and the iteration's exchange step
+        # (example all-gather + tallies, once per timed region)
+        'rank_ms_per_step': {'max': round(t['rank_ms_per_step_max'], 3), 'min': round(t['rank_ms_per_step_min'], 3)},
+        'exchange_ms': round(t['exchange_ms'], 3),
         'roofline': roofline, 'tree_roofline': roof_tree,
     }
     if roof_net is not None and roofline is not roof_net:
@@ -400,7 +463,25 @@ def main():
         roofline['library_gemm_tflops'] = round(lib_tf, 1)
         roofline['vs_library_gemm'] = round(roofline['achieved'] / lib_tf, 3)
     if world == 1 and not a.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(W, nets if arena else [net], arena)
+        out['cpu_baseline'] = cpu_baseline(c.W, c.nets, c.arena)
+    if world == 1 and a.workload == 'connect4' and not a.no_other_workloads and not a.slots:
+        # BASELINE configs 3-5 at their per-GPU size: 8 graph-replayed rounds each after 2 warm-up rounds (their own full lines:
+        # --workload NAME; profiles/r03_bench_*.json)
+        release(c)
+        others = {}
+        for name in ('brandubh', 'arena', 'trimok'):
+            oc = build(name, a, rank, local_rank, dev, 8 + 2 + 2 + 8)
+            ot = timed_region(oc, 8, 2, world, rank)
+            onp, opf = profile_rounds(oc, 1)
+            orf, otr, _ = rooflines(oc, onp, opf)
+            others[name] = {'workload': workload_label(oc), 'value': round(ot['expansions'] / ot['dt'], 1), 'unit': 'expansions/s',
+                            'games_per_sec': round(ot['games'] / ot['dt'], 2), 'steps': 8, 'warmup': 2,
+                            'ms_per_step': round(ot['dt'] * 1e3 / 8, 3), 'fused_search_launch': oc.fused_search,
+                            'roofline': None if orf is None else {k: orf[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                                                     'avg_launch_us', 'launches_timed', 'traffic')},
+                            'tree_launch_us': None if otr is None else otr['avg_launch_us']}
+            release(oc)
+        out['other_workloads'] = others
     print(json.dumps(out))
     return 0
 

@@ -186,6 +186,11 @@ int  azg_root_probs(azg_engine *e, void *stream, float temp, float *probs_dev /*
 int  azg_root_value(azg_engine *e, void *stream, int average, float *value_dev /*[B]*/);          /* MCTS.value  :331-344 */
 /* MCTS.update_root(gs, a) (:185-195) on one slot's tree(s); the game state itself is NOT advanced. blocking. */
 int  azg_update_root(azg_engine *e, void *stream, int slot, int action);
+/* Node reclamation on demand: copy the subtree under the root of the slot's tree(s) (slot < 0: every slot) into the other
+ * semi-space and drop everything else -- what azg_advance / azg_update_root do by themselves once less than one move's worth
+ * of nodes is free.  force = 0: only trees that are that full.  Must not be called between a find_leaf and its process_results
+ * (azg_select .. azg_backup): the pending leaf's indices are void afterwards.  Results never change. */
+int  azg_compact(azg_engine *e, void *stream, int slot, int force);
 /* children of a slot's root in list order (Node._children): a, n, q, p, v.  blocking; returns k or <0. */
 int  azg_root_children(azg_engine *e, void *stream, int slot, int tree, int max_k, int32_t *a, int32_t *n, float *q, float *p, float *v);
 /* children of an arbitrary node (node < 0: the root) incl. their node indices, for tree walks
@@ -289,6 +294,20 @@ int  azg_resnet_tower_features_f16(void *stream, int game, const void *x_dev, co
 int  azg_policy_value_heads_fact_f16(void *stream, const void *feat_dev, const void *wp_packed_dev, const void *wv_packed_dev,
                                      const float *head_b_dev, int boards, int feat_k, int A, int NV, float *logits_ws_dev,
                                      float *policy_dev, float *value_dev);
+
+/* The sparse heads as their own launch: for every slot's last leaf (the one azg_select / azg_backup_select* left), the logits row
+ * azg_backup_select_features computes internally -- the P + 1 value logits and the policy logits of the leaf's valid actions from
+ * the board's head features, -inf for every other action -- into logits_dev[row][logits_stride] (A policy logits, then P + 1 value
+ * logits; a terminal leaf, which takes no evaluation, gets zeros).  Same arithmetic, so azg_heads_softmax + azg_backup /
+ * azg_backup_select_logits on these rows reproduce azg_backup_select_features bit for bit: the evaluation a leaf receives on
+ * the sparse-heads path (NNetWrapper.process masked to the valid moves, MCTS.pyx:239-245), exposed for callers and for parity
+ * tests against the CPU oracle.  Arguments as azg_backup_select_features. */
+int  azg_leaf_heads_sparse_f16(azg_engine *e, void *stream, const void *feat_dev, int feat_k, const void *head_rows_dev,
+                               const float *head_b_dev, const int32_t *row_of_slot, float *logits_dev, int logits_stride);
+/* exp(log_softmax) of NNetArchitecture.py:112-118 on rows of logits (A policy logits then NV value logits, stride
+ * logits_stride): policy f32 [boards, A], value f32 [boards, NV] -- the second launch of azg_policy_value_heads_*_f16 by itself. */
+int  azg_heads_softmax(void *stream, const float *logits_dev, int boards, int logits_stride, int A, int NV, float *policy_dev,
+                       float *value_dev);
 
 /* Host-side layout tables of one tower instantiation (no device needed; for tests and tooling): pixmap[NSUB*16] = pixel of
  * (subtile, lane & 15) or -1, qrow[ROWS] = padded LDS row of pixel p, info8 = {NSUB, ROWS, row stride B, tile rows, tile bytes,

@@ -186,7 +186,8 @@ def test_node_reclamation_is_invisible(game, B, sims, moves):
 
 def test_brandubh_4096_games_fit_one_gpu():
     """BASELINE config 3's WHOLE job (4096 games x 200 simulations) on one GPU: with reclaimed node stores the trees take
-    4096 x 2 x 153 664 nodes x 32 B = 40 GB (round 1: 82 MB per tree = 336 GB, did not fit).  A short run, properties only."""
+    4096 x 2 x 307 264 nodes x 32 B = 81 GB (16 moves' worth per semi-space; round 1: 82 MB per tree = 336 GB, did not fit).  A short
+    run, properties only."""
     import torch
     from alphazero_general_amd.engine import DeviceEngine
     B, sims = 4096, 200
@@ -201,9 +202,86 @@ def test_brandubh_4096_games_fit_one_gpu():
         eng.backup(pol, val)
         eng.advance(True)
     c = eng.counters()
-    assert c['sims'] == 2 * 25 * B and 0 < c['max_nodes_used'] <= 8 * sims * 96 + 64
+    assert c['sims'] == 2 * 25 * B and 0 < c['max_nodes_used'] <= 16 * sims * 96 + 64
     assert all(t == 2 for (_, _, t) in eng.get_states(B - 4, 4))
     eng.close()
+
+
+@pytest.mark.parametrize('game,sims,B', [(0, 100, 256), (1, 60, 48)])
+def test_sharp_policy_whole_games_fit_the_default_node_store(game, sims, B):
+    """A trained, sharp network carries most of a search's visits into the played move, so the subtree kept across moves grows to
+    f / (1 - f) moves' worth of nodes (the reference keeps it on the Python heap, MCTS.pyx:185-195).  Synthetic evaluator: 0.95 of
+    the prior mass on ONE action per slot at every leaf (renormalised over the legal moves), flat value -- whole games at the
+    default nodes_per_tree must finish without AZG_E_TREE_FULL; how many moves' worth of nodes a compaction kept is recorded."""
+    import json
+    import os
+    import torch
+    from alphazero_general_amd import _abi
+    from alphazero_general_amd.engine import DeviceEngine
+    gi = _abi.game_info(game)
+    A, NV = gi.action_size, gi.num_players + 1
+    eng = DeviceEngine(game, B, cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=8, sims_hint=sims,
+                       games_per_iteration=1 << 30, example_capacity=B * 4 * (gi.max_turns + 1) * gi.num_symmetries)
+    g = torch.Generator(device='cpu'); g.manual_seed(4)
+    val = torch.full((B, NV), 1.0 / NV, device=eng.device)
+    obs = eng.new_obs(torch.float16)
+    rounds = gi.max_turns + 8
+    for mv in range(rounds):
+        if mv % 6 == 0:                                                  # the favoured action moves now and then (it may be illegal)
+            fav = torch.randint(0, A, (B,), generator=g)
+            pol = torch.full((B, A), 0.05 / (A - 1))
+            pol[torch.arange(B), fav] = 0.95
+            pol = pol.to(eng.device)
+        eng.select(obs)
+        for s in range(sims):
+            if s + 1 < sims:
+                eng.backup_select(pol, val, obs)
+            else:
+                eng.backup(pol, val)
+        eng.advance(True)
+    c = eng.counters()                                                   # raises on a sticky AZG_E_TREE_FULL
+    per_move = sims * gi.max_children
+    assert c['sims'] == B * sims * rounds and c['games_played'] >= B // 2
+    assert c['max_nodes_used'] <= eng.nodes_per_tree
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/nn_error.jsonl', 'a') as fh:
+        fh.write(json.dumps({'test': 'sharp_policy_node_store', 'game': game, 'slots': B, 'sims': sims, 'rounds': rounds,
+                             'nodes_per_tree': eng.nodes_per_tree, 'max_nodes_used': c['max_nodes_used'], 'max_nodes_kept': c['max_nodes_kept'],
+                             'kept_in_moves_worth': round(c['max_nodes_kept'] / per_move, 3),
+                             'used_in_moves_worth': round(c['max_nodes_used'] / per_move, 3)}) + '\n')
+    eng.close()
+
+
+def test_mcts_class_keeps_searching_at_one_root():
+    """search() with far more simulations than args.numMCTSSims promised (the engine's reclamation reserve is sized from that hint):
+    update_root then leaves less room than the next search needs, and find_leaf's forced compaction must reclaim the played
+    moves' dead siblings in time -- same trees as an engine whose store never fills."""
+    from alphazero_general_amd.MCTS import MCTS
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.utils import dotdict
+    args = dotdict(root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1, fpu_reduction=0.2, cpuct=1.25, _num_players=3,
+                   numMCTSSims=10, _azg_seed=77)
+    small, big = MCTS(args), MCTS(args)
+    g = Game()
+    step = [0]
+
+    def nn(obs):
+        p, v = ol.fake_eval(77, 0, step[0], 7, 3)
+        step[0] += 1
+        return p, v
+    small._ensure(g); big._ensure(g)
+    small._engine.close()
+    from alphazero_general_amd.engine import DeviceEngine
+    small._engine = DeviceEngine(0, 1, cpuct=1.25, fpu_reduction=0.2, seed=77, sims_hint=10, nodes_per_tree=2000)  # < 3 moves' worth
+    for mv in range(8):
+        step[0] = 1000 * mv
+        small.search(g, nn, 100, False, False)
+        step[0] = 1000 * mv
+        big.search(g, nn, 100, False, False)
+        assert (small.counts(g) == big.counts(g)).all(), mv
+        a = big.best_action(g)
+        small.update_root(g, a); big.update_root(g, a)
+        g.play_action(a)
 
 
 @pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200), ('brandubh', 1, 2),

@@ -106,29 +106,37 @@ def test_c4_reference_test_data_on_device():
         assert bool(e & 1) == (winner == 1) and bool(e & 2) == (winner == -1), i
         assert (np.sort(eng.root_children(i)['a']) == np.flatnonzero(b[0] == 0)).all(), i     # columns whose top cell is free
     eng.close()
-    # move lists played on the device: one slot per list, the tree steered move by move (advance needs a search, so the moves are
-    # applied through find_leaf descents: every prefix is set as a root, its successor read back as the leaf)
-    lists = [[4, 5, 4, 3, 0, 6]] + [list(mv[mv >= 0]) for mv in d['vm_moves']]
-    expect_valid = [None] + list(d['vm_expected'])
-    for mv, ev in zip(lists, expect_valid):
-        eng = _engine(C4, 1)
-        cells = np.zeros(42, np.int8)
-        for t, a in enumerate(mv):
-            eng.set_states([(cells, t % 2, t)])
-            eng.select(None)
-            pol = np.full((1, 7), 1e-4, np.float32); pol[0, a] = 0.9
-            eng.backup(torch.from_numpy(pol).to(eng.device), torch.full((1, 3), 1 / 3, device=eng.device))
-            eng.select(None)
-            assert list(eng.last_path(0)) == [a]
-            cells = eng.get_leaf_states()[0][0].copy()
-        eng.set_states([(cells, len(mv) % 2, len(mv))])
+    # :31-39 the move list [4, 5, 4, 3, 0, 6] played on the device (every prefix set as a root, the tree steered onto the next move, its
+    # successor read back as the leaf) must give the reference's board
+    eng = _engine(C4, 1)
+    cells = np.zeros(42, np.int8)
+    for t, a in enumerate([4, 5, 4, 3, 0, 6]):
+        eng.set_states([(cells, t % 2, t)])
         eng.select(None)
-        if ev is None:
-            assert (cells.reshape(6, 7) == d['moves_board']).all()
-        else:
-            v = np.zeros(7, np.uint8); v[eng.root_children(0)['a']] = 1
-            assert (v == ev).all()
-        eng.close()
+        pol = np.full((1, 7), 1e-4, np.float32); pol[0, a] = 0.9
+        eng.backup(torch.from_numpy(pol).to(eng.device), torch.full((1, 3), 1 / 3, device=eng.device))
+        eng.select(None)
+        assert list(eng.last_path(0)) == [a]
+        cells = eng.get_leaf_states()[0][0].copy()
+    assert (cells.reshape(6, 7) == d['moves_board']).all()
+    eng.close()
+    # :58-64 valid-move table.  The reference's test keeps dropping stones after a four-in-a-row (its Board does not stop), which a
+    # search never does, so these boards are built on the host (a stone falls to the lowest free cell of its column, +1 / -1
+    # alternating) and the device answers valid_moves for them
+    lists = [[int(x) for x in mv[mv >= 0]] for mv in d['vm_moves']]
+    boards = []
+    for mv in lists:
+        b = np.zeros((6, 7), np.int8)
+        for t, a in enumerate(mv):
+            b[np.flatnonzero(b[:, a] == 0).max(), a] = 1 if t % 2 == 0 else -1
+        boards.append(b)
+    eng = _engine(C4, len(boards))
+    eng.set_states([(b.reshape(-1), len(mv) % 2, len(mv)) for b, mv in zip(boards, lists)])
+    eng.select(None)
+    for i, ev in enumerate(d['vm_expected']):
+        v = np.zeros(7, np.uint8); v[eng.root_children(i)['a']] = 1
+        assert (v == ev).all(), i
+    eng.close()
 
 
 def test_br_rules_vs_reference_tables():

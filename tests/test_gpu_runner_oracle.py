@@ -10,8 +10,15 @@ the SAME real network, for every hand-over form between the network and the tree
 The oracle (oracle/azg_mcts_ref.c, pinned to the reference's goldens) plays SelfPlayAgent.generateBatch / processBatch / playMoves
 (SelfPlayAgent.pyx:103-202, MCTS.pyx:208-289) with the probabilities NNetWrapper.process returns for ITS leaf observations.  For
 probs / logits every action, sample, result and counter must be identical until every slot has finished a game and restarted.
-The sparse-heads forms (features, wide search) renormalise over the valid actions only: priors agree to ~1e-8, so a PUCT
-near-tie can flip; those tests follow every slot until it diverges and require the committed seed to never diverge."""
+The sparse-heads forms (features, wide search) evaluate a leaf as softmax over its VALID actions' logits (fp32 dot products
+instead of the MFMA chains of the full-width heads), which equals NNetWrapper.process followed by the mask + renormalisation
+of MCTS.pyx:239-245 only to rounding (~1e-8 on a prior).  Two tests therefore:
+  * test_sparse_heads_launches_vs_oracle_bit_exact: the oracle is fed the sparse evaluation itself (azg_leaf_heads_sparse_f16 +
+    azg_heads_softmax, the same arithmetic as its own launch) -- then azg_search_wide_f16, azg_backup_select_features and the
+    oracle must agree bit for bit, which pins the TREE side of the timed launches of configs 3 and 5;
+  * test_runner_timed_launches_vs_oracle_with_real_net: the oracle is fed NNetWrapper.process; every slot is followed until its
+    first differing move and the fraction that never diverged is recorded -- a statement about the NETWORK rounding (a 1e-8
+    prior difference flips a PUCT near-tie about once per 2e5 simulations), bounded, not required to be zero."""
 import importlib
 import json
 import os
@@ -97,8 +104,8 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
     move; connect4: azg_search_f16) and the launch-per-phase sparse-heads form, against the oracle fed by NNetWrapper.process
     (full-width heads: softmax over all A, mask, renormalise -- what the reference computes, MCTS.pyx:239-245).  connect4's fused
     heads hand over exact probabilities: bit-identical, asserted.  The sparse heads agree to rounding only: a slot is followed
-    until its first differing move; the fraction that never diverged is recorded (gpurun_out/nn_error.jsonl) and must be 1.0 on
-    this seed -- counts and pi(T=1) of every agreeing slot are compared every round."""
+    until its first differing move; the fraction that never diverged is recorded (gpurun_out/nn_error.jsonl) and must stay
+    above 0.85 (observed: 45 of 48 brandubh slots after 60 moves x 200 simulations, all slots in the other cases)."""
     import torch
     from alphazero_general_amd.selfplay import SelfPlayRunner
     Game, net = _setup(game, 7)
@@ -147,10 +154,72 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
                              'slots_never_diverged': frac, 'first_divergence_round': first_div,
                              'games_finished': int(ag.games_played)}) + '\n')
     assert ag.games_played > 0
-    assert frac == 1.0, (frac, first_div)
+    if game == 'connect4':
+        assert frac == 1.0, (frac, first_div)
+    else:
+        assert frac >= 0.85, (frac, first_div)
+        if frac < 1.0:
+            return                                              # (diverged slots play different games: the totals below differ)
     c = r.engine.counters()
     assert c['games_played'] == ag.games_played and c['sims'] == ag.sims_done and c['expansions'] == ag.expansions
     oo, op, oz = ag.samples()
     eo, ep, ez = [t.cpu().numpy() for t in r.engine.examples()]
     assert eo.shape == oo.shape and (eo == oo).all() and (ez == oz).all()
     assert (ep == op).all()                                     # pi(T=1) is counts / sum: identical counts, identical pi
+
+
+@pytest.mark.parametrize('game,B,sims', [('brandubh', 48, 40), ('trimok', 64, 24)])
+def test_sparse_heads_launches_vs_oracle_bit_exact(game, B, sims):
+    """Three engines and the oracle on the same seed and network, every round until every slot has restarted:
+      ea  azg_search_wide_f16                (the launch --workload brandubh | trimok times: tree, tower, sparse heads in one launch)
+      eb  azg_backup_select_features         (the same per phase: tower launch + two-wave tree launch with the sparse heads inside)
+      ec  azg_select, tower, azg_leaf_heads_sparse_f16, azg_heads_softmax, azg_backup  (every stage its own launch)
+      oracle  generateBatch / processBatch / playMoves fed the probabilities ec's softmax launch produced for the same leaves.
+    Leaf observations (ec vs oracle), visit counts, actions, tape counters, samples, results, counters: identical."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    Game, net = _setup(game, 9)
+    hip = net._hip
+    assert hip.fact_head and hip.can_search
+    gid, seed, games = Game.AZG_GAME_ID, 31, 3 * B
+    gi = ol.game_info(gid)
+    kw = dict(cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=seed, games_per_iteration=games,
+              example_capacity=4 * B * (gi.max_turns + 1) * gi.num_symmetries, sims_hint=sims)
+    ea, eb, ec = DeviceEngine(gid, B, **kw), DeviceEngine(gid, B, **kw), DeviceEngine(gid, B, **kw)
+    ag = ol.OAgent(gid, B, sims=sims, games_per_iteration=games, seed=seed, add_root_noise=True, add_root_temp=True)
+    hw = gi.obs_h * gi.obs_w
+    ob = torch.zeros((B, hw, 8), dtype=torch.float16, device=ea.device)
+    oc = ec.new_obs(torch.float32)                                # f32 planes: compared with the oracle's, then fed to the network
+    rounds = 0
+    while ag.games_played < games and len(set(ag.results()[2].tolist())) < B:
+        hip.search(ea, sims)
+        eb.select(ob)
+        ag.begin_round()
+        for s in range(sims):
+            eb.backup_select_features(hip.forward_features_nhwc8(ob, key=1), hip.head_rows, hip.head2_b, ob, select=s + 1 < sims)
+            oobs, _, _ = ag.generate_batch()
+            ec.select(oc)
+            if s % 5 == 0:
+                assert (oc.cpu().numpy() == oobs).all(), (rounds, s)
+            lg = ec.leaf_heads_sparse(hip.forward_features_nhwc8(hip.to_nhwc8(oc), key=2), hip.head_rows, hip.head2_b)
+            pol, val = ec.heads_softmax(lg)
+            ec.backup(pol, val)
+            ag.process_batch(pol.cpu().numpy(), val.cpu().numpy())
+        cnt = ea.root_counts()
+        assert torch.equal(cnt, eb.root_counts()) and torch.equal(cnt, ec.root_counts()), rounds
+        assert torch.equal(ea.root_probs(1.0), ec.root_probs(1.0)) and torch.equal(ea.root_value(True), ec.root_value(True))
+        ag.play_moves()
+        for e in (ea, eb, ec):
+            e.advance(True)
+            assert (e.last_actions().cpu().numpy() == ag.last_actions()).all(), rounds
+        assert (ea.tape_counters() == ec.tape_counters()).all() and (eb.tape_counters() == ec.tape_counters()).all()
+        rounds += 1
+    c = ea.counters()
+    assert c == eb.counters() and c == ec.counters()
+    assert c['games_played'] == ag.games_played and c['sims'] == ag.sims_done and c['expansions'] == ag.expansions and c['games_played'] > 0
+    oo, op, oz = ag.samples()
+    for e in (ea, eb, ec):
+        eo, ep, ez = [t.cpu().numpy() for t in e.examples()]
+        assert eo.shape == oo.shape and (eo == oo).all() and (ep == op).all() and (ez == oz).all()
+        for x, y in zip(e.results(), ag.results()):
+            assert (x == y).all()
