@@ -731,6 +731,9 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
         const int bt = forced ? forced : n <= 640 ? 1 : n <= 1280 ? 2 : 4;
         if (bt == 1 && psplit == 2) return launch_tower<C4::H, C4::W, 1, 128, 2>(s, P);   // 8 waves, 2 + 1 pixel subtiles: measured slower (101 vs 69 us)
         if (bt == 1) return launch_tower<C4::H, C4::W, 1, 128>(s, P);
+#ifdef AZG_TUNING
+        if (bt == 2 && psplit == 2) return launch_tower<C4::H, C4::W, 2, 128, 2>(s, P);   // (sweep only: profiles/r03_arena_tile_sweep.txt)
+#endif
         if (bt == 2) return launch_tower<C4::H, C4::W, 2, 128>(s, P);
         return launch_tower<C4::H, C4::W, 4, 128>(s, P);
     }
