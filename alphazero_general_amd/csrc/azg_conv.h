@@ -427,7 +427,11 @@ template <class G> struct SearchWide { View ev; int sims; HeadRows hd; using Gam
 template <class G, int HW> struct WideScratch {
     static constexpr int A = G::A, NV = G::P + 1, OPAD = (A + NV + 15) / 16 * 16, FK = (HW * 16 + 31) / 32 * 32;
     static constexpr int LG = 0, PI = LG + OPAD * 4, M = PI + A * 4, SCR = M + (A < 8 ? 8 : A) * 4, ACT = SCR + 256,
-                         LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + 512, FEAT = FLAGS + 16, BYTES = (FEAT + 2 * FK * 2 + 15) / 16 * 16;
+                         LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + 512, FEAT = FLAGS + 16,
+                         // the game's tree state for the length of the launch (the workgroup owns the game): header, last path, tape
+                         // counter + the two per-slot tallies, root state -- read and written in LDS, copied from / to HBM once
+                         HDR = (FEAT + 2 * FK * 2 + 63) / 64 * 64, PATH = HDR + 64, MAXD = G::MAX_TURNS + 2, CTR = PATH + MAXD * 16,
+                         STATE = CTR + 32, BYTES = (STATE + (int)sizeof(azg_state) + 15) / 16 * 16;
 };
 // all of the wide search mode's LDS behind the image: the per-game scratch and an error word
 template <class G, int HW, int BOARDS> struct WideLds {
@@ -519,6 +523,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
         const int rows_here = min(ROWS, P.boards * HW - row0);
         int nsims = 1;
         if constexpr (IS_SEARCH) nsims = sa.sims + (IS_WIDE ? 1 : 0);  // (wide: the last iteration is the last backup, no tower)
+        [[maybe_unused]] bool lds_live = false;                  // wide search: the games' tree state is in LDS (written back after the loop)
         for (int sim = 0; sim < nsims; sim++) {
 #ifdef AZG_TOWER_TIMING
         unsigned long long wt_[6] = {0, 0, 0, 0, 0, 0};
@@ -551,13 +556,38 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
             asm volatile("" : "+v"(slot));                       // (opaque: nothing of the trees is hoisted out of the simulation loop)
             slot = __builtin_amdgcn_readfirstlane(slot);
             const bool livegame = slot < sa.ev.B && role < 2;
-            int tree = 0; HdrR hr; uint64_t ctr0 = 0;
-            if (livegame) { tree = tree_of_slot(sa.ev, slot); load_hdr(sa.ev.hdr + tree, hr); ctr0 = sa.ev.tape_ctr[slot]; }
+            const int tree = slot;                               // (self-play engines only: one tree per slot)
+            // The tree functions reach the header, the path, the tape counter, the tallies and the root state through the View's
+            // pointers: here those point into the game's LDS scratch (offset so that [tree] / [slot] lands on it), so that every
+            // simulation's header / path / counter reads are LDS reads instead of a chain of three or four L2 round trips (4 k
+            // of the walker's 26 k cycles) and the tallies' read-modify-writes never wait for HBM.  Node blocks stay in HBM.
+            View evl = sa.ev;
+            evl.hdr = reinterpret_cast<TreeHdr *>(ws + WS::HDR) - tree;
+            evl.path = reinterpret_cast<PathEnt *>(ws + WS::PATH) - (size_t)tree * sa.ev.maxd;
+            evl.tape_ctr = reinterpret_cast<uint64_t *>(ws + WS::CTR) - slot;
+            evl.slot_sims = reinterpret_cast<int64_t *>(ws + WS::CTR + 8) - slot;
+            evl.slot_exp = reinterpret_cast<int64_t *>(ws + WS::CTR + 16) - slot;
+            evl.states = reinterpret_cast<azg_state *>(ws + WS::STATE) - slot;
+            if (sim == 0) {                                      // HBM -> LDS, once per launch
+                if (livegame && role == 0) {
+                    if (lane < 4) reinterpret_cast<uint4 *>(ws + WS::HDR)[lane] = reinterpret_cast<const uint4 *>(sa.ev.hdr + tree)[lane];
+                    if (lane < (int)sizeof(azg_state) / 16) reinterpret_cast<uint4 *>(ws + WS::STATE)[lane] = reinterpret_cast<const uint4 *>(sa.ev.states + slot)[lane];
+                    if (lane == 0) {
+                        *reinterpret_cast<uint64_t *>(ws + WS::CTR) = sa.ev.tape_ctr[slot];
+                        *reinterpret_cast<int64_t *>(ws + WS::CTR + 8) = sa.ev.slot_sims[slot];
+                        *reinterpret_cast<int64_t *>(ws + WS::CTR + 16) = sa.ev.slot_exp[slot];
+                    }
+                }
+                lds_live = true;
+                __syncthreads();
+            }
+            HdrR hr; uint64_t ctr0 = 0;
+            if (livegame) { load_hdr(evl.hdr + tree, hr); ctr0 = evl.tape_ctr[slot]; }
             __syncthreads();                                     // both wavefronts of a game hold the header as the last launch / phase left it
             const bool has_policy = livegame && sim > 0 && !hr.leaf_e && hr.leaf_fc >= 0;
             const bool root_noise = has_policy && hr.leaf == LEAF_IS_ROOT && sa.ev.add_noise;
             if (livegame && role == 0) {
-                typename G::S st = G::load(&sa.ev.states[slot], lane);
+                typename G::S st = G::load(&evl.states[slot], lane);
                 auto sink = [&](const typename G::S &ls, int ln) {   // leaf observation -> the image rows of board bd (32 stem channels)
                     if (ln < HW) {
                         char *row = img + GEO::qrow(bd * HW + ln) * RS;
@@ -568,7 +598,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 };
                 int *act = reinterpret_cast<int *>(ws + WS::ACT);
                 if (sim == 0) {
-                    select_tree<G>(sa.ev, slot, tree, hr, st, ctr0, lane, act, sink, NoGate{}, NoRanks{});
+                    select_tree<G>(evl, slot, tree, hr, st, ctr0, lane, act, sink, NoGate{}, NoRanks{});
                 } else {
                     Node *nodes = tree_nodes(sa.ev, tree, hr.base);
                     float val[NV];
@@ -581,12 +611,12 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
 #pragma unroll
                     for (int j = 0; j < NV; j++) val[j] = rl(pv, j);
                     const int prev_leaf = hr.leaf;
-                    backup_path<G>(sa.ev, slot, tree, hr, nodes, val, lane);
+                    backup_path<G>(evl, slot, tree, hr, nodes, val, lane);
                     if (sim < sa.sims) {
                         wave_sync();
                         bool waited = false;
                         const unsigned long long *less = reinterpret_cast<const unsigned long long *>(ws + WS::LESS);
-                        select_tree<G>(sa.ev, slot, tree, hr, st, ctr0, lane, act, sink, [&](int node) {
+                        select_tree<G>(evl, slot, tree, hr, st, ctr0, lane, act, sink, [&](int node) {
                             if (waited || node != prev_leaf) return false;
                             flag_wait_gen(sa.ev, &flags[0], sim); waited = true;
                             return root_noise;
@@ -620,7 +650,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                     policy_softmax_row(lg, lane, A, pi);
                     wave_sync();
                     AZG_HSTAMP(4);
-                    backup_policy<G>(sa.ev, slot, hr, nodes, pi, reinterpret_cast<float *>(ws + WS::M), reinterpret_cast<float *>(ws + WS::SCR), lane);
+                    backup_policy<G>(evl, slot, hr, nodes, pi, reinterpret_cast<float *>(ws + WS::M), reinterpret_cast<float *>(ws + WS::SCR), lane);
                     AZG_HSTAMP(5);
                 }
                 flag_set_gen(&flags[0], sim, lane);
@@ -941,6 +971,25 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
         }
         __syncthreads();
         }                                                        // sims
+        if constexpr (IS_WIDE) {
+            // LDS -> HBM: header, tape counter, tallies and the last path of every game, as the launch-per-phase path leaves them
+            using G = typename SEARCH::Game;
+            using WS = WideScratch<G, HW>;
+            __syncthreads();
+            const int bd = wave % BOARDS, role = wave / BOARDS, slot = tile * BOARDS + bd;
+            if (lds_live && role == 0 && slot < sa.ev.B) {
+                const char *ws = smem + TILE + bd * WS::BYTES;
+                if (lane < 4) reinterpret_cast<uint4 *>(sa.ev.hdr + slot)[lane] = reinterpret_cast<const uint4 *>(ws + WS::HDR)[lane];
+                const int depth = reinterpret_cast<const int *>(ws + WS::HDR)[10];
+                for (int j = lane; j < depth && j < sa.ev.maxd; j += 64)
+                    reinterpret_cast<uint4 *>(sa.ev.path + (size_t)slot * sa.ev.maxd)[j] = reinterpret_cast<const uint4 *>(ws + WS::PATH)[j];
+                if (lane == 0) {
+                    sa.ev.tape_ctr[slot] = *reinterpret_cast<const uint64_t *>(ws + WS::CTR);
+                    sa.ev.slot_sims[slot] = *reinterpret_cast<const int64_t *>(ws + WS::CTR + 8);
+                    sa.ev.slot_exp[slot] = *reinterpret_cast<const int64_t *>(ws + WS::CTR + 16);
+                }
+            }
+        }
     }
 #ifdef AZG_TOWER_TIMING
     if (P.dbg && tid == 0) P.dbg[2048 + (size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
