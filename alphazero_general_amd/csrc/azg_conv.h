@@ -637,7 +637,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
 #endif
                 AZG_HSTAMP(1);
                 if (sim < sa.sims) {                                 // (masks first: every expansion waits for them, see k_backup_select2)
-                    reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+                    reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
                     flag_set_gen(&flags[1], sim, lane);
                 }
                 AZG_HSTAMP(2);

@@ -110,11 +110,12 @@ AZG_DEV int add_children_any(const View &ev, int slot, Node *nodes, int &alloc, 
 // For lane i: the set of j in [0, 64) whose (tape key, index) pair sorts below (key_i, i), keys of counters ctr .. ctr + 63.
 // The rank of child i among k <= 64 children is then popcount(mask & ((1 << k) - 1)): the all-pairs part of the shuffle does
 // not depend on k, so it can be prepared before the leaf is known.
+template <int NJ = 64>                                                       // only bits j < k <= NJ are ever looked at (NJ = min(64, the game's MAXK))
 AZG_DEV uint64_t shuffle_less_mask(const View &ev, int slot, uint64_t ctr, int lane) {
     const uint64_t key = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr + (uint64_t)lane);
     uint64_t less = 0;
 #pragma unroll
-    for (int j = 0; j < 64; j++) {
+    for (int j = 0; j < NJ; j++) {
         const uint64_t kj = rl(key, j);
         less |= (uint64_t)((kj < key || (kj == key && j < lane)) ? 1 : 0) << j;
     }
@@ -488,46 +489,71 @@ struct HeadDot {
     }
 };
 
-// policy logits of the last leaf's k children (one wavefront): lg[a] for their actions, -inf for every other a < A.  Four
-// children per pass (one per DPP row), the weight rows prefetched DEPTH passes ahead.  feat: the board's policy features, IN LDS
-// (a global read between the passes would drain the prefetches: vmcnt waits in order).
+// policy logits of the last leaf's k children (one wavefront): lg[a] for their actions, -inf for every other a < A.
+// The k dot products run on the MFMA pipe, which is idle while the trees are walked: 16 children per v_mfma_f32_16x16x32_f16 --
+// A operand = 16 weight rows x 32 features (lane g * 16 + i gathers 16 bytes of child i's row), B operand = the board's features
+// from LDS in all 16 columns, one accumulation chain over the FK / 32 k-steps per 16 children.  The rows of the NEXT 16 children are
+// fetched while the current chain runs (one 16-byte load per lane and k-step, FK / 32 of them in flight: the job is L2 latency, 64 KB
+// of rows per leaf), the biases travel with the rows.  Same association in every kernel that calls it.
+typedef float hfloatx4 __attribute__((ext_vector_type(4)));
 template <class G>
 AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, int k, const _Float16 *feat, float *lg, int lane) {
-    constexpr int A = G::A, FK = head_fk<G>(), DEPTH = 4;
-    using HD = HeadDot<FK>;
+    constexpr int A = G::A, FK = head_fk<G>(), KSTEPS = FK / 32, NCH = (G::MAXK + 63) / 64;
     for (int a = lane; a < A; a += 64) lg[a] = -INFINITY;
-    int acts[(G::MAXK + 63) / 64];                                           // child i's action in lane i & 63 of acts[i >> 6]
+    int acts[NCH];                                                           // child i's action in lane i & 63 of acts[i >> 6]
 #pragma unroll
-    for (int c = 0; c < (G::MAXK + 63) / 64; c++) acts[c] = c * 64 + lane < k ? (int)nodes[fc + c * 64 + lane].a : 0;
+    for (int c = 0; c < NCH; c++) acts[c] = c * 64 + lane < k ? (int)nodes[fc + c * 64 + lane].a : 0;
     wave_sync();
-    const int r = lane >> 4, j16 = lane & 15, npass = (k + 3) >> 2;
-    hrow8 w[DEPTH][HD::IT];
-    int act[DEPTH];
-    float bias[DEPTH];                                                       // (fetched with the rows: a load issued at the point of use
-    auto issue = [&](int d, int p) {                                         //  would make the in-order vmcnt wait drain the prefetches)
-        const int i = 4 * p + r;
+    const int g = lane >> 4, i16 = lane & 15, nsub = (k + 15) >> 4;
+    auto action_of = [&](int child) {                                        // (child < k; any lane may ask for any child)
         int a = 0;
 #pragma unroll
-        for (int c = 0; c < (G::MAXK + 63) / 64; c++) {
-            const int v = __builtin_amdgcn_ds_bpermute((i & 63) << 2, acts[c]);
-            if ((i >> 6) == c) a = v;
+        for (int c = 0; c < NCH; c++) {
+            const int v = __builtin_amdgcn_ds_bpermute((child & 63) << 2, acts[c]);
+            if ((child >> 6) == c) a = v;
         }
-        act[d] = a;
-        bias[d] = hd.bias[a];
-        HD::load(w[d], hd.rows + (size_t)a * hd.fk, j16, i < k);
+        return a;
     };
-    // branch-free body (passes past the end load nothing and store nothing: lane predicates only), so that the compiler can
-    // count the loads in flight and wait for exactly the oldest pass (vmcnt(n), not a drain)
+    // two row buffers: while the chain of 16 children runs out of one, the rows of the next 16 land in the other (the loads are
+    // issued BEFORE the chain: the compiler keeps program order between loads and the MFMAs that read their registers)
+    hrow8 wa[KSTEPS], wb[KSTEPS];
+    float bias_a, bias_b;
+    auto fetch = [&](int sub, hrow8 (&w)[KSTEPS], float &bias) {
+        const int an = action_of(min(16 * sub + i16, k - 1));
+        const _Float16 *rn = hd.rows + (size_t)an * hd.fk + g * 8;
+        bias = hd.bias[an];
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) issue(d, d);
-    for (int p0 = 0; p0 < npass; p0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            const int p = p0 + d;
-            const float x = HD::dot(w[d], feat, j16);
-            if (j16 == 0 && 4 * p + r < k) lg[act[d]] = x + bias[d];
-            issue(d, p + DEPTH);
+        for (int ks = 0; ks < KSTEPS; ks++) w[ks] = *reinterpret_cast<const hrow8 *>(rn + ks * 32);
+    };
+    const _Float16 *fb = feat + g * 8;
+    auto chain = [&](int sub, const hrow8 (&w)[KSTEPS], float bias) {
+        hfloatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // even / odd k-steps: two independent chains (a
+#pragma unroll                                                               //  dependent MFMA waits ~2x its issue interval), summed at the end
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            const hrow8 b = *reinterpret_cast<const hrow8 *>(fb + ks * 32);
+            if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks], b, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks], b, acc0, 0, 0, 0);
         }
+        const hfloatx4 acc = acc0 + acc1;
+        // D[row 4 g + r][column n] sits in lane g * 16 + n, element r; every column is the same dot product, so lane (g, n < 4)
+        // delivers child 16 sub + 4 g + n
+        const int child = 16 * sub + 4 * g + (i16 & 3);
+        const float x = (i16 & 3) == 0 ? acc[0] : (i16 & 3) == 1 ? acc[1] : (i16 & 3) == 2 ? acc[2] : acc[3];
+        const int aw = action_of(min(child, k - 1));
+        const float bw = __int_as_float(__builtin_amdgcn_ds_bpermute((4 * g + (i16 & 3)) << 2, __float_as_int(bias)));
+        if (i16 < 4 && child < k) lg[aw] = x + bw;
+    };
+    fetch(0, wa, bias_a);
+    for (int s = 0; s < nsub; s += 2) {                                      // (sched_barrier: left alone the scheduler sinks the loads
+        if (s + 1 < nsub) fetch(s + 1, wb, bias_b);                          //  of the next subtile below the chain that should hide them;
+        __builtin_amdgcn_sched_barrier(0);                                   //  the branches are wave-uniform)
+        chain(s, wa, bias_a);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 >= nsub) break;
+        if (s + 2 < nsub) fetch(s + 2, wa, bias_a);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(s + 1, wb, bias_b);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // the P + 1 value logits of a board into lg[0 .. NV) (one wavefront, one pass).  feat: the board's value features.
@@ -587,7 +613,7 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
         //  for, go first, and the priors, which only a descent through the previous leaf waits for, second)
         constexpr bool MASKS_FIRST = MODE == IN_FEATURES;
         if (MASKS_FIRST && do_select) {
-            less_lds[lane] = shuffle_less_mask(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+            less_lds[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
             flag_set_gen(&flags[1], 1, lane);
         }
         if (has_policy) {
@@ -606,7 +632,7 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
         flag_set_gen(&flags[0], 1, lane);
         AZG_TSTAMP(ev, slot, lane, 9);
         if (!MASKS_FIRST && do_select) {
-            less_lds[lane] = shuffle_less_mask(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+            less_lds[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
             flag_set_gen(&flags[1], 1, lane);
         }
         AZG_TSTAMP(ev, slot, lane, 0);
