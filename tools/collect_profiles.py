@@ -2,12 +2,12 @@
 
     python tools/collect_profiles.py --git <short hash of the commit being profiled> [--workloads connect4 brandubh arena trimok]
 
-Per workload: (1) `rocprofv3 --kernel-trace --stats` of the bench command -> profiles/r02_<workload>_kernel_stats.csv and the bench
+Per workload: (1) `rocprofv3 --kernel-trace --stats` of the bench command -> profiles/<round>_<workload>_kernel_stats.csv and the bench
 line printed under the profiler; (2) PMC passes of the same command, one counter set per pass as MI355X_MICROARCH.md prescribes
 (FETCH_SIZE and WRITE_SIZE cannot share a pass; never combined with --stats / trace domains other than the kernel trace):
 (profiles/ does not travel back from the GPU box, gpurun_out/ does: re-run with --reuse in the build container to rebuild the
-profiles/r02_* files from the raw output)  per-kernel averages -> profiles/r02_pmc_summary.csv, and HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; the
-guide's gfx950 correction: FETCH_SIZE reports half the bytes of wide loads) -> profiles/r02_pmc.json, which bench.py reads for its
+profiles/<round>_* files from the raw output)  per-kernel averages -> profiles/<round>_pmc_summary.csv, and HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; the
+guide's gfx950 correction: FETCH_SIZE reports half the bytes of wide loads) -> profiles/<round>_pmc.json, which bench.py reads for its
 `traffic` fields.  The connect4 run adds an MFMA / LDS / clock pass for the search launch."""
 import argparse
 import csv
@@ -20,7 +20,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-SCRATCH = os.path.join(ROOT, 'gpurun_out', 'r02_prof')
+ROUND = 'r03'
+SCRATCH = os.path.join(ROOT, 'gpurun_out', ROUND + '_prof')
 KEEP = ('k_tower2', 'k_backup_select2', 'k_heads', 'k_select', 'k_backup', 'k_play', 'k_compact', 'k_emit', 'k_finalize', 'k_arena_rows')
 
 
@@ -78,26 +79,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--git', default=os.environ.get('AZG_GIT', 'unknown'))
     ap.add_argument('--workloads', nargs='*', default=['connect4', 'brandubh', 'arena', 'trimok'])
-    ap.add_argument('--reuse', action='store_true', help='rebuild profiles/r02_* from the raw output already under gpurun_out/r02_prof')
+    ap.add_argument('--reuse', action='store_true', help='rebuild profiles/<round>_* from the raw output already under gpurun_out/<round>_prof')
     a = ap.parse_args()
     global REUSE
     REUSE = a.reuse
     os.makedirs(PROF, exist_ok=True); os.makedirs(SCRATCH, exist_ok=True)
     summary_rows, pmc = [], {'git': a.git, 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
     for w in a.workloads:
-        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm']
+        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm', '--no-other-workloads']
         out, line, rc = rocprof('kt_' + w, ['--kernel-trace', '--stats'], base + ['--steps', '12', '--warmup', '2'])
         stats = glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True)
         if stats:
-            shutil.copy(stats[0], os.path.join(PROF, 'r02_%s_kernel_stats.csv' % w))
+            shutil.copy(stats[0], os.path.join(PROF, ROUND + '_%s_kernel_stats.csv' % w))
         if line:
-            with open(os.path.join(PROF, 'r02_%s_bench_line_under_rocprof.json' % w), 'w') as fh:
+            with open(os.path.join(PROF, ROUND + '_%s_bench_line_under_rocprof.json' % w), 'w') as fh:
                 fh.write(line + '\n')
         print(w, 'kernel trace rc', rc, 'stats' if stats else 'NO STATS', flush=True)
         passes = [['FETCH_SIZE'], ['WRITE_SIZE']]
         if w == 'connect4':
             passes += [['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_WAIT_INST_ANY',
                         'GRBM_GUI_ACTIVE'], ['TCC_HIT_sum', 'TCC_MISS_sum']]
+        else:
+            passes += [['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE']]
         per_kernel = {}
         for cs in passes:
             out, _, rc = rocprof('pmc_%s_%s' % (w, cs[0]), ['--pmc'] + cs, base + ['--steps', '4', '--warmup', '1'])
@@ -112,14 +115,16 @@ def main():
                 f, wv = cs['FETCH_SIZE'][0], cs['WRITE_SIZE'][0]
                 rec[k] = {'fetch_kb': round(f, 2), 'write_kb': round(wv, 2), 'traffic_bytes': int((2 * f + wv) * 1024),
                           'dispatches': int(cs['FETCH_SIZE'][1])}
+                if cs.get('SQ_VALU_MFMA_BUSY_CYCLES', (0, 0))[0] > 0:   # cycles the MFMA pipes were busy, summed over the chip, per launch
+                    rec[k]['mfma_busy_cycles'] = round(cs['SQ_VALU_MFMA_BUSY_CYCLES'][0], 1)
         pmc['workloads'][w] = rec
-    with open(os.path.join(PROF, 'r02_pmc.json'), 'w') as fh:
+    with open(os.path.join(PROF, ROUND + '_pmc.json'), 'w') as fh:
         json.dump(pmc, fh, indent=1, sort_keys=True)
-    with open(os.path.join(PROF, 'r02_pmc_summary.csv'), 'w', newline='') as fh:
+    with open(os.path.join(PROF, ROUND + '_pmc_summary.csv'), 'w', newline='') as fh:
         wr = csv.writer(fh)
         wr.writerow(['workload', 'kernel', 'counter', 'dispatches', 'avg_per_dispatch'])
         wr.writerows(summary_rows)
-    print('wrote profiles/r02_pmc.json, profiles/r02_pmc_summary.csv')
+    print('wrote profiles/%s_pmc.json, profiles/%s_pmc_summary.csv' % (ROUND, ROUND))
 
 
 if __name__ == '__main__':
