@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AZG_ABI_VERSION 2
+#define AZG_ABI_VERSION 3
 
 typedef enum azg_status {
     AZG_OK = 0,
