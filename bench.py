@@ -12,9 +12,9 @@ resident in HBM; the only host traffic in the timed region is one counter read p
 N > 1: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run, one per GPU, RCCL); under an external
 torch.distributed.run it uses the ranks it was given.  n_gpus in the output is the number of ranks that actually ran.
 
-Measured inside the run (HIP events on the launch stream, one eagerly launched round in the middle of the timed region):
+Measured inside the run (HIP events on the launch stream, rounds launched eagerly AFTER the timed region, which holds product rounds only):
 `roofline` = the dominant kernel of a simulation step, `tree_roofline` = the tree launch.  `traffic` (HBM bytes per launch) comes
-from the committed rocprofv3 --pmc summary profiles/r02_pmc.json (tools/collect_profiles.py, run on the GPU box), never from a
+from the committed rocprofv3 --pmc summary profiles/r03_pmc.json (tools/collect_profiles.py, run on the GPU box), never from a
 constant in this file.  `cpu_baseline` (rank 0, N = 1 only) = the C oracle on the host cores, bounded sample.
 """
 import argparse
@@ -470,17 +470,20 @@ def main():
         release(c)
         others = {}
         for name in ('brandubh', 'arena', 'trimok'):
-            oc = build(name, a, rank, local_rank, dev, 8 + 2 + 2 + 8)
-            ot = timed_region(oc, 8, 2, world, rank)
-            onp, opf = profile_rounds(oc, 1)
-            orf, otr, _ = rooflines(oc, onp, opf)
-            others[name] = {'workload': workload_label(oc), 'value': round(ot['expansions'] / ot['dt'], 1), 'unit': 'expansions/s',
-                            'games_per_sec': round(ot['games'] / ot['dt'], 2), 'steps': 8, 'warmup': 2,
-                            'ms_per_step': round(ot['dt'] * 1e3 / 8, 3), 'fused_search_launch': oc.fused_search,
-                            'roofline': None if orf is None else {k: orf[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
-                                                                                     'avg_launch_us', 'launches_timed', 'traffic')},
-                            'tree_launch_us': None if otr is None else otr['avg_launch_us']}
-            release(oc)
+            try:                                                     # (a failure here must not take the headline line with it)
+                oc = build(name, a, rank, local_rank, dev, 8 + 2 + 2 + 8)
+                ot = timed_region(oc, 8, 2, world, rank)
+                onp, opf = profile_rounds(oc, 1)
+                orf, otr, _ = rooflines(oc, onp, opf)
+                others[name] = {'workload': workload_label(oc), 'value': round(ot['expansions'] / ot['dt'], 1), 'unit': 'expansions/s',
+                                'games_per_sec': round(ot['games'] / ot['dt'], 2), 'steps': 8, 'warmup': 2,
+                                'ms_per_step': round(ot['dt'] * 1e3 / 8, 3), 'fused_search_launch': oc.fused_search,
+                                'roofline': None if orf is None else {k: orf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                                                             'executed_frac', 'avg_launch_us', 'launches_timed', 'traffic')},
+                                'tree_launch_us': None if otr is None else otr['avg_launch_us']}
+                release(oc)
+            except Exception as ex:                                  # noqa: BLE001
+                others[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
         out['other_workloads'] = others
     print(json.dumps(out))
     return 0
