@@ -591,15 +591,6 @@ extern "C" int azg_last_actions_dev(azg_engine *e, int32_t **actions) {
     return AZG_OK;
 }
 
-// device buffers that belong to the library rather than to an engine (the towers' pixel tables): released when the library is unloaded
-static std::vector<void *> g_static_allocs;
-static std::mutex g_static_mu;
-__attribute__((destructor)) static void azg_library_unload() {
-    std::lock_guard<std::mutex> lk(g_static_mu);
-    for (void *p : g_static_allocs) (void)hipFree(p);            // (an error -- the HIP runtime already gone at process exit -- is ignored)
-    g_static_allocs.clear();
-}
-
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
 static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}, bool init_only = false) {
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
@@ -608,8 +599,8 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
         if constexpr (IS_SEARCH) { if constexpr (SEARCH::WIDE) return (size_t)GEO::TILE + (size_t)WideLds<typename SEARCH::Game, H * W, BOARDS>::BYTES; }
         return (size_t)GEO::TILE;
     }();
-    // per (instantiation, device): the pixel -> (subtile, lane) table, a few hundred bytes that live as long as the library is
-    // loaded (the table is a pure function of the template arguments; freed by azg_library_unload); first use is serialised
+    // per (instantiation, device): the pixel -> (subtile, lane) table, a few hundred bytes that live as long as the process
+    // (the table is a pure function of the template arguments); first use is serialised
     static int16_t *d_map[16] = {nullptr};
     static std::mutex d_map_mu;
     int dev = 0, cus = 256;
@@ -623,7 +614,6 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
             int16_t *d = nullptr;
             HIPCHK(hipMalloc((void **)&d, sizeof(map)));
             HIPCHK(hipMemcpy(d, map, sizeof(map), hipMemcpyHostToDevice));
-            { std::lock_guard<std::mutex> lk2(g_static_mu); g_static_allocs.push_back(d); }
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             d_map[dev] = d;
         }
