@@ -647,7 +647,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                     leaf_policy_logits<G>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
                     wave_sync();
                     AZG_HSTAMP(3);
-                    policy_softmax_row(lg, lane, A, pi);
+                    policy_softmax_row<A>(lg, lane, A, pi);
                     wave_sync();
                     AZG_HSTAMP(4);
                     backup_policy<G>(evl, slot, hr, nodes, pi, reinterpret_cast<float *>(ws + WS::M), reinterpret_cast<float *>(ws + WS::SCR), lane);

@@ -203,6 +203,10 @@ template <int N> AZG_DEV float wave_max_n(float m) {
     if (N > 32) r = fmaxf(fmaxf(r, rl(m, 32)), rl(m, 48));
     return r;
 }
+AZG_DEV float wave_sum_f(float m) {                            // every lane returns the SAME float sum over the 64 lanes (fixed tree)
+    m += dpp_f<DPP_QUAD_XOR1>(m); m += dpp_f<DPP_QUAD_XOR2>(m); m += dpp_f<DPP_ROW_HALF_MIRROR>(m); m += dpp_f<DPP_ROW_MIRROR>(m);
+    return (rl(m, 0) + rl(m, 16)) + (rl(m, 32) + rl(m, 48));
+}
 AZG_DEV int wave_sum_i(int m) {                                // every lane returns the sum over the 64 lanes
     m += dpp_i<DPP_QUAD_XOR1>(m); m += dpp_i<DPP_QUAD_XOR2>(m); m += dpp_i<DPP_ROW_HALF_MIRROR>(m); m += dpp_i<DPP_ROW_MIRROR>(m);
     return (rl(m, 0) + rl(m, 16)) + (rl(m, 32) + rl(m, 48));
@@ -292,37 +296,34 @@ AZG_DEV float np_sum_static(const float *m, float *scr, int lane) {
 
 // softmax over the A policy logits of one board by one wavefront (NNetArchitecture.py:112-118, exp(log_softmax)): lane owns logits
 // lane, lane + 64, ... (A <= 1024).  pol may be global or LDS.
+// AC > 0: the row length is known at compile time, so only the ceil(AC / 64) register slots that can hold a logit are touched; the
+// others would hold -inf, whose exp is an exact +0 in the lane's sum -- the result is bit-identical to the run-time form.
+template <int AC = 0>
 AZG_DEV void policy_softmax_row(const float *lg, int lane, int A, float *pol) {
-    float x[16], m = -INFINITY;
+    constexpr int NJ = AC > 0 ? (AC + 63) / 64 : 16;
+    float x[NJ], m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < NJ; j++) {
         const int o = lane + 64 * j;
         x[j] = lg[min(o, A - 1)];
         if (o >= A) x[j] = -INFINITY;
         m = fmaxf(m, x[j]);
     }
+    m = wave_max(m);                                           // (DPP row reductions + four readlanes: ~60 cycles; six ds_bpermute round
+    float sum = 0.f;                                           //  trips -- __shfl_xor -- cost ~600 on a wavefront that has its SIMD alone)
 #pragma unroll
-    for (int d = 32; d; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; j++) { x[j] = __expf(x[j] - m); sum += x[j]; }    // exp(-inf) = 0 for the padding
-#pragma unroll
-    for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+    for (int j = 0; j < NJ; j++) { x[j] = __expf(x[j] - m); sum += x[j]; }    // exp(-inf) = 0 for the padding
+    sum = wave_sum_f(sum);
     const float inv = 1.f / sum;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { const int o = lane + 64 * j; if (o < A) pol[o] = x[j] * inv; }
+    for (int j = 0; j < NJ; j++) { const int o = lane + 64 * j; if (o < A) pol[o] = x[j] * inv; }
 }
 // the same for the NV <= 64 value logits lg[0 .. NV): lane j < NV returns probability j (other lanes 0)
 AZG_DEV float value_softmax(const float *lg, int lane, int NV) {
     const float v = lg[min(lane, NV - 1)];
-    float vm = lane < NV ? v : -INFINITY;
-#pragma unroll
-    for (int d = 32; d; d >>= 1) vm = fmaxf(vm, __shfl_xor(vm, d));
+    const float vm = wave_max(lane < NV ? v : -INFINITY);
     const float ev = lane < NV ? __expf(v - vm) : 0.f;
-    float vs = ev;
-#pragma unroll
-    for (int d = 32; d; d >>= 1) vs += __shfl_xor(vs, d);
-    return ev / vs;
+    return ev / wave_sum_f(ev);
 }
 AZG_DEV void heads_softmax_row(const float *lg, int lane, int A, int NV, float *pol, float *val) {
     policy_softmax_row(lg, lane, A, pol);

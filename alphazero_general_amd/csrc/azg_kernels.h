@@ -626,7 +626,7 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
                 wave_sync();
                 pi = lg_lds;
             }
-            if constexpr (LOGITS) { policy_softmax_row(pi, lane, A, pi_lds); wave_sync(); pi = pi_lds; }
+            if constexpr (LOGITS) { policy_softmax_row<A>(pi, lane, A, pi_lds); wave_sync(); pi = pi_lds; }
             backup_policy<G>(ev, slot, hr, nodes, pi, m_lds, scr, lane);
         }
         flag_set_gen(&flags[0], 1, lane);
