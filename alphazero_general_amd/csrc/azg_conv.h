@@ -433,9 +433,12 @@ template <class G, int HW> struct WideScratch {
                          HDR = (FEAT + 2 * FK * 2 + 63) / 64 * 64, PATH = HDR + 64, MAXD = G::MAX_TURNS + 2, CTR = PATH + MAXD * 16,
                          STATE = CTR + 32, BYTES = (STATE + (int)sizeof(azg_state) + 15) / 16 * 16;
 };
-// all of the wide search mode's LDS behind the image: the per-game scratch and an error word
+// all of the wide search mode's LDS behind the image: the per-game scratch, an error word, and the value head's P + 1 weight rows
+// + biases (the same for every game and simulation: fetched once per launch instead of once per simulation by every walker)
 template <class G, int HW, int BOARDS> struct WideLds {
-    static constexpr int BYTES = (BOARDS * WideScratch<G, HW>::BYTES + 16 + 15) / 16 * 16;
+    static constexpr int NV = G::P + 1, FK = WideScratch<G, HW>::FK;
+    static constexpr int ERR = BOARDS * WideScratch<G, HW>::BYTES, VROWS = (ERR + 16 + 15) / 16 * 16, VBIAS = VROWS + NV * FK * 2,
+                         BYTES = (VBIAS + NV * 4 + 15) / 16 * 16;
 };
 
 // (the wide search mode keeps one workgroup per CU busy for a whole move and mixes three phases with different register needs:
@@ -469,8 +472,12 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
     }
     for (int c = tid; c < TILE / 16; c += NT) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
     if constexpr (IS_WIDE) {                                     // (the feature rows' padding must read as zero)
-        constexpr int WB = WideLds<typename SEARCH::Game, HW, BOARDS>::BYTES;
-        for (int c = tid; c < WB / 16; c += NT) reinterpret_cast<uint4 *>(smem + TILE)[c] = make_uint4(0, 0, 0, 0);
+        using WL = WideLds<typename SEARCH::Game, HW, BOARDS>;
+        for (int c = tid; c < WL::VROWS / 16; c += NT) reinterpret_cast<uint4 *>(smem + TILE)[c] = make_uint4(0, 0, 0, 0);
+        constexpr int A_ = SEARCH::Game::A;
+        const uint4 *vsrc = reinterpret_cast<const uint4 *>(sa.hd.rows + (size_t)A_ * sa.hd.fk);      // rows A .. A + P of the head matrix
+        for (int c = tid; c < WL::NV * WL::FK * 2 / 16; c += NT) reinterpret_cast<uint4 *>(smem + TILE + WL::VROWS)[c] = vsrc[c];
+        if (tid < WL::NV) reinterpret_cast<float *>(smem + TILE + WL::VBIAS)[tid] = sa.hd.bias[A_ + tid];
     }
     unsigned lb[NSUB];
     unsigned livemask = 0;
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
             char *ws = smem + TILE + bd * WS::BYTES;
             float *lg = reinterpret_cast<float *>(ws + WS::LG);
             int *flags = reinterpret_cast<int *>(ws + WS::FLAGS);
-            int *errw = reinterpret_cast<int *>(smem + TILE + BOARDS * WS::BYTES);
+            int *errw = reinterpret_cast<int *>(smem + TILE + WideLds<G, HW, BOARDS>::ERR);
             if (sim == 0 && tid < 2 * BOARDS) reinterpret_cast<int *>(smem + TILE + (tid >> 1) * WS::BYTES + WS::FLAGS)[tid & 1] = 0;
             if ((sim & 15) == 0) {                                   // sticky device error: stop, uniformly over the workgroup
                 if (tid == 0) *errw = sa.ev.gcount[GC_ERROR];
@@ -587,6 +594,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
             const bool has_policy = livegame && sim > 0 && !hr.leaf_e && hr.leaf_fc >= 0;
             const bool root_noise = has_policy && hr.leaf == LEAF_IS_ROOT && sa.ev.add_noise;
             if (livegame && role == 0) {
+                if (sim < sa.sims) AZG_TSTAMP(evl, slot, lane, 8);   // (tree-timing builds: tools/wide_walker_stamps.py)
                 typename G::S st = G::load(&evl.states[slot], lane);
                 auto sink = [&](const typename G::S &ls, int ln) {   // leaf observation -> the image rows of board bd (32 stem channels)
                     if (ln < HW) {
@@ -604,25 +612,35 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                     float val[NV];
                     float pv = 0.f;
                     if (!hr.leaf_e) {                                // (a terminal leaf backs its win state up, not the network)
-                        leaf_value_logits<G>(sa.hd, reinterpret_cast<const _Float16 *>(ws + WS::FEAT) + sa.hd.fk, lg + A, lane);
+                        using WL = WideLds<G, HW, BOARDS>;
+                        HeadRows hv = sa.hd;                         // the value rows and biases out of LDS (offset so that row A + r lands on them)
+                        hv.rows = reinterpret_cast<const _Float16 *>(smem + TILE + WL::VROWS) - (size_t)A * sa.hd.fk;
+                        hv.bias = reinterpret_cast<const float *>(smem + TILE + WL::VBIAS) - A;
+                        leaf_value_logits<G>(hv, reinterpret_cast<const _Float16 *>(ws + WS::FEAT) + sa.hd.fk, lg + A, lane);
                         wave_sync();
                         pv = value_softmax(lg + A, lane, NV);
                     }
 #pragma unroll
                     for (int j = 0; j < NV; j++) val[j] = rl(pv, j);
                     const int prev_leaf = hr.leaf;
+                    if (sim < sa.sims) AZG_TSTAMP(evl, slot, lane, 1);
                     backup_path<G>(evl, slot, tree, hr, nodes, val, lane);
+                    if (sim < sa.sims) AZG_TSTAMP(evl, slot, lane, 3);
                     if (sim < sa.sims) {
                         wave_sync();
                         bool waited = false;
                         const unsigned long long *less = reinterpret_cast<const unsigned long long *>(ws + WS::LESS);
                         select_tree<G>(evl, slot, tree, hr, st, ctr0, lane, act, sink, [&](int node) {
                             if (waited || node != prev_leaf) return false;
+                            AZG_TSTAMP(evl, slot, lane, 9);
                             flag_wait_gen(sa.ev, &flags[0], sim); waited = true;
+                            AZG_TSTAMP(evl, slot, lane, 0);
                             return root_noise;
                         }, [&](int k, int ln, int &pos) {
                             if (k > 64) return false;
+                            AZG_TSTAMP(evl, slot, lane, 2);
                             flag_wait_gen(sa.ev, &flags[1], sim);
+                            AZG_TSTAMP(evl, slot, lane, 15);
                             pos = __popcll(less[ln] & (k == 64 ? ~0ULL : ((1ULL << k) - 1ULL)));
                             return true;
                         });

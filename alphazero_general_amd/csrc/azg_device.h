@@ -207,6 +207,20 @@ AZG_DEV float wave_sum_f(float m) {                            // every lane ret
     m += dpp_f<DPP_QUAD_XOR1>(m); m += dpp_f<DPP_QUAD_XOR2>(m); m += dpp_f<DPP_ROW_HALF_MIRROR>(m); m += dpp_f<DPP_ROW_MIRROR>(m);
     return (rl(m, 0) + rl(m, 16)) + (rl(m, 32) + rl(m, 48));
 }
+AZG_DEV int wave_max_i(int m) {                                // every lane returns the maximum over the 64 lanes
+    m = max(m, dpp_i<DPP_QUAD_XOR1>(m)); m = max(m, dpp_i<DPP_QUAD_XOR2>(m)); m = max(m, dpp_i<DPP_ROW_HALF_MIRROR>(m)); m = max(m, dpp_i<DPP_ROW_MIRROR>(m));
+    return max(max(rl(m, 0), rl(m, 16)), max(rl(m, 32), rl(m, 48)));
+}
+template <int CTRL> AZG_DEV double dpp_d(double x) {
+    union { double d; int i[2]; } c; c.d = x;
+    c.i[0] = dpp_i<CTRL>(c.i[0]); c.i[1] = dpp_i<CTRL>(c.i[1]);
+    return c.d;
+}
+// sum of 64 doubles by a fixed tree -- callers use it only where every partial sum is exact, so that the order does not matter
+AZG_DEV double wave_sum_d(double m) {
+    m += dpp_d<DPP_QUAD_XOR1>(m); m += dpp_d<DPP_QUAD_XOR2>(m); m += dpp_d<DPP_ROW_HALF_MIRROR>(m); m += dpp_d<DPP_ROW_MIRROR>(m);
+    return (rl(m, 0) + rl(m, 16)) + (rl(m, 32) + rl(m, 48));
+}
 AZG_DEV int wave_sum_i(int m) {                                // every lane returns the sum over the 64 lanes
     m += dpp_i<DPP_QUAD_XOR1>(m); m += dpp_i<DPP_QUAD_XOR2>(m); m += dpp_i<DPP_ROW_HALF_MIRROR>(m); m += dpp_i<DPP_ROW_MIRROR>(m);
     return (rl(m, 0) + rl(m, 16)) + (rl(m, 32) + rl(m, 48));
