@@ -421,7 +421,7 @@ template <class G> struct SearchArgs { View ev; int sims; using Game = G; static
 // b, wave BOARDS + b prepares its priors and shuffle (the two-wave scheme of k_backup_select2), the head convolutions leave their
 // features in LDS and the next tree phase computes the logits it needs from them (azg_kernels.h, sparse heads: the value
 // logits by the walker, the policy logits of the leaf's valid actions by the helper) -- the code of the launch-per-phase path.
-template <class G> struct SearchWide { View ev; int sims; HeadRows hd; using Game = G; static constexpr bool WIDE = true; };
+template <class G, int MINB = 1> struct SearchWide { View ev; int sims; HeadRows hd; using Game = G; static constexpr bool WIDE = true; static constexpr int MIN_BLOCKS = MINB; };
 
 // per-game LDS scratch of the wide search mode (behind the image)
 template <class G, int HW> struct WideScratch {
@@ -443,7 +443,7 @@ template <class G, int HW, int BOARDS> struct WideLds {
 
 // (the wide search mode keeps one workgroup per CU busy for a whole move and mixes three phases with different register needs:
 //  one wave per SIMD, the whole register file)
-template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else return SEARCH::WIDE ? 1 : 2; }
+template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else { if constexpr (SEARCH::WIDE) return SEARCH::MIN_BLOCKS; else return 2; } }
 
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
 __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {

@@ -854,8 +854,8 @@ extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, c
     hipStream_t s = (hipStream_t)stream;
     EvPair ep; const bool prof = sims > 0 && netprof_begin(s, ep);
     int r = AZG_E_UNSUPPORTED;
-    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 2, 64, 2, SearchWide<BR>>(s, P, SearchWide<BR>{e->v, sims, hd}, sims == 0);
-    else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM>>(s, P, SearchWide<TM>{e->v, sims, hd}, sims == 0);
+    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 1, 64, 1, SearchWide<BR>>(s, P, SearchWide<BR>{e->v, sims, hd}, sims == 0);
+    else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) r = launch_tower<TM::H, TM::W, 1, 32, 2, SearchWide<TM>>(s, P, SearchWide<TM>{e->v, sims, hd}, sims == 0);
     else { g_kev = nullptr; return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)"); }
     netprof_end(s, 2, prof, ep);
     return r;
