@@ -186,9 +186,10 @@ int  azg_root_probs(azg_engine *e, void *stream, float temp, float *probs_dev /*
 int  azg_root_value(azg_engine *e, void *stream, int average, float *value_dev /*[B]*/);          /* MCTS.value  :331-344 */
 /* MCTS.update_root(gs, a) (:185-195) on one slot's tree(s); the game state itself is NOT advanced. blocking. */
 int  azg_update_root(azg_engine *e, void *stream, int slot, int action);
-/* Node reclamation on demand: copy the subtree under the root of the slot's tree(s) (slot < 0: every slot) into the other
- * semi-space and drop everything else -- what azg_advance / azg_update_root do by themselves once less than one move's worth
- * of nodes is free.  force = 0: only trees that are that full.  Must not be called between a find_leaf and its process_results
+/* Node reclamation on demand -- the reference's counterpart is Python's GC freeing the siblings of the played move once
+ * MCTS.update_root rebinds _root (alphazero/MCTS.pyx:185-195): copy the subtree under the root of the slot's tree(s) (slot < 0:
+ * every slot) into the other semi-space and drop everything else -- what azg_advance / azg_update_root do by themselves once less
+ * than one move's worth of nodes is free.  force = 0: only trees that are that full.  Must not be called between a find_leaf and its process_results
  * (azg_select .. azg_backup): the pending leaf's indices are void afterwards.  Results never change. */
 int  azg_compact(azg_engine *e, void *stream, int slot, int force);
 /* children of a slot's root in list order (Node._children): a, n, q, p, v.  blocking; returns k or <0. */
@@ -300,8 +301,8 @@ int  azg_policy_value_heads_fact_f16(void *stream, const void *feat_dev, const v
  * the board's head features, -inf for every other action -- into logits_dev[row][logits_stride] (A policy logits, then P + 1 value
  * logits; a terminal leaf, which takes no evaluation, gets zeros).  Same arithmetic, so azg_heads_softmax + azg_backup /
  * azg_backup_select_logits on these rows reproduce azg_backup_select_features bit for bit: the evaluation a leaf receives on
- * the sparse-heads path (NNetWrapper.process masked to the valid moves, MCTS.pyx:239-245), exposed for callers and for parity
- * tests against the CPU oracle.  Arguments as azg_backup_select_features. */
+ * the sparse-heads path -- NNetWrapper.process (alphazero/NNetWrapper.py:225-232) restricted to the leaf's valid moves, which is
+ * all MCTS.process_results keeps of it (alphazero/MCTS.pyx:239-245) -- exposed for callers and for parity tests against the oracle.  Arguments as azg_backup_select_features. */
 int  azg_leaf_heads_sparse_f16(azg_engine *e, void *stream, const void *feat_dev, int feat_k, const void *head_rows_dev,
                                const float *head_b_dev, const int32_t *row_of_slot, float *logits_dev, int logits_stride);
 /* exp(log_softmax) of NNetArchitecture.py:112-118 on rows of logits (A policy logits then NV value logits, stride
