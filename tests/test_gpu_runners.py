@@ -271,6 +271,41 @@ def test_fused_search_kernel_tree_arena_overflow_is_reported():
     assert e2.counters()['sims'] == 37 * 60
 
 
+def test_example_buffer_overflow_is_reported():
+    """a training-example buffer that is too small for the finished games' samples (SelfPlayAgent.pyx:184-196 puts them on a queue
+    that cannot fill up): k_finalize must raise the sticky AZG_E_EXAMPLES_FULL BEFORE any sample is written past the buffer, and the
+    next counter read must report it."""
+    import torch
+    from alphazero_general_amd import _abi
+    from alphazero_general_amd.engine import DeviceEngine
+    B = 16
+    e = DeviceEngine(0, B, cpuct=1.25, fpu_reduction=0.2, seed=5, sims_hint=4, example_capacity=8, games_per_iteration=64)
+    pol = torch.full((B, 7), 1 / 7, dtype=torch.float32, device=e.device)
+    val = torch.full((B, 3), 1 / 3, dtype=torch.float32, device=e.device)
+    guard = torch.full((4096,), 7.0, device=e.device)                   # (allocated right after the engine's buffers)
+    with pytest.raises(_abi.AzgError) as ei:
+        for mv in range(64):                                            # a connect4 game ends within 42 plies: >= 7 positions x 2 symmetries > 8
+            e.select(None)
+            for s in range(3):
+                e.backup_select(pol, val, None)
+            e.backup(pol, val)
+            e.advance(record_history=True)
+            e.counters()
+    assert ei.value.code == _abi.E_EXAMPLES_FULL
+    assert (guard == 7.0).all()
+    e.close()
+    e2 = DeviceEngine(0, B, cpuct=1.25, fpu_reduction=0.2, seed=5, sims_hint=4, example_capacity=4096, games_per_iteration=64)
+    for mv in range(64):                                                # the same games with room for their samples
+        e2.select(None)
+        for s in range(3):
+            e2.backup_select(pol, val, None)
+        e2.backup(pol, val)
+        e2.advance(record_history=True)
+    c = e2.counters()
+    assert c['games_played'] > 0 and c['num_examples'] >= 14 * c['games_played']
+    e2.close()
+
+
 @pytest.mark.parametrize('game', ['brandubh', 'trimok'])
 def test_wide_search_kernel_tree_arena_overflow_is_reported(game):
     """the same for the two-wavefront persistent launch (azg_search_wide_f16): walker and helper of a game must both stop on the
