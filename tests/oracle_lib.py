@@ -188,6 +188,30 @@ class OGame:
         return self.s.cells_np(self.gi.cells)
 
 
+def br_wide_positions(n, seed):
+    """positions of the 7x7 tafl env in which the side to move has MORE THAN 64 legal moves (playouts from the start position stay
+    at <= 63, tests/golden/br_rules.npz max_k; the rules allow up to 96): eight pieces of the side that moves first scattered
+    over an almost empty board, the king and up to two of its men somewhere else."""
+    rng = np.random.RandomState(seed)
+    base = np.zeros(49, np.int8); base[[0, 6, 42, 48]] = 5; base[24] = 4        # escape corners, empty throne (cengine.pyx:24-32)
+    free = np.flatnonzero(base == 0)
+    out = []
+    for _ in range(400000):
+        if len(out) >= n:
+            break
+        c = base.copy()
+        pick = rng.choice(free, 9 + rng.randint(0, 3), replace=False)
+        c[pick[:8]] = 2; c[pick[8]] = 3; c[pick[9:]] = 1
+        st = State()
+        for i in range(49):
+            st.cells[i] = int(c[i])
+        g = OGame(GAME_BRANDUBH, state=st)
+        if not g.win_state().any() and int(g.valid_moves().sum()) > 64:
+            out.append(g)
+    assert len(out) == n
+    return out
+
+
 def mcts_args(game, cpuct=1.25, fpu_reduction=0.2, root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0,
               seed=0, stream=0):
     gi = game_info(game)

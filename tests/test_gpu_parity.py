@@ -521,6 +521,50 @@ def test_br_tree_vs_reference_goldens(torch_mod, cname):
     eng.close()
 
 
+@pytest.mark.parametrize('noise', [False, True])
+def test_br_nodes_with_more_than_64_children_vs_oracle(torch_mod, noise):
+    """The two-chunk paths of the tree kernels (a node's children spread over two lanes-of-64 passes: valid list, add_children with
+    the rank-by-key shuffle of k > 64 keys, best_child, leaf policy with numpy-order renormalisation, root noise over k > 64
+    children) are never reached by playouts from the start position.  Crafted positions with 65-74 legal moves, every simulation
+    against the oracle's MCTS on the same tape: paths, counts, q, priors bit for bit; both launch forms."""
+    torch = torch_mod
+    M, sims, seed, A, NV = 24, 48, 77, 588, 3
+    pos = ol.br_wide_positions(M, 11)
+    ks = [int(g.valid_moves().sum()) for g in pos]
+    assert min(ks) > 64 and max(ks) >= 70
+    oms = [ol.OMCTS(BR, seed=seed, stream=r) for r in range(M)]
+    engs = [engine(game=BR, B=M, seed=seed, add_root_noise=noise, sims_hint=sims) for _ in range(2)]    # phase launches, fused launch
+    for e in engs:
+        e.set_states([(g.cells(), g.player, g.turns, g.s.aux[0]) for g in pos])
+    obs = engs[0].new_obs()
+    engs[1].select(None)
+    for s in range(sims):
+        engs[0].select(obs)
+        o = obs.cpu().numpy()
+        pol, val = fake_batch(torch, seed, range(M), s, A, NV, engs[0].device)
+        for r in range(M):
+            leaf, _ = oms[r].find_leaf(pos[r])
+            assert (engs[0].last_path(r) == oms[r].last_path()).all() and (engs[1].last_path(r) == oms[r].last_path()).all(), (r, s)
+            assert (o[r] == leaf.observation()).all(), (r, s)
+            p, v = ol.fake_eval(seed, r, s, A, NV)
+            oms[r].process_results(v, p, noise=noise, temp=False)
+        engs[0].backup(pol, val)
+        if s + 1 < sims:
+            engs[1].backup_select(pol, val, None)
+        else:
+            engs[1].backup(pol, val)
+    for e in engs:
+        for r in range(M):
+            ch, och = e.root_children(r), oms[r].root_children()
+            assert len(ch['a']) == ks[r]
+            for f in ('a', 'n', 'q', 'p', 'v'):
+                assert (ch[f] == och[f]).all(), (f, r)
+        pr = e.root_probs(1.0).cpu().numpy()
+        assert all((pr[r] == oms[r].probs(1.0)).all() for r in range(M))
+        e.counters()
+        e.close()
+
+
 @pytest.mark.parametrize('launch', LAUNCHES)
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
 def test_br_agent_vs_reference_goldens(torch_mod, cname, kw, launch):

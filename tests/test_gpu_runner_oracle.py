@@ -223,3 +223,51 @@ def test_sparse_heads_launches_vs_oracle_bit_exact(game, B, sims):
         assert eo.shape == oo.shape and (eo == oo).all() and (ep == op).all() and (ez == oz).all()
         for x, y in zip(e.results(), ag.results()):
             assert (x == y).all()
+
+
+def test_sparse_heads_with_more_than_64_children_vs_oracle():
+    """The same three launch forms from roots with 65-70 legal moves (ol.br_wide_positions: playouts never get there): the sparse heads'
+    MFMA passes over five subtiles of 16 children, the shuffle without the pre-computed 64-key masks, two-chunk priors -- one move's
+    simulations against the oracle's MCTS fed the probabilities of the split launches, every engine against every other."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    Game, net = _setup('brandubh', 9)
+    hip = net._hip
+    gid, seed, M, sims = Game.AZG_GAME_ID, 41, 24, 64
+    pos = ol.br_wide_positions(M, 11)
+    ks = [int(g.valid_moves().sum()) for g in pos]
+    assert min(ks) > 64
+    kw = dict(cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=seed, sims_hint=sims)
+    ea, eb, ec = DeviceEngine(gid, M, **kw), DeviceEngine(gid, M, **kw), DeviceEngine(gid, M, **kw)
+    oms = [ol.OMCTS(gid, seed=seed, stream=r) for r in range(M)]
+    for e in (ea, eb, ec):
+        e.set_states([(g.cells(), g.player, g.turns, g.s.aux[0]) for g in pos])
+    ob = torch.zeros((M, 49, 8), dtype=torch.float16, device=ea.device)
+    oc = ec.new_obs(torch.float32)
+    hip.search(ea, sims)
+    eb.select(ob)
+    for s in range(sims):
+        eb.backup_select_features(hip.forward_features_nhwc8(ob, key=1), hip.head_rows, hip.head2_b, ob, select=s + 1 < sims)
+        ec.select(oc)
+        o = oc.cpu().numpy()
+        lg = ec.leaf_heads_sparse(hip.forward_features_nhwc8(hip.to_nhwc8(oc), key=2), hip.head_rows, hip.head2_b)
+        pol, val = ec.heads_softmax(lg)
+        ec.backup(pol, val)
+        pn, vn = pol.cpu().numpy(), val.cpu().numpy()
+        for r in range(M):
+            leaf, _ = oms[r].find_leaf(pos[r])
+            assert (ec.last_path(r) == oms[r].last_path()).all() and (o[r] == leaf.observation().reshape(o[r].shape)).all(), (r, s)
+            oms[r].process_results(vn[r], pn[r], noise=True, temp=True)
+    for r in range(M):
+        och = oms[r].root_children()
+        assert len(och['a']) == ks[r]
+        for e in (ea, eb, ec):
+            ch = e.root_children(r)
+            for f in ('a', 'n', 'q', 'p', 'v'):
+                assert (ch[f] == och[f]).all(), (f, r)
+    assert (ea.tape_counters() == ec.tape_counters()).all() and (eb.tape_counters() == ec.tape_counters()).all()
+    c = ea.counters()
+    assert c == eb.counters() and c == ec.counters() and c['sims'] == M * sims
+    for e in (ea, eb, ec):
+        e.close()
+
