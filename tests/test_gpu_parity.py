@@ -565,6 +565,56 @@ def test_br_nodes_with_more_than_64_children_vs_oracle(torch_mod, noise):
         e.close()
 
 
+@pytest.mark.parametrize('game,spread', [(BR, 95.0), (BR, 12.0), (0, 95.0), (2, 40.0)])
+def test_prior_spreads_from_denormal_to_one_vs_oracle(torch_mod, game, spread):
+    """Python's sum() over the visited children's priors (MCTS.pyx:91, double, list order) is taken by a reduction tree when the
+    priors' exponents prove every partial sum exact, by the serial loop otherwise (csrc/azg_kernels.h best_child).  Policies whose
+    entries span e^-spread .. 1 (spread 95: down to float32 denormals and exact zeros after renormalisation; spread 12: everything
+    inside the 22 binades of the exact case) put both forms, and the switch between them from one simulation to the next, against
+    the oracle: every path, and a / n / q / p / v of every root child at the end, bit for bit."""
+    torch = torch_mod
+    gi = ol.game_info(game)
+    A, NV, M, sims, seed = gi.action_size, gi.num_players + gi.has_draw, 32, 160, 5
+    rng = np.random.RandomState(int(spread) + game)
+    pos = []
+    for r in range(M):
+        g = ol.OGame(game)
+        for _ in range(rng.randint(0, 6)):
+            g.play(int(rng.choice(np.flatnonzero(g.valid_moves()))))
+        pos.append(g)
+    oms = [ol.OMCTS(game, seed=seed, stream=r, cpuct=1.0, fpu_reduction=-1.0) for r in range(M)]    # (a first-play BONUS: every child gets visited)
+    engs = [engine(game=game, B=M, seed=seed, cpuct=1.0, fpu_reduction=-1.0, sims_hint=sims) for _ in range(2)]
+    for e in engs:
+        e.set_states([(g.cells(), g.player, g.turns, g.s.aux[0]) if game == BR else ostate(g) for g in pos])
+    engs[1].select(None)
+    visited_max = 0
+    for s in range(sims):
+        engs[0].select(None)
+        pol = np.exp(-rng.uniform(0.0, spread, size=(M, A))).astype(np.float32)
+        val = rng.dirichlet(np.ones(NV), size=M).astype(np.float32)
+        for r in range(M):
+            oms[r].find_leaf(pos[r])
+            assert (engs[0].last_path(r) == oms[r].last_path()).all() and (engs[1].last_path(r) == oms[r].last_path()).all(), (r, s)
+            oms[r].process_results(val[r], pol[r])
+        tp, tv = torch.from_numpy(pol).to(engs[0].device), torch.from_numpy(val).to(engs[0].device)
+        engs[0].backup(tp, tv)
+        if s + 1 < sims:
+            engs[1].backup_select(tp, tv, None)
+        else:
+            engs[1].backup(tp, tv)
+    for r in range(M):
+        och = oms[r].root_children()
+        visited_max = max(visited_max, int((och['n'] > 0).sum()))
+        for e in engs:
+            ch = e.root_children(r)
+            for f in ('a', 'n', 'q', 'p', 'v'):
+                assert (ch[f] == och[f]).all(), (f, r)
+    assert visited_max > 6                                         # (the reduction tree is only taken above six visited children)
+    for e in engs:
+        e.counters()
+        e.close()
+
+
 @pytest.mark.parametrize('launch', LAUNCHES)
 @pytest.mark.parametrize('cname,kw', [('plain', dict()), ('noisy', dict(add_root_noise=True, add_root_temp=True)), ('wide', dict())])
 def test_br_agent_vs_reference_goldens(torch_mod, cname, kw, launch):
