@@ -271,3 +271,55 @@ def test_sparse_heads_with_more_than_64_children_vs_oracle():
     for e in (ea, eb, ec):
         e.close()
 
+
+@pytest.mark.parametrize('game', ['connect4', 'brandubh', 'trimok'])
+def test_persistent_launches_at_finished_and_almost_finished_roots(game):
+    """find_leaf at a root whose game is over returns the root itself (MCTS.pyx:213) and process_results backs the win state up
+    (:234-235) -- a simulation without an evaluation; one or two plies earlier most leaves are terminal.  The persistent launches
+    (azg_search_f16 / azg_search_wide_f16: the tower runs for the workgroup whether or not its game's leaf takes the result) against
+    the launch-per-phase form from such roots, and the visit count of a finished root against the oracle's."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    Game, net = _setup(game, 9)
+    hip = net._hip
+    gid, sims = Game.AZG_GAME_ID, 16
+    gi = ol.game_info(gid)
+    rng = np.random.RandomState(3)
+    pos = []
+    while len(pos) < 24:
+        g = ol.OGame(gid); hist = [g.clone()]
+        while not g.win_state().any():
+            g.play(int(rng.choice(np.flatnonzero(g.valid_moves())))); hist.append(g.clone())
+        pos += [hist[-1], hist[-2], hist[max(0, len(hist) - 3)]]
+    B = len(pos)
+    st = [(g.cells(), g.player, g.turns, g.s.aux[0]) if game == 'brandubh' else (g.cells(), g.player, g.turns) for g in pos]
+    ea, eb = DeviceEngine(gid, B, seed=1, sims_hint=sims), DeviceEngine(gid, B, seed=1, sims_hint=sims)
+    ea.set_states(st); eb.set_states(st)
+    hip.search(ea, sims)
+    if hip.fact_head:
+        ob = torch.zeros((B, gi.obs_h * gi.obs_w, 8), dtype=torch.float16, device=ea.device)
+        eb.select(ob)
+        for s in range(sims):
+            eb.backup_select_features(hip.forward_features_nhwc8(ob, key=1), hip.head_rows, hip.head2_b, ob, select=s + 1 < sims)
+    else:
+        obs = eb.new_obs()
+        for s in range(sims):
+            eb.select(obs)
+            eb.backup(*net.process(obs))
+    assert torch.equal(ea.root_counts(), eb.root_counts()) and torch.equal(ea.root_value(True), eb.root_value(True))
+    pa, pb = ea.root_probs(1.0), eb.root_probs(1.0)                # (a finished root has no children: counts / 0, never asked for by playMoves)
+    assert torch.equal(torch.isnan(pa), torch.isnan(pb)) and torch.equal(torch.nan_to_num(pa), torch.nan_to_num(pb))
+    assert (ea.tape_counters() == eb.tape_counters()).all()
+    c = ea.counters()
+    assert c == eb.counters() and c['sims'] == B * sims
+    uni_p, uni_v = np.ones(gi.action_size, np.float32), np.full(gi.num_players + gi.has_draw, 1.0, np.float32)
+    for r, g in enumerate(pos):
+        if g.win_state().any():
+            m = ol.OMCTS(gid, seed=1, stream=r)
+            for s in range(sims):
+                leaf, exp = m.find_leaf(g)
+                m.process_results(uni_v, uni_p)
+            ti = ea.tree_info(r)
+            assert ti['n'] == m.root_n == sims and ti['nodes_used'] == eb.tree_info(r)['nodes_used'] and ti['max_depth'] == 0, r
+    ea.close(); eb.close()
+
