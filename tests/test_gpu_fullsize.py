@@ -135,6 +135,54 @@ def test_arena_64_slots_vs_oracle_with_real_nets():
     assert (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all() and len(ws) >= games
 
 
+@pytest.mark.parametrize('game,B,sims,games', [('trimok', 48, 20, 52), ('brandubh', 32, 16, 34)])
+def test_arena_three_players_and_wide_heads_vs_oracle(game, B, sims, games):
+    """The batched Arena for the games whose heads are not fused into the tower (every simulation: device-side grouping of the leaf
+    rows by model, one evaluation per model, results routed back) and for THREE players (three trees per game, three models, a seat
+    permutation of three; Arena.pyx:208-328, SelfPlayAgent.pyx:44-47,117-132,142-151): the native runner against the CPU oracle fed by
+    the same networks until every slot has restarted.  Actions every round, tallies, results."""
+    import importlib
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.selfplay import ArenaRunner
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    P = Game.num_players()
+    nets = []
+    for m in range(P):
+        torch.manual_seed(20 + m)
+        n = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+        n.refresh()
+        nets.append(n)
+    gid, seed = Game.AZG_GAME_ID, 13
+    gi = ol.game_info(gid)
+    r = ArenaRunner(Game, nets, _args(numMCTSSims=sims, gamesPerIteration=games), num_slots=B, seed=seed)
+    ag = ol.OAgent(gid, B, sims=sims, games_per_iteration=games, seed=seed, cpuct=4.0, fpu_reduction=0.4, is_arena=True, ref_misroute=False)
+    assert ag.player_to_index() == r.player_to_index and sorted(r.player_to_index) == list(range(P))
+    rounds = 0
+    while ag.games_played < games:
+        ag.begin_round()
+        for _ in range(sims):
+            oobs, rg, rm = ag.generate_batch()
+            pol = np.zeros((B, gi.action_size), np.float32); val = np.zeros((B, gi.num_players + gi.has_draw), np.float32)
+            for m, n in enumerate(nets):
+                idx = np.flatnonzero(rm == m)
+                if len(idx):
+                    p, v = n.process(torch.from_numpy(oobs[idx]))
+                    pol[idx], val[idx] = p.cpu().numpy(), v.cpu().numpy()
+            ag.process_batch(pol, val)
+        ag.play_moves()
+        r.play_round()
+        assert (r.engine.last_actions().cpu().numpy() == ag.last_actions()).all(), rounds
+        rounds += 1
+    c = r.engine.counters()
+    assert c['games_played'] == ag.games_played == games and c['sims'] == ag.sims_done and c['expansions'] == ag.expansions
+    ws, turns, slot = r.engine.results()
+    ows, oturns, oslot = ag.results()
+    assert (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all() and len(ws) >= games
+    wins, draws, _ = r.results()
+    assert sum(wins) + draws == len(ws) >= c['games_played'] and len(wins) == P    # (every finished game is put on the result queue, SelfPlayAgent.pyx:178; the cap only stops the count)
+
+
 @pytest.mark.parametrize('game,B,sims,moves', [(0, 192, 24, 44), (1, 48, 40, 36)])
 def test_node_reclamation_is_invisible(game, B, sims, moves):
     """Semi-space compaction of the node store after a move (the GPU counterpart of the reference dropping the played move's
