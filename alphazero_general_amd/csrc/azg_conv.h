@@ -315,9 +315,15 @@ __device__ __forceinline__ void static_for(F &&f) {            // f(integral_con
 // tap 8 carry zero weights and re-read the centre).  3 k-steps instead of 9 one-eighth-full ones.  The weight ring runs on as in
 // conv_main2 (slot kk, prefetch WR - 1 k-steps ahead into the next layer).
 constexpr int STEM_KSTEPS = 3;
-template <class GEO, int NSUB, int WR>
-__device__ __forceinline__ void conv_stem(const char *in, const unsigned (&lb)[NSUB], int g, const half8 *wfrag, half8 (&a)[WR][2],
-                                          floatx4 (&acc)[2][NSUB]) {
+// (k-split towers: a wave's main stream starts at wmain and advances KSTR k-steps of the packed order per step of its own; KSTR = 1,
+//  wmain = wfrag + STEM_KSTEPS * WSTEP is the plain continuous stream)
+template <class GEO, int KSTR>
+__device__ __forceinline__ const half8 *stream_frag(const half8 *wfrag, const half8 *wmain, int step) {
+    return step < STEM_KSTEPS ? wfrag + (size_t)step * GEO::WSTEP : wmain + (size_t)(step - STEM_KSTEPS) * (KSTR * GEO::WSTEP);
+}
+template <class GEO, int NSUB, int WR, int KSTR = 1>
+__device__ __forceinline__ void conv_stem(const char *in, const unsigned (&lb)[NSUB], int g, const half8 *wfrag, const half8 *wmain,
+                                          half8 (&a)[WR][2], floatx4 (&acc)[2][NSUB]) {
     unsigned soff[STEM_KSTEPS];
 #pragma unroll
     for (int kk = 0; kk < STEM_KSTEPS; kk++) {
@@ -333,7 +339,7 @@ __device__ __forceinline__ void conv_stem(const char *in, const unsigned (&lb)[N
 #pragma unroll
         for (int kk = 0; kk < STEM_KSTEPS; kk++) {
             const int an = (kk + WR - 1) % WR, ac = kk % WR;
-            a[an][0] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP + 64];
+            { const half8 *f = stream_frag<GEO, KSTR>(wfrag, wmain, kk + WR - 1); a[an][0] = f[0]; a[an][1] = f[64]; }
 #pragma unroll
             for (int ps = 0; ps < NSUB; ps++) {
                 acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], b[kk][ps], acc[0][ps], 0, 0, 0);
@@ -344,7 +350,7 @@ __device__ __forceinline__ void conv_stem(const char *in, const unsigned (&lb)[N
 #pragma unroll
         for (int kk = 0; kk < STEM_KSTEPS; kk++) {
             const int an = (kk + WR - 1) % WR, ac = kk % WR;
-            a[an][0] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP + 64];
+            { const half8 *f = stream_frag<GEO, KSTR>(wfrag, wmain, kk + WR - 1); a[an][0] = f[0]; a[an][1] = f[64]; }
             half8 b[NSUB];
 #pragma unroll
             for (int ps = 0; ps < NSUB; ps++) b[ps] = *reinterpret_cast<const half8 *>(in + lb[ps] + soff[kk]);
@@ -365,9 +371,11 @@ struct TapPlan {                                             // which fragments 
     static constexpr int reads(int kk, int pf) { int n = 0; for (int ps = 0; ps < NSUB; ps++) n += act(kk * NSUB + ps + pf); return n; }
 };
 
-template <class GEO, int KS, int NSUB, int RB, int WR, bool SKIP>
+// KSTR: see stream_frag.  DUAL: the k-steps of the second half of every tap's channels accumulate into accB (the caller adds the two
+// sets at the end): the summation order of the k-split form, so that a board's outputs do not depend on the tile shape.
+template <class GEO, int KS, int NSUB, int RB, int WR, bool SKIP, int KSTR = 1, bool DUAL = false>
 __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[NSUB], const half8 *wfrag, half8 (&a)[WR][2],
-                                           floatx4 (&acc)[2][NSUB]) {
+                                           floatx4 (&acc)[2][NSUB], floatx4 (&accB)[2][NSUB]) {
     // fragment t = (kk, ps) is read PF fragments ahead into a register ring.  Large tiles index the ring by subtile (slot
     // ps % RING: collision-free with PF = 4 for NSUB = 11 at RING = 6, checked case by case; one slot per subtile otherwise);
     // small tiles (NSUB <= 4, the low-latency shapes for small batches) by fragment number, RING = PF + 1.
@@ -385,15 +393,20 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
     static_for<0, NSTEP>([&](auto ki) __attribute__((always_inline)) {
         constexpr int kk = decltype(ki)::value;
         constexpr int an = (RB + kk + WR - 1) % WR, ac = (RB + kk) % WR;
-        a[an][0] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * GEO::WSTEP + 64];
+        a[an][0] = wfrag[(size_t)(kk + WR - 1) * (KSTR * GEO::WSTEP)]; a[an][1] = wfrag[(size_t)(kk + WR - 1) * (KSTR * GEO::WSTEP) + 64];
         static_for<0, NSUB>([&](auto pi) __attribute__((always_inline)) {
             constexpr int ps = decltype(pi)::value;
             constexpr int t = kk * NSUB + ps, psn = (ps + PF) % NSUB;
             constexpr int cur = (TRING ? t : ps) % RING, nxt = (TRING ? t + PF : psn) % RING;
             if constexpr (TP::act(t + PF)) bb[nxt] = *reinterpret_cast<const half8 *>(in + lb[psn] + FO::get(t + PF));
             if constexpr (TP::act(t)) {
-                acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur], acc[0][ps], 0, 0, 0);
-                acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur], acc[1][ps], 0, 0, 0);
+                if constexpr (DUAL && (kk % KS) >= KS / 2) {
+                    accB[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur], accB[0][ps], 0, 0, 0);
+                    accB[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur], accB[1][ps], 0, 0, 0);
+                } else {
+                    acc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][0], bb[cur], acc[0][ps], 0, 0, 0);
+                    acc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ac][1], bb[cur], acc[1][ps], 0, 0, 0);
+                }
             }
         });
         constexpr int NR = TP::reads(kk, PF), NM = TP::mfmas(kk);
@@ -445,15 +458,26 @@ template <class G, int HW, int BOARDS> struct WideLds {
 //  one wave per SIMD, the whole register file)
 template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else { if constexpr (SEARCH::WIDE) return SEARCH::MIN_BLOCKS; else return 2; } }
 
-template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
-__global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
+// KSPLIT = 2 (64-channel towers of one board): the two 32-channel k-steps of every tap go to two wave groups -- wave = (cout group
+// cg, pixel group ph, k group kg), every wave runs 9 k-steps over ALL its pixel group's subtiles and finishes half of them: the
+// partial sums of the other half go to the partner through LDS.  No weight fragment is fetched twice (unlike a pixel split), every
+// SIMD gets a wave of each of the CU's two workgroups, and a wave's load issue hides under the other's MFMAs.
+// KHALF order (7x7 x 64 channels, every tile shape): out = (bias + sum over the first channel half) + (sum over the second half).
+template <int H, int W, int C> constexpr bool tower_khalf_order() { return H == 7 && W == 7 && C == 64; }
+template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch, int KSPLIT = 1>
+__global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     constexpr bool IS_WIDE = []() { if constexpr (IS_SEARCH) return SEARCH::WIDE; else return false; }();
     static_assert(!IS_SEARCH || IS_WIDE || (PSPLIT == 1 && C == 128 && BOARDS == C / 32), "search mode: one wave per game, fused heads");
     static_assert(!IS_WIDE || (C / 32) * PSPLIT >= 2 * BOARDS, "wide search mode: a walker and a helper wavefront per game");
     TowerParams P = Pin;
-    constexpr int NT = C * 2 * PSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
+    constexpr int NT = C * 2 * PSPLIT * KSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
+    constexpr bool KHALF = tower_khalf_order<H, W, C>();
+    constexpr int XCHG_OFF = []() {                              // the k-split exchange area: behind the image and the wide search mode's scratch
+        if constexpr (IS_WIDE) return GEO::TILE + WideLds<typename SEARCH::Game, GEO::HW, BOARDS>::BYTES; else return GEO::TILE;
+    }();
+    static_assert(KSPLIT == 1 || (KSPLIT == 2 && KS == 2 && KHALF), "k-split: 64-channel towers in k-half order");
     constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
     constexpr bool TAPSKIP = PSPLIT == 1 && GEO::CLASSES > 1;   // (a wave's subtile numbers must be compile-time constants)
     constexpr int HW = GEO::HW, ROWS = GEO::ROWS, TILE = GEO::TILE, RS = GEO::RSTRIDE;
@@ -463,8 +487,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
     static_assert(!IS_SEARCH || IS_WIDE || SCRATCH_PV + 1024 <= (GEO::LEAD + GEO::PW) * RS, "scratch must stay inside the pad rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
-    const int cg = wave % (C / 32), ph = wave / (C / 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15, lane_k = lane;
+    const int cg = wave % (C / 32), ph = (wave / (C / 32)) % PSPLIT, kg = wave / ((C / 32) * PSPLIT);
     int ntiles = (Pin.boards + BOARDS - 1) / BOARDS;
     if (Pin.rows_per_model) {
         ntiles = 0;
@@ -496,7 +520,17 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
     const unsigned slot_role = __builtin_amdgcn_s_getreg(63492) & 1;       // HW_ID.wave_id parity: the two waves of a SIMD differ
     half8 a[WR][2];
     floatx4 acc[2][NSUB];
-    half2v sreg[NSUB][4];
+    constexpr int NOWN = NSUB / KSPLIT;                          // subtiles whose sums this wave finishes (k-split: ps in [kg * NOWN, + NOWN))
+    static_assert(NSUB % KSPLIT == 0, "k-split: an even number of subtiles per wave");
+    half2v sreg[NOWN][4];
+    unsigned lbo[NOWN];                                          // their image rows, their live bits
+    unsigned liveown = 0;
+#pragma unroll
+    for (int j = 0; j < NOWN; j++) {
+        lbo[j] = lb[j];
+        liveown |= ((livemask >> j) & 1u) << j;
+        if constexpr (KSPLIT == 2) { if (kg) { lbo[j] = lb[j + NOWN]; liveown = (liveown & ~(1u << j)) | (((livemask >> (j + NOWN)) & 1u) << j); } }
+    }
     __syncthreads();
 
 #ifdef AZG_TOWER_TIMING
@@ -526,12 +560,19 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
             }
         }
         const half8 *wl = reinterpret_cast<const half8 *>(P.w) + (size_t)(2 * cg) * 64 + lane;
+        const half8 *wm0 = wl + (size_t)(STEM_KSTEPS + (KSPLIT == 2 ? kg : 0)) * GEO::WSTEP;      // the wave's main stream (see stream_frag)
         const int row0 = tile * ROWS;
         const int rows_here = min(ROWS, P.boards * HW - row0);
         int nsims = 1;
         if constexpr (IS_SEARCH) nsims = sa.sims + (IS_WIDE ? 1 : 0);  // (wide: the last iteration is the last backup, no tower)
         [[maybe_unused]] bool lds_live = false;                  // wide search: the games' tree state is in LDS (written back after the loop)
         for (int sim = 0; sim < nsims; sim++) {
+        // (wide search mode: an opaque copy of the lane id, new in every simulation.  Nothing a phase derives from it is invariant in
+        //  the simulation loop, so LLVM cannot hoist one phase's per-lane constants out of the loop, where they would stay live through
+        //  the OTHER phases and add to their registers instead of sharing them -- the launch has to fit two waves per SIMD)
+        int lane_sim = lane_k;
+        if constexpr (IS_WIDE) asm volatile("" : "+v"(lane_sim));
+        const int lane = lane_sim, tid = wave * 64 + lane, g = lane >> 4, i16 = lane & 15;
 #ifdef AZG_TOWER_TIMING
         unsigned long long wt_[6] = {0, 0, 0, 0, 0, 0};
 #define AZG_WPHASE(i) do { if (IS_WIDE) wt_[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -662,7 +703,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 if (has_policy) {
                     Node *nodes = tree_nodes(sa.ev, tree, hr.base);
                     float *pi = reinterpret_cast<float *>(ws + WS::PI);
-                    leaf_policy_logits<G>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
+                    leaf_policy_logits<G, tower_min_blocks<SEARCH>() == 1>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
                     wave_sync();
                     AZG_HSTAMP(3);
                     policy_softmax_row<A>(lg, lane, A, pi);
@@ -731,9 +772,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
 #ifdef AZG_TOWER_TIMING
         if (P.dbg && tid == 0) P.dbg[1024 + blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
 #endif
-        const half8 *wt = wl;
+        const half8 *wt = wm0;
 #pragma unroll
-        for (int j = 0; j < WR - 1; j++) { a[j][0] = wt[(size_t)j * GEO::WSTEP]; a[j][1] = wt[(size_t)j * GEO::WSTEP + 64]; }
+        for (int j = 0; j < WR - 1; j++) { const half8 *f = stream_frag<GEO, KSPLIT>(wl, wm0, j); a[j][0] = f[0]; a[j][1] = f[64]; }
 #ifdef AZG_TOWER_TIMING
         asm volatile("s_waitcnt vmcnt(0)");
         if (P.dbg && tid == 0) P.dbg[1024 + blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
@@ -762,7 +803,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const int c0 = (2 * cg + m) * 16 + g * 4;
-                const floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
+                floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
+                if constexpr (KSPLIT == 2) { if (kg && layer) bv = (floatx4){0.f, 0.f, 0.f, 0.f}; }   // (the stem is not split: both k groups run it whole)
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
             }
@@ -784,28 +826,72 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 }
             };
             if constexpr (AFFINE_EARLY) fetch_affine();
-            if (layer == 0) { conv_stem<GEO, NSUB, WR>(smem, lb, g, wt, a, acc); wt += (size_t)STEM_KSTEPS * GEO::WSTEP; }
-            else { conv_main2<GEO, KS, NSUB, STEM_KSTEPS % WR, WR, TAPSKIP>(smem, lb, wt, a, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
+            if (layer == 0) conv_stem<GEO, NSUB, WR, KSPLIT>(smem, lb, g, wl, wm0, a, acc);
+            else if constexpr (KSPLIT == 2) {                   // this wave's channel half: the image rows shifted by kg * 64 bytes, 9 k-steps
+                conv_main2<GEO, 1, NSUB, STEM_KSTEPS % WR, WR, TAPSKIP, 2>(smem + kg * 64, lb, wt, a, acc, acc);
+                wt += (size_t)9 * KS * GEO::WSTEP;
+            } else if constexpr (KHALF) {
+                floatx4 accB[2][NSUB];
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int ps = 0; ps < NSUB; ps++) accB[m][ps] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                conv_main2<GEO, KS, NSUB, STEM_KSTEPS % WR, WR, TAPSKIP, 1, true>(smem, lb, wt, a, acc, accB);
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int ps = 0; ps < NSUB; ps++) acc[m][ps] += accB[m][ps];
+                wt += (size_t)9 * KS * GEO::WSTEP;
+            } else { conv_main2<GEO, KS, NSUB, STEM_KSTEPS % WR, WR, TAPSKIP>(smem, lb, wt, a, acc, acc); wt += (size_t)9 * KS * GEO::WSTEP; }
             AZG_STAMP2(1);
             if constexpr (!AFFINE_EARLY) fetch_affine();
+            // k-split: the partial sums of the subtiles the PARTNER finishes go to it through LDS (this wave's region, 1 KB per
+            // accumulator tile), those of this wave's own subtiles come back after the barrier: out = first half + second half
+            [[maybe_unused]] char *xown = nullptr, *xpar = nullptr;
+            if constexpr (KSPLIT == 2) {
+                char *xb = smem + XCHG_OFF + lane * 16;
+                xown = xb + wave * (2 * NOWN * 1024);
+                xpar = xb + (wave ^ ((C / 32) * PSPLIT)) * (2 * NOWN * 1024);
+                if (layer) {
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+#pragma unroll
+                        for (int j = 0; j < NOWN; j++)
+                            *reinterpret_cast<floatx4 *>(xown + (m * NOWN + j) * 1024) = kg ? acc[m][j] : acc[m][j + NOWN];
+                }
+            }
             __syncthreads();                                    // every wave is done reading the image
             AZG_STAMP2(2);
+            floatx4 fin[2][NOWN];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int j = 0; j < NOWN; j++) {
+                    fin[m][j] = acc[m][j];
+                    if constexpr (KSPLIT == 2) {
+                        if (kg) fin[m][j] = acc[m][j + NOWN];
+                        if (layer) {
+                            const floatx4 o = *reinterpret_cast<const floatx4 *>(xpar + (m * NOWN + j) * 1024);
+                            fin[m][j] = kg ? o + fin[m][j] : fin[m][j] + o;      // (first half + second half, whoever adds)
+                        }
+                    }
+                }
             int oz = 0;                                         // opaque zero: the store offsets lb + edelta are loop invariants that
             asm volatile("" : "+s"(oz));                        // LLVM would otherwise precompute, keep live across the main loop and spill
 #pragma unroll
-            for (int ps = 0; ps < NSUB; ps++) {
+            for (int ps = 0; ps < NOWN; ps++) {
                 half2v v[4];
                 {
                     union { half2v h; unsigned u; } a0, a1, b0, b1;
-                    a0.h = (half2v){(_Float16)acc[0][ps][0], (_Float16)acc[0][ps][1]}; a1.h = (half2v){(_Float16)acc[0][ps][2], (_Float16)acc[0][ps][3]};
-                    b0.h = (half2v){(_Float16)acc[1][ps][0], (_Float16)acc[1][ps][1]}; b1.h = (half2v){(_Float16)acc[1][ps][2], (_Float16)acc[1][ps][3]};
+                    a0.h = (half2v){(_Float16)fin[0][ps][0], (_Float16)fin[0][ps][1]}; a1.h = (half2v){(_Float16)fin[0][ps][2], (_Float16)fin[0][ps][3]};
+                    b0.h = (half2v){(_Float16)fin[1][ps][0], (_Float16)fin[1][ps][1]}; b1.h = (half2v){(_Float16)fin[1][ps][2], (_Float16)fin[1][ps][3]};
                     auto r0 = __builtin_amdgcn_permlane16_swap(a0.u, b0.u, false, false);
                     auto r1 = __builtin_amdgcn_permlane16_swap(a1.u, b1.u, false, false);
                     a0.u = r0[0]; b0.u = r0[1]; a1.u = r1[0]; b1.u = r1[1];
                     v[0] = a0.h; v[1] = a1.h; v[2] = b0.h; v[3] = b1.h;
                 }
-                const unsigned off = lb[ps] + (edelta + (unsigned)oz);
-                const bool lv = (livemask >> ps) & 1;
+                const unsigned off = lbo[ps] + (edelta + (unsigned)oz);
+                const bool lv = (liveown >> ps) & 1;
                 if (!is_s) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = __builtin_elementwise_max(v[j], zero2);
@@ -843,28 +929,28 @@ __global__ __launch_bounds__(C * 2 * PSPLIT, tower_min_blocks<SEARCH>()) void k_
                 int opaque = 0;
                 asm volatile("" : "+s"(opaque));                 // (keeps these loop invariants from being hoisted across the layers)
                 const half8 *hw1 = reinterpret_cast<const half8 *>(P.head1_w) + lane + opaque;
-                floatx4 hacc[2][NSUB];
+                floatx4 hacc[2][NOWN];                          // (k-split: each k group does the subtiles it finished)
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
                     const int c0 = m * 16 + g * 4;
                     const floatx4 bv = {P.head1_b[c0], P.head1_b[c0 + 1], P.head1_b[c0 + 2], P.head1_b[c0 + 3]};
 #pragma unroll
-                    for (int ps = 0; ps < NSUB; ps++) hacc[m][ps] = bv;
+                    for (int ps = 0; ps < NOWN; ps++) hacc[m][ps] = bv;
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     const half8 a0 = hw1[(size_t)(ks * 2) * 64], a1 = hw1[(size_t)(ks * 2 + 1) * 64];
 #pragma unroll
-                    for (int ps = 0; ps < NSUB; ps++) {
-                        const half8 b = *reinterpret_cast<const half8 *>(img + lb[ps] + (GEO::BIAS + ks * 64));
+                    for (int ps = 0; ps < NOWN; ps++) {
+                        const half8 b = *reinterpret_cast<const half8 *>(img + lbo[ps] + (GEO::BIAS + ks * 64));
                         hacc[0][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, hacc[0][ps], 0, 0, 0);
                         hacc[1][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, hacc[1][ps], 0, 0, 0);
                     }
                 }
                 _Float16 *fg = reinterpret_cast<_Float16 *>(P.feat);
 #pragma unroll
-                for (int ps = 0; ps < NSUB; ps++) {
-                    const int gs = ph * NSUB + ps;
+                for (int ps = 0; ps < NOWN; ps++) {
+                    const int gs = ph * NSUB + ps + (KSPLIT == 2 ? kg * NOWN : 0);
                     const int p = gs < NSUBT ? pixmap[min(gs, NSUBT - 1) * 16 + i16] : -1;
                     if (p >= 0 && p < rows_here) {
                         const int bd = p / HW, pos = p - bd * HW;

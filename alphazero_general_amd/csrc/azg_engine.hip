@@ -591,14 +591,16 @@ extern "C" int azg_last_actions_dev(azg_engine *e, int32_t **actions) {
     return AZG_OK;
 }
 
-template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch>
+template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch, int KSPLIT = 1>
 static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}, bool init_only = false) {
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     using GEO = TowerGeom<H, W, BOARDS, C>;
-    constexpr size_t LDS_BYTES = []() {                        // the image (+ the wide search mode's scratch behind it)
+    constexpr size_t LDS_IMG = []() {                          // the image (+ the wide search mode's scratch behind it)
         if constexpr (IS_SEARCH) { if constexpr (SEARCH::WIDE) return (size_t)GEO::TILE + (size_t)WideLds<typename SEARCH::Game, H * W, BOARDS>::BYTES; }
         return (size_t)GEO::TILE;
     }();
+    // (+ the k-split exchange area: per wave one 1 KB accumulator tile for each of the 2 x NSUB / 2 tiles its partner finishes)
+    constexpr size_t LDS_BYTES = LDS_IMG + (KSPLIT == 2 ? (size_t)(C / 32 * PSPLIT * 2) * ((GEO::NSUB + PSPLIT - 1) / PSPLIT) * 1024 : 0);
     // per (instantiation, device): the pixel -> (subtile, lane) table, a few hundred bytes that live as long as the process
     // (the table is a pure function of the template arguments); first use is serialised
     static int16_t *d_map[16] = {nullptr};
@@ -614,7 +616,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
             int16_t *d = nullptr;
             HIPCHK(hipMalloc((void **)&d, sizeof(map)));
             HIPCHK(hipMemcpy(d, map, sizeof(map), hipMemcpyHostToDevice));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             d_map[dev] = d;
         }
     }
@@ -629,7 +631,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
         static unsigned long long *dbg = nullptr; static int calls = 0;
         if (!dbg) { HIPCHK(hipMalloc((void **)&dbg, (2048 + 4096 * 8) * 8)); HIPCHK(hipMemset(dbg, 0, (2048 + 4096 * 8) * 8)); }
         TowerParams Q = P; Q.dbg = dbg;
-        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), LDS_BYTES, s, Q, (const int16_t *)d_map[dev], sa);
+        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>), dim3(grid), dim3(C * 2 * PSPLIT * KSPLIT), LDS_BYTES, s, Q, (const int16_t *)d_map[dev], sa);
         if constexpr (IS_SEARCH) if constexpr (SEARCH::WIDE) {
             static unsigned long long w[512 * 4];
             HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(w, dbg + 2048 + 4096 * 4, sizeof(unsigned long long) * 4 * (grid < 512 ? grid : 512), hipMemcpyDeviceToHost));
@@ -663,7 +665,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
                                                    w[b * 8 + 4] - w[b * 8], w[b * 8 + 5] - w[b * 8 + 4], w[b * 8 + 6] - w[b * 8 + 5], w[b * 8 + 7] - w[b * 8 + 6], w[b * 8 + 1] - w[b * 8 + 7]);
         }
 #else
-        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH>), dim3(grid), dim3(C * 2 * PSPLIT), LDS_BYTES, s, P, (const int16_t *)d_map[dev], sa);
+        AZG_LAUNCH((k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>), dim3(grid), dim3(C * 2 * PSPLIT * KSPLIT), LDS_BYTES, s, P, (const int16_t *)d_map[dev], sa);
 #endif
     }
     HIPCHK(hipGetLastError());
@@ -746,8 +748,10 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
     if (game == AZG_GAME_BRANDUBH && channels == 64) {           // two cout groups: split the pixels too at small batches
         // measured (us per evaluation incl. heads, 256 / 512 / 1024 / 2048 boards): 1 board, no split 39 / 47 / 66 / 107;
         // 1 board, split 35 / 46 / 80 / 113; 2 boards, split 39 / 43 / 63 / 113
-        const int bt = forced ? forced : n <= 256 ? 1 : 2;
-        const int sp = psplit ? psplit : n <= 1024 ? 2 : 1;
+        // round 3, the k-split 1-board tile (`sp == 3`): 28 / 36 / 64 / 114 -- the shape up to 512 boards
+        const int bt = forced ? forced : n <= 512 ? 1 : 2;
+        const int sp = psplit ? psplit : n <= 512 ? 3 : n <= 1024 ? 2 : 1;
+        if (bt == 1 && sp == 3) return launch_tower<BR::H, BR::W, 1, 64, 1, NoSearch, 2>(s, P);   // k-split: 4 waves = (cout group, k group)
         if (bt == 1 && sp == 2) return launch_tower<BR::H, BR::W, 1, 64, 2>(s, P);
         if (bt == 1) return launch_tower<BR::H, BR::W, 1, 64>(s, P);
         if (sp == 2) return launch_tower<BR::H, BR::W, 2, 64, 2>(s, P);
@@ -854,7 +858,7 @@ extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, c
     hipStream_t s = (hipStream_t)stream;
     EvPair ep; const bool prof = sims > 0 && netprof_begin(s, ep);
     int r = AZG_E_UNSUPPORTED;
-    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 1, 64, 1, SearchWide<BR>>(s, P, SearchWide<BR>{e->v, sims, hd}, sims == 0);
+    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 1, 64, 1, SearchWide<BR, 2>, 2>(s, P, SearchWide<BR, 2>{e->v, sims, hd}, sims == 0);
     else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) r = launch_tower<TM::H, TM::W, 1, 32, 2, SearchWide<TM>>(s, P, SearchWide<TM>{e->v, sims, hd}, sims == 0);
     else { g_kev = nullptr; return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)"); }
     netprof_end(s, 2, prof, ep);

@@ -514,7 +514,9 @@ struct HeadDot {
 // fetched while the current chain runs (one 16-byte load per lane and k-step, FK / 32 of them in flight: the job is L2 latency, 64 KB
 // of rows per leaf), the biases travel with the rows.  Same association in every kernel that calls it.
 typedef float hfloatx4 __attribute__((ext_vector_type(4)));
-template <class G>
+// TWO_BUFFERS = false (launches that must fit two waves per SIMD): one row buffer, the gather of a subtile is not hidden under the
+// previous chain.  Same arithmetic either way.
+template <class G, bool TWO_BUFFERS = true>
 AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, int k, const _Float16 *feat, float *lg, int lane) {
     constexpr int A = G::A, FK = head_fk<G>(), KSTEPS = FK / 32, NCH = (G::MAXK + 63) / 64;
     for (int a = lane; a < A; a += 64) lg[a] = -INFINITY;
@@ -534,8 +536,10 @@ AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, i
     };
     // two row buffers: while the chain of 16 children runs out of one, the rows of the next 16 land in the other (the loads are
     // issued BEFORE the chain: the compiler keeps program order between loads and the MFMAs that read their registers)
-    hrow8 wa[KSTEPS], wb[KSTEPS];
-    float bias_a, bias_b;
+    hrow8 wa[KSTEPS];
+    [[maybe_unused]] hrow8 wb[TWO_BUFFERS ? KSTEPS : 1];
+    float bias_a;
+    [[maybe_unused]] float bias_b;
     auto fetch = [&](int sub, hrow8 (&w)[KSTEPS], float &bias) {
         const int an = action_of(min(16 * sub + i16, k - 1));
         const _Float16 *rn = hd.rows + (size_t)an * hd.fk + g * 8;
@@ -561,6 +565,14 @@ AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, i
         const float bw = __int_as_float(__builtin_amdgcn_ds_bpermute((4 * g + (i16 & 3)) << 2, __float_as_int(bias)));
         if (i16 < 4 && child < k) lg[aw] = x + bw;
     };
+    if constexpr (!TWO_BUFFERS) {
+        for (int s = 0; s < nsub; s++) {
+            fetch(s, wa, bias_a);
+            __builtin_amdgcn_sched_barrier(0);
+            chain(s, wa, bias_a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     fetch(0, wa, bias_a);
     for (int s = 0; s < nsub; s += 2) {                                      // (sched_barrier: left alone the scheduler sinks the loads
         if (s + 1 < nsub) fetch(s + 1, wb, bias_b);                          //  of the next subtile below the chain that should hide them;
@@ -572,6 +584,7 @@ AZG_DEV void leaf_policy_logits(const HeadRows &hd, const Node *nodes, int fc, i
         __builtin_amdgcn_sched_barrier(0);
         chain(s + 1, wb, bias_b);
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
 }
 // the P + 1 value logits of a board into lg[0 .. NV) (one wavefront, one pass).  feat: the board's value features.
