@@ -263,9 +263,10 @@ int  azg_search_f16(azg_engine *e, void *stream, const void *w_packed_dev, const
                     const float *pre_shift_dev, int nblocks, const void *head_w_packed_dev, const float *head_b_dev, int sims);
 
 /* The same for networks with FACTORISED heads (wide action spaces): brandubh x 64 channels and the 3-player env x 32 channels, ONE
- * game per workgroup of two wavefronts (the games of a CU then never wait for each other).  Per simulation: one wavefront walks
- * the game's tree and its partner prepares the priors and the shuffle, the two run the tower on the leaf planes left in LDS, the 1x1 head convolutions leave their features in
- * LDS, and the next tree phase computes the logits it needs from them (azg_backup_select_features' code).  Results are
+ * game per workgroup (the games of a CU then never wait for each other) of four wavefronts for brandubh (cout group x k group: two
+ * waves of different games on every SIMD), two for the 3-player env.  Per simulation: one wavefront walks the game's tree and a
+ * second prepares the priors and the shuffle, all of them run the tower on the leaf planes left in LDS, the 1x1 head convolutions
+ * leave their features in LDS, and the next tree phase computes the logits it needs from them (azg_backup_select_features' code).  Results are
  * identical to `sims` x [azg_select / azg_backup_select_features, azg_resnet_tower_features_f16] + a final
  * azg_backup_select_features without select.  Parameters as those two functions take them; sims == 0: one-time setup only. */
 int  azg_search_wide_f16(azg_engine *e, void *stream, const void *w_packed_dev, const float *bias_dev, const float *pre_scale_dev,
