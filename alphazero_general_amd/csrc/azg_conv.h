@@ -603,7 +603,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             int slot = tile * BOARDS + bd;
             asm volatile("" : "+v"(slot));                       // (opaque: nothing of the trees is hoisted out of the simulation loop)
             slot = __builtin_amdgcn_readfirstlane(slot);
-            const bool livegame = slot < sa.ev.B && role < 2;
+            // (k-split workgroups have wavefronts to spare in the tree phase: the third one takes the shuffle masks off the helper)
+            constexpr bool MASK_WAVE = NT / 64 >= 3 * BOARDS;
+            const bool livegame = slot < sa.ev.B && role < (MASK_WAVE ? 3 : 2);
             const int tree = slot;                               // (self-play engines only: one tree per slot)
             // The tree functions reach the header, the path, the tape counter, the tallies and the root state through the View's
             // pointers: here those point into the game's LDS scratch (offset so that [tree] / [slot] lands on it), so that every
@@ -687,6 +689,11 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                         });
                     }
                 }
+            } else if (MASK_WAVE && livegame && role == 2) {         // the shuffle of the next expansion (every expansion waits for it)
+                if (sim > 0 && sim < sa.sims) {
+                    reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+                    flag_set_gen(&flags[1], sim, lane);
+                }
             } else if (livegame && sim > 0) {                        // the helper: shuffle of the next expansion, priors of the previous leaf
 #ifdef AZG_TOWER_TIMING
                 unsigned long long ht_[6] = {wt_[0], 0, 0, 0, 0, 0};
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
 #define AZG_HSTAMP(i) do { } while (0)
 #endif
                 AZG_HSTAMP(1);
-                if (sim < sa.sims) {                                 // (masks first: every expansion waits for them, see k_backup_select2)
+                if (!MASK_WAVE && sim < sa.sims) {                   // (masks first: every expansion waits for them, see k_backup_select2)
                     reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
                     flag_set_gen(&flags[1], sim, lane);
                 }
