@@ -515,7 +515,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
         lb[ps] = (unsigned)(q * RS + g * 16 - GEO::BIAS);
     }
     const unsigned edelta = (unsigned)(GEO::BIAS - g * 16 + ecol * 2);      // epilogue cell of a pixel = fragment base + edelta
-    constexpr int WR = WeightRing<NSUB, C / 32>::N;
+    // (the four-wave search launch: two waves per SIMD cover each other's weight latency, and its registers are the scarce resource --
+    //  a ring of 3 k-steps instead of 9: 82 -> 48 spilled registers, launch 5.47 -> 5.38 ms)
+    constexpr int WR = (IS_WIDE && KSPLIT == 2) ? 3 : WeightRing<NSUB, C / 32>::N;
     static_assert((9 * (C / 32)) % WR == 0, "a layer must advance the weight ring by whole turns");
     const unsigned slot_role = __builtin_amdgcn_s_getreg(63492) & 1;       // HW_ID.wave_id parity: the two waves of a SIMD differ
     half8 a[WR][2];
