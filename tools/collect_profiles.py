@@ -63,7 +63,10 @@ def short(name):
 
 def pmc_averages(outdir):
     acc = {}
-    for f in glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True):
+    # (gpurun merges a call's output INTO the local directory: files of earlier collections -- their names carry the profiler's process
+    #  id -- stay next to the new ones; only the newest run counts)
+    files = glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = short(row['Kernel_Name'])
@@ -90,7 +93,7 @@ def main():
         out, line, rc = rocprof('kt_' + w, ['--kernel-trace', '--stats'], base + ['--steps', '12', '--warmup', '2'])
         stats = glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True)
         if stats:
-            shutil.copy(stats[0], os.path.join(PROF, ROUND + '_%s_kernel_stats.csv' % w))
+            shutil.copy(max(stats, key=os.path.getmtime), os.path.join(PROF, ROUND + '_%s_kernel_stats.csv' % w))
         if line:
             with open(os.path.join(PROF, ROUND + '_%s_bench_line_under_rocprof.json' % w), 'w') as fh:
                 fh.write(line + '\n')
