@@ -444,7 +444,8 @@ template <class G, int HW> struct WideScratch {
                          // the game's tree state for the length of the launch (the workgroup owns the game): header, last path, tape
                          // counter + the two per-slot tallies, root state -- read and written in LDS, copied from / to HBM once
                          HDR = (FEAT + 2 * FK * 2 + 63) / 64 * 64, PATH = HDR + 64, MAXD = G::MAX_TURNS + 2, CTR = PATH + MAXD * 16,
-                         STATE = CTR + 32, BYTES = (STATE + (int)sizeof(azg_state) + 15) / 16 * 16;
+                         STATE = CTR + 32, MAIL = (STATE + (int)sizeof(azg_state) + 15) / 16 * 16,                 // (WalkMail: azg_kernels.h)
+                         BYTES = (MAIL + (int)sizeof(WalkMail) + 15) / 16 * 16;
 };
 // all of the wide search mode's LDS behind the image: the per-game scratch, an error word, and the value head's P + 1 weight rows
 // + biases (the same for every game and simulation: fetched once per launch instead of once per simulation by every walker)
@@ -607,7 +608,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             slot = __builtin_amdgcn_readfirstlane(slot);
             // (k-split workgroups have wavefronts to spare in the tree phase: the third one takes the shuffle masks off the helper)
             constexpr bool MASK_WAVE = NT / 64 >= 3 * BOARDS;
-            const bool livegame = slot < sa.ev.B && role < (MASK_WAVE ? 3 : 2);
+            // (and the fourth one runs the game rules one level behind the walk: WalkMail, azg_kernels.h)
+            constexpr bool RULES_WAVE = NT / 64 >= 4 * BOARDS && __is_same(G, BR);
+            const bool livegame = slot < sa.ev.B && role < (RULES_WAVE ? 4 : MASK_WAVE ? 3 : 2);
+            [[maybe_unused]] WalkMail *mail = reinterpret_cast<WalkMail *>(ws + WS::MAIL);
             const int tree = slot;                               // (self-play engines only: one tree per slot)
             // The tree functions reach the header, the path, the tape counter, the tallies and the root state through the View's
             // pointers: here those point into the game's LDS scratch (offset so that [tree] / [slot] lands on it), so that every
@@ -621,6 +625,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             evl.slot_exp = reinterpret_cast<int64_t *>(ws + WS::CTR + 16) - slot;
             evl.states = reinterpret_cast<azg_state *>(ws + WS::STATE) - slot;
             if (sim == 0) {                                      // HBM -> LDS, once per launch
+                if (RULES_WAVE && role == 0 && lane < 8) reinterpret_cast<int *>(mail)[lane] = 0;
                 if (livegame && role == 0) {
                     if (lane < 4) reinterpret_cast<uint4 *>(ws + WS::HDR)[lane] = reinterpret_cast<const uint4 *>(sa.ev.hdr + tree)[lane];
                     if (lane < (int)sizeof(azg_state) / 16) reinterpret_cast<uint4 *>(ws + WS::STATE)[lane] = reinterpret_cast<const uint4 *>(sa.ev.states + slot)[lane];
@@ -638,18 +643,18 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             __syncthreads();                                     // both wavefronts of a game hold the header as the last launch / phase left it
             const bool has_policy = livegame && sim > 0 && !hr.leaf_e && hr.leaf_fc >= 0;
             const bool root_noise = has_policy && hr.leaf == LEAF_IS_ROOT && sa.ev.add_noise;
+            auto sink = [&](const typename G::S &ls, int ln) {       // leaf observation -> the image rows of board bd (32 stem channels)
+                if (ln < HW) {
+                    char *row = img + GEO::qrow(bd * HW + ln) * RS;
+                    *reinterpret_cast<half8 *>(row) = G::obs8(ls, ln);
+                    const uint4 z = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4 *>(row + 16) = z; *reinterpret_cast<uint4 *>(row + 32) = z; *reinterpret_cast<uint4 *>(row + 48) = z;
+                }
+            };
+            int *act = reinterpret_cast<int *>(ws + WS::ACT);
             if (livegame && role == 0) {
                 if (sim < sa.sims) AZG_TSTAMP(evl, slot, lane, 8);   // (tree-timing builds: tools/wide_walker_stamps.py)
                 typename G::S st = G::load(&evl.states[slot], lane);
-                auto sink = [&](const typename G::S &ls, int ln) {   // leaf observation -> the image rows of board bd (32 stem channels)
-                    if (ln < HW) {
-                        char *row = img + GEO::qrow(bd * HW + ln) * RS;
-                        *reinterpret_cast<half8 *>(row) = G::obs8(ls, ln);
-                        const uint4 z = make_uint4(0, 0, 0, 0);
-                        *reinterpret_cast<uint4 *>(row + 16) = z; *reinterpret_cast<uint4 *>(row + 32) = z; *reinterpret_cast<uint4 *>(row + 48) = z;
-                    }
-                };
-                int *act = reinterpret_cast<int *>(ws + WS::ACT);
                 if (sim == 0) {
                     select_tree<G>(evl, slot, tree, hr, st, ctr0, lane, act, sink, NoGate{}, NoRanks{});
                 } else {
@@ -688,9 +693,11 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                             AZG_TSTAMP(evl, slot, lane, 15);
                             pos = __popcll(less[ln] & (k == 64 ? ~0ULL : ((1ULL << k) - 1ULL)));
                             return true;
-                        });
+                        }, RULES_WAVE ? mail : nullptr, sim);
                     }
                 }
+            } else if (RULES_WAVE && livegame && role == 3) {        // the rules of the walk: play_action per level, then the leaf
+                if (sim > 0 && sim < sa.sims) follow_tree<G>(evl, slot, G::load(&evl.states[slot], lane), mail, sim, lane, act, sink);
             } else if (MASK_WAVE && livegame && role == 2) {         // the shuffle of the next expansion (every expansion waits for it)
                 if (sim > 0 && sim < sa.sims) {
                     reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);

@@ -196,10 +196,47 @@ AZG_DEV int best_child(const View &ev, const Node *nodes, int fc, int k, const N
 // waits there for the priors the other wave is still writing); it returns true if the slot's tape counter must be re-read.
 // Dependent-load chain: header (the root is in it) -> one child block per level.
 struct NoGate { AZG_DEV bool operator()(int) const { return false; } };
+
+// find_leaf by TWO wavefronts (launches that have one to spare): the walk needs only the node records -- which child to enter is
+// decided by PUCT on the children's statistics -- while the game rules (play_action at every level, then win_state / valid_moves
+// / observation of the leaf) need only the sequence of chosen actions.  The walker publishes every action it takes into a mailbox in
+// LDS and goes on to the next level at once; the rules wavefront follows one level behind, and hands the leaf's valid-move list
+// (left in act_lds), win state and player to move back for add_children.  Words grow monotonically over the simulations of a launch
+// (gen = simulation number), so nothing is ever reset: cnt = gen * 1024 + actions published, fin = gen * 1024 + 512 * expand + depth,
+// res = gen once k / e / player are valid.  Same arithmetic, same results as the one-wave form.
+struct WalkMail { int cnt, fin, res, k, e, player, pad0, pad1; int act[128]; };
+AZG_DEV int mail_load(const int *w) { return __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AZG_DEV void mail_store(int *w, int v, int lane) { if (lane == 0) __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class G, class Sink>
+AZG_DEV void follow_tree(const View &ev, int slot, typename G::S st, WalkMail *mb, int gen, int lane, int *act_lds, Sink &&sink) {
+    constexpr int NCH = (G::MAXK + 63) / 64;
+    const int base = gen * 1024;
+    int d = 0, fin = -1;
+    for (int spin = 0; spin < (1 << 23); spin++) {
+        const int f = mail_load(&mb->fin);                                   // (fin before cnt: a final depth implies its actions are published)
+        const int c = mail_load(&mb->cnt);
+        const int avail = c >= base ? c - base : 0;
+        while (d < avail) { G::play(st, mb->act[d]); d++; }                  // MCTS.pyx:216
+        if (f >= base) { fin = f - base; if (d == (fin & 511)) break; }
+        if (d == avail) __builtin_amdgcn_s_sleep(1);
+    }
+    if (fin < 0) { if (lane == 0) raise_error(ev, AZG_E_INTERNAL); return; }
+    if (fin & 512) {                                                         // :223-226 the leaf is new: its win state and moves
+        const int e = G::win_bits(st);
+        int my_a[NCH];
+        const int k = G::valid_list(st, lane, act_lds, my_a);
+        wave_sync();
+        if (lane == 0) { mb->k = k; mb->e = e; mb->player = st.player; }
+        mail_store(&mb->res, gen, lane);
+    }
+    G::store(st, &ev.leaf_states[slot], lane);
+    sink(st, lane);
+}
 template <class G, class Sink, class Gate, class Ranks>
 AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typename G::S st, uint64_t ctr, int lane, int *act_lds,
-                         Sink &&sink, Gate &&gate, Ranks &&ranks) {
+                         Sink &&sink, Gate &&gate, Ranks &&ranks, WalkMail *mb = nullptr, int gen = 0) {
     constexpr int NCH = (G::MAXK + 63) / 64;
+    const bool split = mb != nullptr;                                        // (follow_tree runs the rules: see WalkMail)
     TreeHdr *h = ev.hdr + tree;
     Node *nodes = tree_nodes(ev, tree, hr.base);
     PathEnt *path = ev.path + (size_t)tree * ev.maxd;
@@ -221,10 +258,14 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
         }
         cn = sel;
         AZG_TSTAMP(ev, slot, lane, 11);
-        G::play(st, cn.a);                                                   // :216
+        if (split) {
+            if (lane == 0) mb->act[depth] = cn.a;
+            mail_store(&mb->cnt, gen * 1024 + depth + 1, lane);
+        } else G::play(st, cn.a);                                            // :216
         AZG_TSTAMP(ev, slot, lane, 12);
         depth++;
     }
+    if (split) mail_store(&mb->fin, gen * 1024 + (cn.n == 0 ? 512 : 0) + depth, lane);
     int expanded = 0;
     int alloc = hr.alloc;
     AZG_TSTAMP(ev, slot, lane, 5);
@@ -232,13 +273,24 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
     if (ev.dbg && lane == 0) ev.dbg[(size_t)slot * 16 + 15] = (unsigned long long)depth;
 #endif
     if (cn.n == 0) {                                                         // :223-226 expand
-        const int e = G::win_bits(st);
+        int e, k, player = st.player;
         int my_a[NCH];
-        const int k = G::valid_list(st, lane, act_lds, my_a);
+        if (split) {                                                         // (the rules wavefront left the list in act_lds)
+            for (int spin = 0; mail_load(&mb->res) < gen; spin++) {
+                if (spin > (1 << 23)) { if (lane == 0) raise_error(ev, AZG_E_INTERNAL); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            k = mb->k; e = mb->e; player = mb->player;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) my_a[c] = c * 64 + lane < k ? act_lds[c * 64 + lane] : -1;
+        } else {
+            e = G::win_bits(st);
+            k = G::valid_list(st, lane, act_lds, my_a);
+        }
         AZG_TSTAMP(ev, slot, lane, 13);
         const int fc = add_children_any<G>(ev, slot, nodes, alloc, k, my_a, ctr, lane, ranks);
         AZG_TSTAMP(ev, slot, lane, 14);
-        cn.fc = fc; cn.nchild = fc < 0 ? 0 : k; cn.player = st.player; cn.e = e;
+        cn.fc = fc; cn.nchild = fc < 0 ? 0 : k; cn.player = player; cn.e = e;
         if (lane == 0) {
             ev.tape_ctr[slot] = ctr;
             const uint4 hi = pack_hi(cn.fc, cn.a, cn.nchild, cn.player, cn.e);
@@ -255,8 +307,10 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
         ev.slot_exp[slot] += expanded;
     }
     AZG_TSTAMP(ev, slot, lane, 6);
-    G::store(st, &ev.leaf_states[slot], lane);
-    sink(st, lane);
+    if (!split) {
+        G::store(st, &ev.leaf_states[slot], lane);
+        sink(st, lane);
+    }
     AZG_TSTAMP(ev, slot, lane, 7);
 }
 
