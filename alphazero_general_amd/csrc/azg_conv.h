@@ -609,7 +609,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             // (k-split workgroups have wavefronts to spare in the tree phase: the third one takes the shuffle masks off the helper)
             constexpr bool MASK_WAVE = NT / 64 >= 3 * BOARDS;
             // (and the fourth one runs the game rules one level behind the walk: WalkMail, azg_kernels.h)
-            constexpr bool RULES_WAVE = NT / 64 >= 4 * BOARDS && __is_same(G, BR);
+            constexpr bool RULES_WAVE = NT / 64 >= 4 * BOARDS;
             const bool livegame = slot < sa.ev.B && role < (RULES_WAVE ? 4 : MASK_WAVE ? 3 : 2);
             [[maybe_unused]] WalkMail *mail = reinterpret_cast<WalkMail *>(ws + WS::MAIL);
             const int tree = slot;                               // (self-play engines only: one tree per slot)

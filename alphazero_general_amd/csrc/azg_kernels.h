@@ -225,6 +225,8 @@ AZG_DEV void follow_tree(const View &ev, int slot, typename G::S st, WalkMail *m
         const int e = G::win_bits(st);
         int my_a[NCH];
         const int k = G::valid_list(st, lane, act_lds, my_a);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) if (c * 64 + lane < k) act_lds[c * 64 + lane] = my_a[c];   // (the hand-over: child i's action at act_lds[i])
         wave_sync();
         if (lane == 0) { mb->k = k; mb->e = e; mb->player = st.player; }
         mail_store(&mb->res, gen, lane);
