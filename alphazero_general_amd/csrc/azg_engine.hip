@@ -647,6 +647,14 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
             if (hn > 0) fprintf(stderr, "  helper wavefront (cycles per simulation with a policy backup): header %.0f masks %.0f logits %.0f softmax %.0f priors %.0f\n",
                                 hp[0] / hn, hp[1] / hn, hp[2] / hn, hp[3] / hn, hp[4] / hn);
             HIPCHK(hipMemset(dbg + 2048 + 4096 * 5, 0, sizeof(unsigned long long) * 8 * 512));
+            {                                                       // the layers of workgroup 0's last simulation (all wavefronts of the workgroup)
+                unsigned long long h[64 * 4 * 5];
+                HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                for (int l = 0; l <= 2 * P.nblocks; l++) for (int w = 0; w < C / 32 * PSPLIT * KSPLIT && w < 4; w++) {
+                    unsigned long long *t = h + (l * 4 + w) * 5;
+                    fprintf(stderr, "  layer %2d wave %d: main %6llu wait %6llu epi %6llu bar %6llu | start %llu\n", l, w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[0] - h[0]);
+                }
+            }
             calls = 100;
         }
         if (++calls == 8) {
