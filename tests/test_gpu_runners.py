@@ -208,6 +208,37 @@ def test_wide_head_runner_graph_equals_eager_launches(game):
         assert x.shape == y.shape and (x == y).all()
 
 
+@pytest.mark.parametrize('game', ['brandubh', 'trimok'])
+def test_wide_head_runner_persistent_launch_with_fast_rounds_and_resets(game):
+    """The persistent wide-head launch inside the native runner (azg_search_wide_f16: brandubh with four wavefronts per game -- k-split
+    tower, shuffle masks and the rules of the walk on wavefronts of their own) against the launch-per-phase runner, with what changes
+    the shape of a round riding along: fast rounds (a second simulation count, no history: SelfPlayAgent.pyx:83-92) and periodic tree
+    resets (mctsResetThreshold, :172-174).  Samples, results, actions, counters identical."""
+    import importlib
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    import torch
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    torch.manual_seed(23)
+    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    B, rounds = 37, 40
+    outs = []
+    for fused in (True, False):
+        r = SelfPlayRunner(Game, net, _args(numMCTSSims=12, numFastSims=5, probFastSim=0.4, mctsResetThreshold=3, cpuct=1.25, fpu_reduction=0.2),
+                           num_slots=B, seed=4, use_graph=True, fused_search=fused, example_capacity=B * 101 * 8 * 3)
+        assert r.fused_search == fused
+        for _ in range(rounds):
+            r.play_round()
+        o, p, z = r.samples()
+        ws, turns, slot = r.results()
+        outs.append((o.cpu().numpy(), p.cpu().numpy(), z.cpu().numpy(), r.engine.last_actions().cpu().numpy(), np.asarray(ws), np.asarray(turns),
+                     np.asarray(slot), r.counters(), list(r.sims_per_round)))
+    a, b = outs
+    assert a[7] == b[7] and a[8] == b[8] and len(set(a[8])) == 2 and a[7]['games_played'] > 0
+    for x, y in zip(a[:7], b[:7]):
+        assert x.shape == y.shape and (x == y).all()
+
+
 def test_runner_writes_coach_iteration_files(tmp_path):
     """SelfPlayRunner.save_iteration_samples writes what Coach.saveIterationSamples writes (Coach.py:363-386): three float32 CPU
     tensors that load with torch.load and line up row by row; game_results is get_game_results (utils.py:34-54)."""
