@@ -181,6 +181,16 @@ def test_tower_tile_shapes_agree(game):
             assert torch.equal(p, outs[0][0]) and torch.equal(v, outs[0][1])
         else:                                      # heads GEMM is a library call whose k-split depends on the batch size
             assert float((p - outs[0][0]).abs().max()) < 1e-4 and float((v - outs[0][1]).abs().max()) < 1e-4
+    if game == 'brandubh':
+        # the tower itself (head features): the k-split 1-board tile (<= 512 boards: wave = cout group x k group, partial sums through
+        # LDS), the 2-board tile in two pixel groups (<= 1024) and the unsplit 2-board tile all sum in k-half order -- bit-identical
+        hip = net._hip
+        feats = []
+        for n in (200, 500, 900, 2100):
+            x = hip.to_nhwc8(base.repeat((n + 199) // 200, 1, 1, 1)[:n].to('cuda:0'))
+            feats.append(hip.forward_features_nhwc8(x, key=n)[:200].clone())
+        for f in feats[1:]:
+            assert torch.equal(f, feats[0])
 
 
 def test_mfma_tower_trimok_32ch_vs_fp32_reference():
