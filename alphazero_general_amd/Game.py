@@ -10,7 +10,9 @@ Coach, Arena, GenericPlayers, the env modules) rely on exactly these members, so
 What this build adds is the device side: a game the MI355X engine can search also carries
   AZG_GAME_ID                          index of its rule kernels in csrc/azg_games.h
   to_azg_state() / from_azg_state()    conversion to / from include/azg.h azg_state
-A GameState without them is rejected by `azg_game_id` with NotImplementedError -- the engine has no CPU search path.
+A GameState without them is rejected by `azg_game_id` with NotImplementedError -- the engine has no CPU search path; behind
+`install()` the MCTS / SelfPlayAgent classes hand such a game to the reference's own classes instead (reference side,
+alphazero_general_amd.reference_class).
 """
 import numpy as np
 
@@ -126,3 +128,11 @@ def azg_game_id(game_cls_or_state):
             return g
     raise NotImplementedError('%s.%s has no device rule kernels registered (csrc/azg_games.h); the MI355X engine has '
                               'no CPU search fallback' % (mod, cls.__name__))
+
+
+def has_device_rules(game_cls_or_state):
+    try:
+        azg_game_id(game_cls_or_state)
+        return True
+    except NotImplementedError:
+        return False

@@ -3,8 +3,10 @@ argument (the args dotdict), same method names / argument meaning / errors, back
 (include/azg.h).  Used by GenericPlayers.MCTSPlayer / RawMCTSPlayer (GenericPlayers.py:100-200) and anything else
 that drives one tree at a time; the batched path (SelfPlayAgent) talks to a B-slot engine directly.
 
-Every call is a kernel launch on a single wavefront plus a host sync, so this class is functional, not fast: the
-throughput path is `alphazero_general_amd.selfplay.SelfPlayRunner` / `SelfPlayAgent`.
+find_leaf / process_results are one kernel launch on a single wavefront plus a host sync each; `search(gs, nn, ...)` with this
+package's NNetWrapper runs all its simulations in ONE persistent launch (azg_search_f16 / azg_search_wide_f16) where the network has
+one.  The throughput path is `alphazero_general_amd.selfplay.SelfPlayRunner` / `SelfPlayAgent`.  Objects pickle (MCTS.pyx:8):
+parameters, tape seed and a snapshot of the tree (azg_slot_export), so an MCTSPlayer can cross a process boundary.
 """
 import os
 
@@ -13,7 +15,7 @@ import torch
 
 from . import _abi
 from .engine import DeviceEngine
-from .Game import azg_game_id
+from .Game import azg_game_id, has_device_rules
 
 NOISE_ALPHA_RATIO = 10.83          # MCTS.pyx:20
 _DRAW_VALUE = 0.5                  # MCTS.pyx:21
@@ -62,6 +64,32 @@ class Node:
         return 'Node(a={}, q={}, v={}, n={}, p={})'.format(self.a, self.q, self.v, self.n, self.p)
 
 
+NODE_STORE_BUDGET = 256 << 20      # default ceiling of ONE MCTS object's node store (two semi-spaces of 32-byte nodes), bytes
+
+
+def _rebuild_mcts(params, game, blob, depth, max_depth, nodes_used):
+    """unpickle (MCTS.__reduce__): same parameters and tape seed; the tree, if there was one, is restored into a fresh engine"""
+    from .utils import dotdict
+    m = MCTS(dotdict(params))
+    m.depth, m.max_depth = depth, max_depth
+    if blob is not None:
+        m._ensure_game(game)
+        m._engine.import_slot(blob)
+        m._nodes_used = nodes_used
+    return m
+
+
+def _rebuild_ref_mcts(args, blob):
+    import pickle
+    from . import reference_module
+    from .utils import dotdict
+    with reference_module('MCTS'):
+        ref = pickle.loads(blob)
+    m = MCTS(dotdict(args))
+    m._ref, m.depth, m.max_depth = ref, ref.depth, ref.max_depth
+    return m
+
+
 class MCTS:
     def __init__(self, args):
         self.root_noise_frac = args.root_noise_frac            # MCTS.pyx:134-139
@@ -70,28 +98,66 @@ class MCTS:
         self.fpu_reduction = args.fpu_reduction
         self.cpuct = args.cpuct
         self._num_players = args._num_players
-        self._seed = int(args.get('_azg_seed', int.from_bytes(os.urandom(7), 'little'))) if hasattr(args, 'get') else 0
-        self._sims_hint = int(args.get('numMCTSSims', 100) or 100) if hasattr(args, 'get') else 100
+        get = args.get if hasattr(args, 'get') else (lambda k, d=None: getattr(args, k, d))
+        self._seed = int(get('_azg_seed', None) if get('_azg_seed', None) is not None else int.from_bytes(os.urandom(7), 'little'))
+        self._sims_hint = int(get('numMCTSSims', 100) or 100)
+        self._nodes_per_tree = int(get('_azg_nodes_per_tree', 0) or 0)       # 0: a whole game's worth, at most NODE_STORE_BUDGET
+        self._args = args
+        self._ref = None                                       # the reference's own MCTS, for a game without device rules (_fallback)
         self._engine = None
         self._game = None
         self._leaf_template = None
+        self._nodes_used = 0
+        self._compact_futile = False
         self.depth = 0
         self.max_depth = 0
 
+    # ---- pickling (MCTS.pyx:8 auto_pickle=True: the reference pickles _root with its whole Node tree, _curnode, _path, depth, max_depth)
+    def __reduce__(self):
+        if self._ref is not None:                              # (the reference's object travels as its own pickle, made where its
+            import pickle                                      #  module is the one the names resolve to: reference_module)
+            from . import reference_module
+            with reference_module('MCTS'):
+                blob = pickle.dumps(self._ref, pickle.HIGHEST_PROTOCOL)
+            return _rebuild_ref_mcts, (dict(self._args), blob)
+        params = dict(root_noise_frac=self.root_noise_frac, root_policy_temp=self.root_temp, min_discount=self.min_discount,
+                      fpu_reduction=self.fpu_reduction, cpuct=self.cpuct, _num_players=self._num_players, _azg_seed=self._seed,
+                      numMCTSSims=self._sims_hint, _azg_nodes_per_tree=self._nodes_per_tree)
+        blob = self._engine.export_slot(0) if self._engine is not None else None
+        return _rebuild_mcts, (params, self._game, blob, self.depth, self.max_depth, self._nodes_used)
+
+    # ---- games without device rule kernels: the reference's own class does the search (reference side) ----
+    def _fallback(self, gs=None):
+        if self._ref is not None or gs is None or self._engine is not None or has_device_rules(gs):
+            return self._ref
+        from . import reference_class
+        cls = reference_class('MCTS')
+        if cls is not None:                                    # (else: azg_game_id raises the NotImplementedError below)
+            self._ref = cls(self._args)
+        return self._ref
+
+    def _via_ref(self, ref, name, *a):
+        out = getattr(ref, name)(*a)
+        self.depth, self.max_depth = ref.depth, ref.max_depth
+        return out
+
     # ---- engine plumbing ----
     def _ensure(self, gs):
-        gid = azg_game_id(gs)
+        return self._ensure_game(azg_game_id(gs))
+
+    def _ensure_game(self, gid):
         if self._engine is None:
             self._game = gid
-            # ONE tree: memory is no concern, so its node store holds a whole game's worth of expansions (max_turns moves x the
-            # simulations per move x max_children: connect4 2.4 MB, brandubh 123 MB at 200 simulations) -- more than a search
-            # that drops nothing could fill; a caller that keeps searching at ONE root (pondering, sims far above
-            # args.numMCTSSims) is served by the forced compaction in find_leaf until the LIVE subtree itself exceeds the store
-            # (AZG_E_TREE_FULL; the reference's limit there is host memory)
-            from . import _abi
+            # ONE tree: its node store holds a whole game's worth of expansions (max_turns moves x the simulations per move x
+            # max_children) -- more than a search that drops nothing could fill -- but at most NODE_STORE_BUDGET bytes (several MCTS
+            # objects live side by side: one per arena player, one per agent): connect4 2.4 MB; brandubh at 200 simulations would be
+            # 123 MB, at 1600 simulations it is clamped to 256 MB (13 moves' worth).  args._azg_nodes_per_tree overrides.  A caller
+            # that keeps searching at ONE root is served by the forced compaction in find_leaf / search until the LIVE subtree
+            # itself exceeds the store (AZG_E_TREE_FULL; the reference's limit there is host memory)
             gi = _abi.game_info(gid)
             sims = max(self._sims_hint, 200)
-            cap = min(max(gi.max_turns, 16) * sims * gi.max_children + 64, (1 << 28) - 1)
+            cap = self._nodes_per_tree or min(max(gi.max_turns, 16) * sims * gi.max_children + 64, NODE_STORE_BUDGET // 64)
+            cap = min(cap, (1 << 28) - 1)
             self._engine = DeviceEngine(gid, 1, cpuct=self.cpuct, fpu_reduction=self.fpu_reduction,
                                         root_noise_frac=self.root_noise_frac, root_policy_temp=self.root_temp,
                                         min_discount=self.min_discount, seed=self._seed, sims_hint=sims, nodes_per_tree=cap)
@@ -100,13 +166,27 @@ class MCTS:
             raise ValueError('this MCTS object was created for another game')
         return self._engine
 
+    def _make_room(self, need):
+        """forced compaction before a find_leaf / search that may not fit: drop what the root no longer reaches.  When the last
+        forced compaction reclaimed next to nothing the LIVE subtree fills the store: do not thrash, let AZG_E_TREE_FULL surface."""
+        e = self._engine
+        if self._nodes_used + need <= e.nodes_per_tree or self._compact_futile:
+            return
+        before = self._nodes_used
+        e.compact(0, force=True)
+        self._nodes_used = e.tree_info(0)['nodes_used']
+        self._compact_futile = before - self._nodes_used < 2 * self._max_children
+
     def _sync_root_state(self, gs):
         self._engine.set_states([encode_state(gs)], reset_trees=False)
 
     def reset(self):                                           # MCTS.pyx:154-160
+        if self._ref is not None:
+            return self._via_ref(self._ref, 'reset')
         if self._engine is not None:
             self._engine.reset()
         self.depth = self.max_depth = 0
+        self._nodes_used, self._compact_futile = 0, False
 
     def __repr__(self):
         return 'MCTS(root_noise_frac={}, root_temp={}, min_discount={}, fpu_reduction={}, cpuct={}, _num_players={}, depth={}, max_depth={})' \
@@ -115,14 +195,47 @@ class MCTS:
 
     # ---- public API ----
     def search(self, gs, nn, sims, add_root_noise, add_root_temp):     # MCTS.pyx:165-173
+        ref = self._fallback(gs)
+        if ref is not None:
+            return self._via_ref(ref, 'search', gs, nn, sims, add_root_noise, add_root_temp)
         e = self._ensure(gs)
         e.reset_max_depth()
+        hip = self._persistent_net(nn, e)
+        if hip is not None and sims > 0:
+            # `nn` is this package's NNetWrapper and a persistent search launch exists for (game, network): all `sims` simulations
+            # -- find_leaf, the network on MFMA, process_results -- in ONE launch instead of 3 launches + a host sync each
+            # (GenericPlayers.py:133-134 calls this once per move).  Same trees as the loop below: connect4 bit for bit (a board's
+            # probabilities do not depend on the launch form), the sparse-heads networks to rounding (include/azg.h)
+            self._sync_root_state(gs)
+            self._make_room(sims * self._max_children)
+            e.set_search_flags(add_root_noise, add_root_temp)
+            hip.search(e, int(sims))
+            info = e.tree_info(0)
+            self._nodes_used = info['nodes_used']
+            self.depth, self.max_depth = info['depth'], info['max_depth']
+            return
         for _ in range(sims):
             leaf = self.find_leaf(gs)
             p, v = nn(leaf.observation())
             self.process_results(leaf, v, p, add_root_noise, add_root_temp)
 
+    @staticmethod
+    def _persistent_net(nn, e):
+        """the HipResNet behind `nn` if nn is an NNetWrapper (or its bound predict / __call__) whose network has a persistent search
+        launch for this engine's game on this engine's device, else None"""
+        from .nnet import NNetWrapper
+        w = nn if isinstance(nn, NNetWrapper) else getattr(nn, '__self__', None)
+        if not isinstance(w, NNetWrapper) or not w.fast or w.device != e.device:
+            return None
+        if w._infer is None:
+            w.refresh()
+        hip = w._hip
+        return hip if (hip is not None and hip.can_search and hip.game == e.game) else None
+
     def raw_search(self, gs, sims, add_root_noise, add_root_temp):     # MCTS.pyx:175-183
+        ref = self._fallback(gs)
+        if ref is not None:
+            return self._via_ref(ref, 'raw_search', gs, sims, add_root_noise, add_root_temp)
         e = self._ensure(gs)
         e.reset_max_depth()
         v = np.zeros(gs.num_players() + 1, dtype=np.float32)
@@ -132,15 +245,21 @@ class MCTS:
             self.process_results(leaf, v, p, add_root_noise, add_root_temp)
 
     def update_root(self, gs, a):                                      # MCTS.pyx:185-195 (raises ValueError)
+        ref = self._fallback(gs)
+        if ref is not None:
+            return self._via_ref(ref, 'update_root', gs, a)
         e = self._ensure(gs)
         self._sync_root_state(gs)
         e.update_root(0, int(a))
+        self._compact_futile = False                                   # (the played move's siblings are garbage now)
 
     def find_leaf(self, gs):                                           # MCTS.pyx:208-228
+        ref = self._fallback(gs)
+        if ref is not None:
+            return self._via_ref(ref, 'find_leaf', gs)
         e = self._ensure(gs)
         self._sync_root_state(gs)
-        if getattr(self, '_nodes_used', 0) + 2 * self._max_children > e.nodes_per_tree:
-            e.compact(0, force=True)                                   # the store is nearly full: drop what the root no longer reaches
+        self._make_room(2 * self._max_children)                       # the store is nearly full: drop what the root no longer reaches
         e.select(None)
         st = e.get_leaf_states(0, 1, full=True)[0]
         info = e.tree_info(0)
@@ -149,6 +268,8 @@ class MCTS:
         return decode_state(gs, *st)
 
     def process_results(self, gs, value, pi, add_root_noise, add_root_temp):   # MCTS.pyx:230-289
+        if self._ref is not None:
+            return self._via_ref(self._ref, 'process_results', gs, value, pi, add_root_noise, add_root_temp)
         e = self._engine
         nv = e.NV
         v = np.zeros(nv, np.float32)
@@ -159,24 +280,36 @@ class MCTS:
         e.backup(pol, val, add_root_noise=bool(add_root_noise), add_root_temp=bool(add_root_temp))
 
     def counts(self, gs):                                              # MCTS.pyx:297-303
+        ref = self._fallback(gs)
+        if ref is not None:
+            return ref.counts(gs)
         return self._ensure(gs).root_counts()[0].cpu().numpy()
 
     def best_action(self, gs):                                         # MCTS.pyx:305-306
+        if self._ref is not None:
+            return self._ref.best_action(gs)
         return int(np.argmax(self.counts(gs)))
 
     def probs(self, gs, temp=1.0):                                     # MCTS.pyx:308-329
+        ref = self._fallback(gs)
+        if ref is not None:
+            return ref.probs(gs, temp)
         p = self._ensure(gs).root_probs(float(np.float32(temp)))[0].cpu().numpy()
         if np.isnan(p).any():                                          # no visited child: counts / 0 under np.seterr(all='raise') (:23)
             raise FloatingPointError('invalid value encountered in divide')
         return p
 
     def value(self, average=False):                                    # MCTS.pyx:331-344
+        if self._ref is not None:
+            return self._ref.value(average)
         if self._engine is None:
             return 0.0
         return float(self._engine.root_value(bool(average))[0].item())
 
     @property
     def _root(self):
+        if self._ref is not None:
+            return self._ref._root
         if self._engine is None:
             return Node(self, -1)
         i = self._engine.tree_info(0)

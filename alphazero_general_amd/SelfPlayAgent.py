@@ -28,7 +28,7 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from .Game import azg_game_id
+from .Game import azg_game_id, has_device_rules
 from .utils import default_temp_scaling, temp_table
 
 
@@ -36,6 +36,17 @@ from ._engine_worker import engine_worker  # noqa: F401  (the device-side half; 
 
 
 class SelfPlayAgent(mp.Process):
+    def __new__(cls, id=None, game_cls=None, *a, **k):
+        """Dispatch per game (SURVEY.md 8b "Game plugin"): an env without device rule kernels is handed to the REFERENCE'S OWN
+        SelfPlayAgent (alphazero_general_amd.reference_class; reference side, not a CPU engine of this package) -- the object
+        returned is then not an instance of this class, so __init__ below does not run on it."""
+        if cls is SelfPlayAgent and game_cls is not None and not has_device_rules(game_cls):
+            from . import reference_class
+            ref = reference_class('SelfPlayAgent')
+            if ref is not None and ref is not SelfPlayAgent:
+                return ref(id, game_cls, *a, **k)
+        return super().__new__(cls)
+
     def __init__(self, id, game_cls, ready_queue, batch_ready, batch_tensor, policy_tensor, value_tensor, output_queue,
                  result_queue, complete_count, games_played, stop_event, pause_event, args, _is_arena=False, _is_warmup=False):
         super().__init__()
@@ -102,34 +113,43 @@ class SelfPlayAgent(mp.Process):
         # mp child: Coach makes the agents daemonic and daemonic processes may not have mp children)
         import subprocess
         import sys
-        from multiprocessing.connection import Listener
+        # the rendezvous is an AF_UNIX socket of our own with an accept timeout (a worker that dies before connecting -- bad
+        # PYTHONPATH, exec failure -- must not leave the agent, and the Coach polling complete_count, waiting forever), wrapped
+        # into a multiprocessing Connection with the same authkey handshake multiprocessing.connection.Listener.accept performs
+        import socket
+        import tempfile
+        from multiprocessing.connection import Connection, answer_challenge, deliver_challenge
         key = os.urandom(16)
-        listener = Listener(family='AF_UNIX', authkey=key)
+        sockdir = tempfile.mkdtemp(prefix='azg-agent-')
+        address = os.path.join(sockdir, 'worker.sock')
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(address); srv.listen(1); srv.settimeout(1.0)
         env = dict(os.environ, AZG_WORKER_KEY=key.hex(),
                    PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
-        self._worker = subprocess.Popen([sys.executable, '-m', 'alphazero_general_amd._engine_worker', listener.address], env=env)
-        # accept with a liveness check: a worker that dies before connecting (bad PYTHONPATH, exec failure) must not leave the
-        # agent -- and the Coach polling complete_count -- waiting forever
-        try:
-            listener._listener._socket.settimeout(1.0)             # (CPython's Listener keeps its socket here; without it the accept
-        except AttributeError:                                     #  below simply blocks until the worker connects)
-            pass
+        self._worker = subprocess.Popen([sys.executable, '-m', 'alphazero_general_amd._engine_worker', address], env=env)
         deadline = time.time() + float(os.environ.get('AZG_WORKER_START_TIMEOUT', '300'))
-        while True:
+        try:
+            while True:
+                try:
+                    peer, _ = srv.accept()
+                    break
+                except socket.timeout:
+                    rc = self._worker.poll()
+                    if rc is not None:
+                        raise RuntimeError('device engine worker exited with code %s before connecting' % rc)
+                    if time.time() > deadline:
+                        self._worker.kill()
+                        raise RuntimeError('device engine worker did not connect in time')
+        finally:
+            srv.close()
             try:
-                self._conn = listener.accept()
-                break
-            except (TimeoutError, OSError) as ex:
-                if not isinstance(ex, TimeoutError) and 'timed out' not in str(ex):
-                    raise
-                rc = self._worker.poll()
-                if rc is not None:
-                    listener.close()
-                    raise RuntimeError('device engine worker exited with code %s before connecting' % rc)
-                if time.time() > deadline:
-                    self._worker.kill(); listener.close()
-                    raise RuntimeError('device engine worker did not connect in time')
-        listener.close()
+                os.unlink(address); os.rmdir(sockdir)
+            except OSError:
+                pass
+        peer.setblocking(True)
+        self._conn = Connection(peer.detach())
+        deliver_challenge(self._conn, key)
+        answer_challenge(self._conn, key)
         self._conn.send(cfg)
         status, out = self._conn.recv()
         if status == 'error':

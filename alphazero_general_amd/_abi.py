@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AZG_LIB_PATH') or os.path.join(HERE, 'lib', 'libazg_hip.so')   # (override: measurement builds)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 GAME_CONNECT4, GAME_BRANDUBH, GAME_TRIMOK = 0, 1, 2
 E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_TREE_FULL, E_EXAMPLES_FULL, E_UNSUPPORTED, E_INTERNAL, E_FLOATING_POINT = -1, -2, -3, -4, -5, -6, -7, -8
@@ -52,6 +52,8 @@ SYMBOLS = {
     'azg_engine_create': (_i, [C.POINTER(Config), C.POINTER(_vp)]),
     'azg_engine_destroy': (_i, [_vp]),
     'azg_engine_reset': (_i, [_vp, _vp]),
+    'azg_engine_info': (_i, [_vp, _i32p]),
+    'azg_set_root_flags': (_i, [_vp, _i]),
     'azg_set_states': (_i, [_vp, _vp, _i, _i, C.POINTER(State), _i]),
     'azg_get_states': (_i, [_vp, _vp, _i, _i, C.POINTER(State)]),
     'azg_get_leaf_states': (_i, [_vp, _vp, _i, _i, C.POINTER(State)]),
@@ -74,6 +76,8 @@ SYMBOLS = {
     'azg_root_value': (_i, [_vp, _vp, _i, _vp]),
     'azg_update_root': (_i, [_vp, _vp, _i, _i]),
     'azg_compact': (_i, [_vp, _vp, _i, _i]),
+    'azg_slot_export': (C.c_int64, [_vp, _vp, _i, _vp, C.c_int64]),
+    'azg_slot_import': (_i, [_vp, _vp, _i, _vp, C.c_int64]),
     'azg_root_children': (_i, [_vp, _vp, _i, _i, _i, _i32p, _i32p, _f32p, _f32p, _f32p]),
     'azg_node_children': (_i, [_vp, _vp, _i, _i, _i, _i, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p]),
     'azg_reset_max_depth': (_i, [_vp, _vp]),
@@ -85,6 +89,7 @@ SYMBOLS = {
     'azg_read_results': (_i, [_vp, _vp, _i, _i, C.POINTER(C.c_uint8), _i32p, _i32p]),
     'azg_clear_outputs': (_i, [_vp, _vp]),
     'azg_last_actions_dev': (_i, [_vp, C.POINTER(_vp)]),
+    'azg_tower_weights_size': (C.c_int64, [_i, _i]),
     'azg_resnet_tower_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'azg_resnet_policy_value_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'azg_resnet_policy_value_multi_f16': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -449,7 +449,8 @@ template <class G, int HW> struct WideScratch {
 };
 // all of the wide search mode's LDS behind the image: the per-game scratch, an error word, and the value head's P + 1 weight rows
 // + biases (the same for every game and simulation: fetched once per launch instead of once per simulation by every walker)
-template <class G, int HW, int BOARDS> struct WideLds {
+template <class G> struct WideMailFits { static_assert(G::MAX_TURNS + 2 <= 128, "WalkMail::act holds one action per level of a find_leaf path"); };
+template <class G, int HW, int BOARDS> struct WideLds : WideMailFits<G> {
     static constexpr int NV = G::P + 1, FK = WideScratch<G, HW>::FK;
     static constexpr int ERR = BOARDS * WideScratch<G, HW>::BYTES, VROWS = (ERR + 16 + 15) / 16 * 16, VBIAS = VROWS + NV * FK * 2,
                          BYTES = (VBIAS + NV * 4 + 15) / 16 * 16;
@@ -1100,7 +1101,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             if (lds_live && role == 0 && slot < sa.ev.B) {
                 const char *ws = smem + TILE + bd * WS::BYTES;
                 if (lane < 4) reinterpret_cast<uint4 *>(sa.ev.hdr + slot)[lane] = reinterpret_cast<const uint4 *>(ws + WS::HDR)[lane];
-                const int depth = reinterpret_cast<const int *>(ws + WS::HDR)[10];
+                static_assert(sizeof(TreeHdr) == 4 * sizeof(uint4) && sizeof(azg_state) % 16 == 0 && sizeof(PathEnt) == sizeof(uint4),
+                              "the LDS mirror moves the header, the root state and the path as whole 16-byte chunks");
+                const int depth = *reinterpret_cast<const int *>(ws + WS::HDR + offsetof(TreeHdr, depth));
                 for (int j = lane; j < depth && j < sa.ev.maxd; j += 64)
                     reinterpret_cast<uint4 *>(sa.ev.path + (size_t)slot * sa.ev.maxd)[j] = reinterpret_cast<const uint4 *>(ws + WS::PATH)[j];
                 if (lane == 0) {

@@ -451,6 +451,79 @@ extern "C" int azg_compact(azg_engine *e, void *stream, int slot, int force) {
     return AZG_OK;
 }
 
+extern "C" int azg_engine_info(azg_engine *e, int32_t *out8) {
+    if (!e || !out8) return fail(AZG_E_INVALID_ARG, "null argument");
+    out8[0] = e->v.cap; out8[1] = e->v.compact_reserve; out8[2] = e->v.T; out8[3] = e->v.maxd; out8[4] = e->v.B;
+    out8[5] = e->v.ex_cap; out8[6] = e->v.res_cap; out8[7] = e->cfg.sims_per_move > 0 ? e->cfg.sims_per_move : 100;
+    return AZG_OK;
+}
+
+extern "C" int azg_set_root_flags(azg_engine *e, int flags) {
+    if (!e || flags < 0) return fail(AZG_E_INVALID_ARG, "null engine or negative flags");
+    e->v.add_noise = ((flags & AZG_FLAG_NOISE) && !e->v.arena) ? 1 : 0; e->v.add_temp = ((flags & AZG_FLAG_TEMP) && !e->v.arena) ? 1 : 0;
+    return AZG_OK;
+}
+
+// ---- snapshot of one slot's search state (pickling of the single-tree MCTS class: MCTS.pyx:8 auto_pickle) ----
+// layout: int64 magic, int32 game, T, maxd, pad | azg_state root, leaf | uint64 tape_ctr | per tree: TreeHdr, PathEnt[maxd], Node[alloc]
+static const int64_t k_snap_magic = 0x315A4E53475A41LL;     // "AZGSNZ1"
+struct SnapHead { int64_t magic; int32_t game, T, maxd, pad; azg_state root, leaf; uint64_t ctr; };
+
+extern "C" int64_t azg_slot_export(azg_engine *e, void *stream, int slot, void *host_buf, int64_t nbytes) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));
+    const int T = e->v.T, maxd = e->v.maxd;
+    std::vector<TreeHdr> hdr((size_t)T);
+    HIPCHK(hipMemcpy(hdr.data(), e->v.hdr + (size_t)slot * T, sizeof(TreeHdr) * T, hipMemcpyDeviceToHost));
+    int64_t need = (int64_t)sizeof(SnapHead);
+    for (int t = 0; t < T; t++) need += (int64_t)sizeof(TreeHdr) + (int64_t)sizeof(PathEnt) * maxd + (int64_t)sizeof(Node) * hdr[t].alloc;
+    if (!host_buf) return need;                              // size query
+    if (nbytes < need) return fail(AZG_E_INVALID_ARG, "snapshot buffer too small");
+    char *o = (char *)host_buf;
+    SnapHead sh; memset(&sh, 0, sizeof(sh));
+    sh.magic = k_snap_magic; sh.game = e->cfg.game; sh.T = T; sh.maxd = maxd;
+    HIPCHK(hipMemcpy(&sh.root, e->v.states + slot, sizeof(azg_state), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&sh.leaf, e->v.leaf_states + slot, sizeof(azg_state), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&sh.ctr, e->v.tape_ctr + slot, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    memcpy(o, &sh, sizeof(sh)); o += sizeof(sh);
+    for (int t = 0; t < T; t++) {
+        const size_t tt = (size_t)slot * T + t;
+        memcpy(o, &hdr[t], sizeof(TreeHdr)); o += sizeof(TreeHdr);
+        HIPCHK(hipMemcpy(o, e->v.path + tt * maxd, sizeof(PathEnt) * maxd, hipMemcpyDeviceToHost)); o += sizeof(PathEnt) * maxd;
+        if (hdr[t].alloc > 0) HIPCHK(hipMemcpy(o, e->v.nodes + tt * 2 * e->v.cap + hdr[t].base, sizeof(Node) * hdr[t].alloc, hipMemcpyDeviceToHost));
+        o += sizeof(Node) * hdr[t].alloc;
+    }
+    return need;
+}
+
+extern "C" int azg_slot_import(azg_engine *e, void *stream, int slot, const void *host_buf, int64_t nbytes) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    if (!host_buf || nbytes < (int64_t)sizeof(SnapHead)) return fail(AZG_E_INVALID_ARG, "snapshot truncated");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));
+    const char *o = (const char *)host_buf, *end = o + nbytes;
+    SnapHead sh; memcpy(&sh, o, sizeof(sh)); o += sizeof(sh);
+    if (sh.magic != k_snap_magic || sh.game != e->cfg.game || sh.T != e->v.T || sh.maxd != e->v.maxd)
+        return fail(AZG_E_INVALID_ARG, "snapshot does not belong to this kind of engine (game / arena mode)");
+    HIPCHK(hipMemcpy(e->v.states + slot, &sh.root, sizeof(azg_state), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->v.leaf_states + slot, &sh.leaf, sizeof(azg_state), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->v.tape_ctr + slot, &sh.ctr, sizeof(uint64_t), hipMemcpyHostToDevice));
+    for (int t = 0; t < sh.T; t++) {
+        const size_t tt = (size_t)slot * sh.T + t;
+        if (end - o < (int64_t)(sizeof(TreeHdr) + sizeof(PathEnt) * sh.maxd)) return fail(AZG_E_INVALID_ARG, "snapshot truncated");
+        TreeHdr h; memcpy(&h, o, sizeof(h)); o += sizeof(h);
+        if (h.alloc < 0 || h.alloc > e->v.cap) return fail(AZG_E_TREE_FULL, "snapshot holds more nodes than this engine's nodes_per_tree");
+        h.base = 0;                                          // the live nodes land in semi-space 0 (indices are relative to the base)
+        HIPCHK(hipMemcpy(e->v.hdr + tt, &h, sizeof(h), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->v.path + tt * sh.maxd, o, sizeof(PathEnt) * sh.maxd, hipMemcpyHostToDevice)); o += sizeof(PathEnt) * sh.maxd;
+        if (end - o < (int64_t)sizeof(Node) * h.alloc) return fail(AZG_E_INVALID_ARG, "snapshot truncated");
+        if (h.alloc > 0) HIPCHK(hipMemcpy(e->v.nodes + tt * 2 * e->v.cap, o, sizeof(Node) * h.alloc, hipMemcpyHostToDevice));
+        o += sizeof(Node) * h.alloc;
+    }
+    return AZG_OK;
+}
+
 static int tree_of(azg_engine *e, int slot, int tree) { return slot * e->v.T + tree; }
 
 // node `node` of a tree (AZG_NODE_ROOT = the root, which lives in the header) and the base of the tree's live semi-space
@@ -911,6 +984,15 @@ extern "C" int azg_heads_softmax(void *stream, const float *logits, int boards, 
     hipLaunchKernelGGL(k_heads_softmax, dim3((boards + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, policy, value, boards, logits_stride, A, NV);
     HIPCHK(hipGetLastError());
     return AZG_OK;
+}
+
+// halves of w_packed a tower launch may read: stem (3 k-steps) + 2 * nblocks convolutions (9 * C/32 k-steps each) + the slack the weight
+// prefetch ring runs into behind the last layer.  The deepest ring is the k-split tile's (azg_conv.h conv_main2<..., WR = 9, KSTR = 2>):
+// its last prefetch of the last layer is k-step 2 * (8 + 8) + 1 = 33 of an 18 k-step layer -- 16 k-steps past the end; 18 are required.
+extern "C" int64_t azg_tower_weights_size(int channels, int nblocks) {
+    if (channels <= 0 || (channels & 31) || nblocks < 0) return fail(AZG_E_INVALID_ARG, "channels must be a positive multiple of 32");
+    const int64_t kstep = (int64_t)channels * 32;
+    return ((int64_t)STEM_KSTEPS + (int64_t)2 * nblocks * 9 * (channels / 32) + AZG_TOWER_W_SLACK_KSTEPS) * kstep;
 }
 
 // host-side layout tables of the tower (no device needed): the pixel -> (subtile, lane) map and the padded LDS row of every pixel

@@ -62,8 +62,9 @@ class DeviceEngine:
             _abi.check(self.L.azg_engine_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self._row_of_slot = None
-        per_move = cfg.sims_per_move * gi.max_children
-        self._nodes_cap = int(nodes_per_tree) if nodes_per_tree > 0 else min(gi.max_turns, 16) * per_move + 64
+        info = (C.c_int32 * 8)()                                  # the sizes in effect (the library resolves the defaults)
+        _abi.check(self.L.azg_engine_info(self.h, info))
+        self._nodes_cap, self.compact_reserve = int(info[0]), int(info[1])
 
     def close(self):
         if getattr(self, 'h', None):
@@ -251,6 +252,20 @@ class DeviceEngine:
 
     def update_root(self, slot, action):
         _abi.check(self.L.azg_update_root(self.h, _stream(), int(slot), int(action)))
+
+    def set_search_flags(self, add_root_noise, add_root_temp):
+        """the engine's default root flags from now on (used by backup(..., flags default) and by the persistent search launches)"""
+        _abi.check(self.L.azg_set_root_flags(self.h, int(bool(add_root_noise)) | 2 * int(bool(add_root_temp))))
+
+    def export_slot(self, slot=0):
+        """bytes: snapshot of one slot's search state (azg_slot_export: trees, path, root / leaf state, tape counter)."""
+        n = _abi.check(self.L.azg_slot_export(self.h, _stream(), int(slot), None, 0))
+        buf = (C.c_char * n)()
+        _abi.check(self.L.azg_slot_export(self.h, _stream(), int(slot), buf, n))
+        return bytes(buf)
+
+    def import_slot(self, blob, slot=0):
+        _abi.check(self.L.azg_slot_import(self.h, _stream(), int(slot), C.c_char_p(blob), len(blob)))
 
     def compact(self, slot=-1, force=True):
         """reclaim the nodes outside the subtree under the root (slot -1: every slot).  Never between select and backup."""

@@ -251,8 +251,13 @@ class HipResNet:
                     w2=pack_conv_weight(folded.w2[i].float(), CH // 32).to(self.device)))
             self.zero_b = torch.zeros(CH, **f32)
             # the same parameters laid out for the fused persistent tower (azg_resnet_tower_f16)
-            self.tower_w = torch.cat([self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])] +
-                                     [torch.zeros(9 * CH * 4 * 8, dtype=torch.float16, device=self.device)]).contiguous()   # ring slack (<= 8 k-steps)
+            # (+ the readable slack the weight prefetch ring runs into behind the last layer: include/azg.h AZG_TOWER_W_SLACK_KSTEPS;
+            #  the library states the total it may read, azg_tower_weights_size)
+            layers = [self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])]
+            need = int(self.L.azg_tower_weights_size(CH, len(self.blocks)))
+            have = sum(int(t.numel()) for t in layers)
+            assert 0 < need - have <= 32 * CH * 32, (need, have)
+            self.tower_w = torch.cat(layers + [torch.zeros(need - have, dtype=torch.float16, device=self.device)]).contiguous()
             self.tower_b = torch.stack([self.stem_b] + [t for b in self.blocks for t in (b['b1'], self.zero_b)]).contiguous()
             nb = len(self.blocks)
             self.tower_ps = torch.stack([b['ps'] for b in self.blocks]).contiguous() if nb else torch.zeros((1, CH), **f32)

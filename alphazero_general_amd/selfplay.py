@@ -40,6 +40,10 @@ class SelfPlayRunner:
         wide heads: softmax inside the launch; else 'probs'); tests pin each form against the oracle.  nodes_per_tree: node
         store of a tree (0 = the library's default, include/azg.h)."""
         assert heads in (None, 'probs', 'logits', 'features')
+        if heads is not None:                                        # a pinned hand-over form IS the launch-per-phase search
+            if fused_search:
+                raise ValueError('heads=%r pins a launch-per-phase form; it cannot be combined with fused_search=True' % heads)
+            fused_search = False
         self.heads = heads
         self.game_cls, self.nnet, self.args = game_cls, nnet, args
         self.game = azg_game_id(game_cls)

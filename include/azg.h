@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AZG_ABI_VERSION 3
+#define AZG_ABI_VERSION 4
 
 typedef enum azg_status {
     AZG_OK = 0,
@@ -78,7 +78,8 @@ typedef struct azg_config {
     int32_t  device;            /* HIP device ordinal */
     int32_t  num_slots;         /* B: concurrent games (batch_tensor.shape[0], SelfPlayAgent.pyx:23-26) */
     int32_t  arena;             /* 1: one tree per player per game (SelfPlayAgent.pyx:60-73)      */
-    int32_t  nodes_per_tree;    /* capacity of each of a tree's two node semi-spaces; 0 = 8 * sims_per_move * max_children + 64 */
+    int32_t  nodes_per_tree;    /* capacity of each of a tree's two node semi-spaces; 0 = min(max_turns, 16) * sims_per_move * max_children + 64
+                                 * (the value in effect: azg_engine_info) */
     int32_t  example_capacity;  /* max (obs, pi, z) samples held; 0 = no sample recording         */
     int32_t  result_capacity;   /* max finished-game records held                                  */
     float    cpuct, fpu_reduction, root_noise_frac, root_policy_temp, min_discount;   /* MCTS.pyx:134-138 */
@@ -117,6 +118,9 @@ int          azg_device_count(void);
 /* ---- engine life cycle (SelfPlayAgent.__init__ :14-58 / MCTS.__init__ :133-145) -------------------------- */
 int  azg_engine_create(const azg_config *cfg, azg_engine **out);
 int  azg_engine_destroy(azg_engine *e);
+/* the sizes in effect (defaults resolved): out8 = {nodes_per_tree, compaction reserve (free nodes below which a move's end compacts),
+ * trees per slot, path entries per tree, num_slots, example_capacity, result_capacity, sims_per_move} */
+int  azg_engine_info(azg_engine *e, int32_t *out8);
 /* reset every slot to the initial position with fresh trees (SelfPlayAgent.pyx:54-59; MCTS.reset :154-160) */
 int  azg_engine_reset(azg_engine *e, void *stream);
 /* overwrite the game state of `count` slots starting at `first` (host array) and give them fresh trees */
@@ -164,6 +168,9 @@ int  azg_backup_select_logits(azg_engine *e, void *stream, const float *logits_d
 int  azg_backup_select_features(azg_engine *e, void *stream, const void *feat_dev, int feat_k, const void *head_rows_dev,
                                 const float *head_b_dev, const int32_t *row_of_slot_dev, int flags, void *obs_dev, int obs_dtype,
                                 int do_select);
+/* replace the engine's default root flags (azg_config.add_root_noise / add_root_temp) from now on -- what AZG_FLAGS_DEFAULT and the
+ * persistent search launches use: MCTS.search(gs, nn, sims, add_root_noise, add_root_temp) passes them per call (MCTS.pyx:165) */
+int  azg_set_root_flags(azg_engine *e, int flags /* AZG_FLAG_NOISE | AZG_FLAG_TEMP */);
 #define AZG_FLAGS_DEFAULT (-1)   /* use azg_config.add_root_noise / add_root_temp                          */
 #define AZG_FLAG_NOISE 1          /* process_results(..., add_root_noise, add_root_temp) per call (:230)    */
 #define AZG_FLAG_TEMP  2
@@ -192,6 +199,14 @@ int  azg_update_root(azg_engine *e, void *stream, int slot, int action);
  * than one move's worth of nodes is free.  force = 0: only trees that are that full.  Must not be called between a find_leaf and its process_results
  * (azg_select .. azg_backup): the pending leaf's indices are void afterwards.  Results never change. */
 int  azg_compact(azg_engine *e, void *stream, int slot, int force);
+/* Snapshot of ONE slot's search state -- every tree of the slot (header with the root, the path of the last find_leaf, the live
+ * nodes), the root and leaf game states and the slot's tape counter -- into / from a host buffer: what pickling an `MCTS` object
+ * carries in the reference (alphazero/MCTS.pyx:8 `auto_pickle=True`: _root and its Node tree, _curnode, _path, depth, max_depth).
+ * azg_slot_export(host_buf = NULL) returns the bytes needed; otherwise the bytes written (or < 0).  azg_slot_import needs an engine of
+ * the same game / arena mode whose nodes_per_tree holds the snapshot's nodes (AZG_E_TREE_FULL otherwise).  A restored tree continues
+ * bit for bit (node indices are relative to the semi-space base; the tape counter travels with it).  blocking. */
+int64_t azg_slot_export(azg_engine *e, void *stream, int slot, void *host_buf, int64_t nbytes);
+int  azg_slot_import(azg_engine *e, void *stream, int slot, const void *host_buf, int64_t nbytes);
 /* children of a slot's root in list order (Node._children): a, n, q, p, v.  blocking; returns k or <0. */
 int  azg_root_children(azg_engine *e, void *stream, int slot, int tree, int max_k, int32_t *a, int32_t *n, float *q, float *p, float *v);
 /* children of an arbitrary node (node < 0: the root) incl. their node indices, for tree walks
@@ -225,10 +240,13 @@ int  azg_last_actions_dev(azg_engine *e, int32_t **actions_dev);
 
 /* The whole residual tower (stem + 2*nblocks convolutions) in ONE persistent launch with activations resident in
  * LDS (csrc/azg_conv.h k_tower2), `channels` = 64 or 128 wide (C below).  x: [boards*H*W, 8] fp16; w_packed: stem fragments
- * then conv1, conv2 of every block, followed by 9 k-steps (9 * C*32 halves) of readable slack -- the weight prefetch ring
- * runs past the last layer; bias: f32 [1 + 2*nblocks][C] (stem, then b1, b2 per block); pre_scale/pre_shift: f32 [nblocks][C];
+ * then conv1, conv2 of every block, followed by AZG_TOWER_W_SLACK_KSTEPS = 18 k-steps (18 * C*32 halves) of readable slack -- the
+ * weight prefetch ring runs past the last layer (the k-split tile: up to 16 k-steps); azg_tower_weights_size(C, nblocks) is the
+ * number of halves every tower / search launch may read from w_packed; bias: f32 [1 + 2*nblocks][C] (stem, then b1, b2 per block); pre_scale/pre_shift: f32 [nblocks][C];
  * y: [boards*H*W, C] fp16 = the final residual stream (input of the collapsed heads GEMM).
  * The kernel evaluates 1, 2 or 4 boards per workgroup tile, chosen by `boards` (small batches: small tiles, more workgroups). */
+#define AZG_TOWER_W_SLACK_KSTEPS 18
+int64_t azg_tower_weights_size(int channels, int nblocks);      /* host only, no device needed */
 int  azg_resnet_tower_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
                           const float *pre_scale_dev, const float *pre_shift_dev, void *y_dev, int boards, int nblocks,
                           int channels /* 128 or 64; every array above is sized by it instead of 128 */);

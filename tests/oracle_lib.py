@@ -440,6 +440,53 @@ class OPool:
         lib().azo_agent_last_actions(lib().azo_pool_agent(self.h, i), a)
         return a
 
+    # ---- whole-pool views in GLOBAL slot order (agent i owns slots [i * B, (i + 1) * B)) ----
+    def last_actions(self):
+        return np.concatenate([self.agent_last_actions(i) for i in range(self.n)])
+
+    def root_counts(self, slots=None):
+        """int32 [n * B, A] visit counts of every game's root children (MCTS.counts), or of the listed global slots only"""
+        L = lib()
+        slots = range(self.n * self.B) if slots is None else slots
+        out = np.zeros((len(slots), self.A), np.int32)
+        for r, gs in enumerate(slots):
+            ch = _root_children(L.azo_agent_mcts(L.azo_pool_agent(self.h, gs // self.B), gs % self.B, 0))
+            out[r, ch['a']] = ch['n']
+        return out
+
+    def root_probs(self, slots, temp=1.0):
+        L = lib()
+        out = np.zeros((len(slots), self.A), np.float32)
+        for r, gs in enumerate(slots):
+            L.azo_mcts_probs(L.azo_agent_mcts(L.azo_pool_agent(self.h, gs // self.B), gs % self.B, 0), self.game, temp, out[r])
+        return out
+
+    def samples(self):
+        """(obs, pi, z) of every agent, agent after agent (each agent's own output_queue order)"""
+        L = lib()
+        obs, pi, z = [], [], []
+        for i in range(self.n):
+            ah = L.azo_pool_agent(self.h, i)
+            n = L.azo_agent_num_samples(ah)
+            o = np.zeros((n, self.O), np.float32); p = np.zeros((n, self.A), np.float32); zz = np.zeros((n, self.NV), np.float32)
+            if n:
+                L.azo_agent_get_samples(ah, o, p, zz)
+            obs.append(o); pi.append(p); z.append(zz)
+        return np.concatenate(obs), np.concatenate(pi), np.concatenate(z)
+
+    def results(self):
+        """(winstate, turns, global slot) of every finished game, agent after agent"""
+        L = lib()
+        ws, turns, slot = [], [], []
+        for i in range(self.n):
+            ah = L.azo_pool_agent(self.h, i)
+            n = L.azo_agent_num_results(ah)
+            w = np.zeros((max(n, 1), self.NV), np.uint8); t = np.zeros(max(n, 1), np.int32); s = np.zeros(max(n, 1), np.int32)
+            if n:
+                L.azo_agent_get_results(ah, w, t, s)
+            ws.append(w[:n]); turns.append(t[:n]); slot.append(s[:n] + i * self.B)
+        return np.concatenate(ws), np.concatenate(turns), np.concatenate(slot)
+
     @property
     def expansions(self):
         return lib().azo_pool_expansions(self.h)

@@ -1,0 +1,77 @@
+"""CPU-side checks of the Python boundary that need no device: the MCTS class pickles (MCTS.pyx:8 auto_pickle), the
+compat agent's worker rendezvous fails fast and loudly when the device side cannot start (there is no CPU fallback), the tower's
+weight-buffer contract (include/azg.h AZG_TOWER_W_SLACK_KSTEPS) covers the deepest prefetch ring, and the runner refuses
+contradictory launch-form arguments."""
+import pickle
+
+import pytest
+
+
+def _args(**kw):
+    from alphazero_general_amd.utils import dotdict
+    a = dotdict(root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1, fpu_reduction=0.2, cpuct=1.25, _num_players=3, numMCTSSims=10,
+                gamesPerIteration=4, probFastSim=0, numFastSims=2)
+    a.update(kw)
+    return a
+
+
+def test_mcts_without_a_tree_pickles():
+    from alphazero_general_amd.MCTS import MCTS
+    m = MCTS(_args(_azg_seed=123, cpuct=2.5))
+    m2 = pickle.loads(pickle.dumps(m))
+    assert type(m2) is MCTS and m2._engine is None
+    assert (m2.cpuct, m2.fpu_reduction, m2.root_temp, m2.root_noise_frac, m2._num_players, m2._seed) == (2.5, 0.2, 1.1, 0.1, 3, 123)
+    assert repr(m2) == repr(m)
+    assert m2.value() == 0.0 and m2._root.n == 0
+
+
+def test_compat_agent_fails_fast_when_the_device_side_cannot_start():
+    """No GPU here: the worker interpreter connects, authenticates, receives its configuration and reports that the engine cannot
+    be created -- the agent must raise (not hang on accept, not fall back to anything)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import torch.multiprocessing as mp
+    from alphazero_general_amd.SelfPlayAgent import SelfPlayAgent
+    from alphazero_general_amd.envs.connect4 import Game
+    bt = torch.zeros((4,) + tuple(Game.observation_size()))
+    ag = SelfPlayAgent(0, Game, mp.Queue(), mp.Event(), bt, torch.zeros(4, 7), torch.zeros(4, 3), mp.Queue(), mp.Queue(), mp.Value('i', 0),
+                       mp.Value('i', 0), mp.Event(), mp.Event(), _args())
+    assert type(ag) is SelfPlayAgent
+    with pytest.raises(RuntimeError, match='device engine worker failed to start'):
+        ag._start_worker()
+    ag._stop_worker()
+
+
+def test_tower_weight_buffer_contract():
+    """azg_tower_weights_size = stem + layers + the slack the prefetch ring may read; the slack covers the k-split tile's ring
+    (conv_main2<WR = 9, KSTR = 2>: 16 k-steps past the last layer)."""
+    from alphazero_general_amd import _abi
+    L = _abi.lib()
+    for ch, nb in ((32, 4), (64, 4), (128, 8), (64, 0)):
+        kstep = ch * 32
+        layers = 3 + 2 * nb * 9 * (ch // 32)
+        total = L.azg_tower_weights_size(ch, nb)
+        assert total % kstep == 0 and total // kstep - layers == 18 >= 2 * (9 - 1) + 2
+    assert L.azg_tower_weights_size(48, 1) < 0 and L.azg_tower_weights_size(64, -1) < 0
+
+
+def test_runner_refuses_contradictory_launch_forms():
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    from alphazero_general_amd.envs.connect4 import Game
+    with pytest.raises(ValueError, match='launch-per-phase'):
+        SelfPlayRunner(Game, None, _args(), num_slots=4, heads='logits', fused_search=True)
+
+
+def test_reference_class_is_none_without_the_reference():
+    import sys
+    import alphazero_general_amd as azg
+    if 'alphazero' in sys.modules or any(p.rstrip('/').endswith('reference') for p in sys.path):
+        pytest.skip('the reference is importable in this process')
+    assert azg.reference_class('MCTS') is None and azg.reference_class('SelfPlayAgent') is None
+    from alphazero_general_amd.MCTS import MCTS
+
+    class NoRules:                                      # a game this build has no device rules for, and no reference to hand it to
+        pass
+    with pytest.raises(NotImplementedError, match='no device rule kernels'):
+        MCTS(_args()).raw_search(NoRules(), 2, False, False)

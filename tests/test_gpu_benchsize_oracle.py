@@ -1,0 +1,159 @@
+"""The launches bench.py TIMES, at the sizes it times them, directly against the CPU oracle (no launch-form-to-launch-form step in
+between):
+
+  config 2   azg_search_f16        connect4, 2048 games x 100 simulations per move
+  config 3   azg_search_wide_f16   brandubh,  512 games x 200 simulations per move (per-GPU shard)
+  config 5   azg_search_wide_f16   3-player env, 256 games x 50 simulations per move (per-GPU shard)
+
+The oracle (oracle/azg_mcts_ref.c + azg_pool_ref.c: SelfPlayAgent.generateBatch / processBatch / playMoves, SelfPlayAgent.pyx:103-202,
+over MCTS.find_leaf / process_results, MCTS.pyx:208-289; pinned to the reference's goldens by tests/test_oracle_golden.py) runs as a
+pool of agents on the host threads, every agent owning a contiguous range of the SAME global slots (same random tape), and is fed
+the network's evaluation of ITS OWN leaf observations every simulation.
+
+connect4 hands over exact probabilities (fused heads): visit counts, pi, sampled actions every move, then samples / results /
+counters must be identical.  The sparse-heads launches (configs 3 and 5) are compared twice: against an oracle fed the sparse
+evaluation itself (azg_leaf_heads_sparse_f16 + azg_heads_softmax on an every-stage-its-own-launch twin): identical; and against an
+oracle fed NNetWrapper.process (full-width heads, what the reference computes: MCTS.pyx:239-245): equal to rounding, the fraction
+of slots that never diverged is recorded (gpurun_out/nn_error.jsonl) and must be >= 0.95."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _threads():
+    """host threads for the oracle pool: the container's CPU quota (cgroup cpu.max), not the host's CPU count"""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            return max(2, min(32, int(round(int(q) / int(per)))))
+    except (OSError, ValueError):
+        pass
+    return max(2, min(32, os.cpu_count() or 2))
+
+
+def _net(game, seed):
+    import torch
+    from alphazero_general_amd import nnet as N
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    args = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[game]
+    torch.manual_seed(seed)
+    net = N.NNetWrapper(Game, args, device='cuda:0', dtype=torch.float16)
+    net.refresh()
+    assert net._hip is not None and net._hip.can_search
+    return Game, net
+
+
+def _pool(gid, B, sims, seed, cpuct, fpu):
+    n = _threads()
+    while B % n:
+        n -= 1
+    return ol.OPool(gid, n, B // n, sims=sims, games_per_iteration=1 << 30, seed=seed, cpuct=cpuct, fpu_reduction=fpu,
+                    add_root_noise=True, add_root_temp=True)
+
+
+def _sorted_rows(*arrs):
+    """the rows of several [n, ...] arrays glued together and sorted: a multiset of samples (the pool's agents each keep their own
+    output_queue, the engine has one)"""
+    flat = np.concatenate([np.ascontiguousarray(a, np.float32).reshape(a.shape[0], -1) for a in arrs], axis=1)
+    v = flat.view(np.uint32)
+    return v[np.lexsort(v.T[::-1])]
+
+
+def test_connect4_search_launch_vs_oracle_at_2048x100():
+    """BASELINE config 2 as bench.py times it: 2048 games x 100 simulations, noise + root temperature on, one azg_search_f16 launch
+    per move; 26 moves, so that games finish, restart and emit samples."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    Game, net = _net('connect4', 0)
+    B, sims, moves, seed = 2048, 100, 26, 0
+    eng = DeviceEngine(0, B, cpuct=4.0, fpu_reduction=0.4, add_root_noise=True, add_root_temp=True, seed=seed, games_per_iteration=1 << 30,
+                       example_capacity=B * 43 * 2 * 2, sims_hint=sims)
+    pool = _pool(0, B, sims, seed, 4.0, 0.4)
+    probe = list(range(0, B, 37))
+    for mv in range(moves):
+        net._hip.search(eng, sims)                                # the timed launch
+        pool.begin_round()
+        for _ in range(sims):
+            p, v = net.process(torch.from_numpy(pool.generate()))
+            pool.process(p.cpu().numpy(), v.cpu().numpy())
+        assert (eng.root_counts().cpu().numpy() == pool.root_counts()).all(), mv
+        assert (eng.root_probs(1.0).cpu().numpy()[probe] == pool.root_probs(probe, 1.0)).all(), mv
+        pool.play(); eng.advance(True)
+        assert (eng.last_actions().cpu().numpy() == pool.last_actions()).all(), mv
+    c = eng.counters()
+    assert c['sims'] == B * sims * moves == pool.sims_done and c['expansions'] == pool.expansions
+    assert c['games_played'] == pool.games_played > 0
+    eo, ep, ez = [t.cpu().numpy() for t in eng.examples()]
+    oo, op, oz = pool.samples()
+    assert eo.shape[0] == oo.shape[0] > 0
+    assert (_sorted_rows(eo, ep, ez) == _sorted_rows(oo, op, oz)).all()
+    ws, turns, slot = eng.results()
+    ows, oturns, oslot = pool.results()
+    key = lambda w, t, s: sorted(zip(s.tolist(), t.tolist(), [tuple(x) for x in w.tolist()]))
+    assert key(ws, turns, slot) == key(ows, oturns, oslot)
+    eng.close()
+
+
+@pytest.mark.parametrize('game,B,sims,moves', [('brandubh', 512, 200, 5), ('trimok', 256, 50, 8)])
+def test_wide_search_launch_vs_oracle_at_bench_size(game, B, sims, moves):
+    """BASELINE configs 3 and 5 (per-GPU shard) as bench.py times them.  ea = azg_search_wide_f16; ec = every stage its own launch
+    (azg_select, tower, azg_leaf_heads_sparse_f16, azg_heads_softmax, azg_backup), whose per-leaf probabilities feed oracle pool
+    `exact`; oracle pool `full` is fed NNetWrapper.process of its own leaves."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    Game, net = _net(game, 7)
+    hip = net._hip
+    gid, seed = Game.AZG_GAME_ID, 29
+    gi = ol.game_info(gid)
+    kw = dict(cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=seed, games_per_iteration=1 << 30,
+              example_capacity=B * (moves + 1) * gi.num_symmetries, sims_hint=sims)
+    ea, ec = DeviceEngine(gid, B, **kw), DeviceEngine(gid, B, **kw)
+    exact, full = _pool(gid, B, sims, seed, 1.25, 0.2), _pool(gid, B, sims, seed, 1.25, 0.2)
+    oc = ec.new_obs(torch.float32)
+    same = np.ones(B, bool)
+    first_div = None
+    for mv in range(moves):
+        hip.search(ea, sims)                                      # the timed launch
+        exact.begin_round(); full.begin_round()
+        for s in range(sims):
+            ec.select(oc)
+            oobs = exact.generate()
+            if s % 20 == 0:
+                assert (oc.cpu().numpy() == oobs).all(), (mv, s)
+            lg = ec.leaf_heads_sparse(hip.forward_features_nhwc8(hip.to_nhwc8(oc), key=2), hip.head_rows, hip.head2_b)
+            pol, val = ec.heads_softmax(lg)
+            ec.backup(pol, val)
+            exact.process(pol.cpu().numpy(), val.cpu().numpy())
+            p, v = net.process(torch.from_numpy(full.generate()))
+            full.process(p.cpu().numpy(), v.cpu().numpy())
+        cnt = ea.root_counts()
+        assert torch.equal(cnt, ec.root_counts()), mv
+        cnt = cnt.cpu().numpy()
+        assert (cnt == exact.root_counts()).all(), mv             # the tree side of the timed launch: bit for bit
+        assert torch.equal(ea.root_probs(1.0), ec.root_probs(1.0)) and torch.equal(ea.root_value(True), ec.root_value(True))
+        same &= (cnt == full.root_counts()).all(1)                # the network side: to rounding
+        exact.play(); full.play(); ea.advance(True); ec.advance(True)
+        act = ea.last_actions().cpu().numpy()
+        assert (act == exact.last_actions()).all() and torch.equal(ea.last_actions(), ec.last_actions()), mv
+        same &= act == full.last_actions()
+        if first_div is None and not same.all():
+            first_div = mv
+    assert (ea.tape_counters() == ec.tape_counters()).all()
+    c = ea.counters()
+    assert c == ec.counters() and c['sims'] == B * sims * moves == exact.sims_done and c['expansions'] == exact.expansions
+    assert c['games_played'] == exact.games_played
+    frac = float(same.mean())
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/nn_error.jsonl', 'a') as fh:
+        fh.write(json.dumps({'test': 'bench_size_search_vs_oracle_' + game, 'slots': B, 'sims': sims, 'rounds': moves,
+                             'vs_oracle_fed_sparse_evaluation': 'identical', 'slots_never_diverged_vs_full_heads': frac,
+                             'first_divergence_round': first_div, 'simulations_compared': B * sims * moves}) + '\n')
+    assert frac >= 0.95, (frac, first_div)
+    ea.close(); ec.close()

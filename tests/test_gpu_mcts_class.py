@@ -1,0 +1,120 @@
+"""The single-tree `MCTS` class (the reference's public surface, MCTS.pyx:119-344) beyond test_gpu_parity.py::test_mcts_class_api_vs_oracle:
+pickling with a live tree (MCTS.pyx:8 auto_pickle), `search` on the persistent launch when `nn` is this package's NNetWrapper
+(MCTS.pyx:165-173 called once per move by GenericPlayers.py:133-134), and the node-store budget."""
+import pickle
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(**kw):
+    from alphazero_general_amd.utils import dotdict
+    a = dotdict(root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1, fpu_reduction=0.2, cpuct=1.25, _num_players=3, numMCTSSims=50,
+                _azg_seed=4242)
+    a.update(kw)
+    return a
+
+
+def test_mcts_pickle_round_trip_continues_bit_for_bit():
+    """search, pickle, unpickle (a fresh engine), and both objects keep searching: same counts, same tree, same random tape; a leaf
+    found before pickling can still be backed up after it (_curnode / _path travel too)."""
+    from alphazero_general_amd.MCTS import MCTS
+    from alphazero_general_amd.envs.connect4 import Game
+    seed = 4242
+    m = MCTS(_args())
+    g = Game()
+    for a in (3, 2):
+        g.play_action(a)
+    step = [0]
+
+    def nn(obs):
+        p, v = ol.fake_eval(seed, 0, step[0], 7, 3)
+        step[0] += 1
+        return p, v
+    m.search(g, nn, 40, True, True)
+    leaf = m.find_leaf(g)                                            # a pending find_leaf crosses the pickle
+    m2 = pickle.loads(pickle.dumps(m))
+    assert type(m2) is MCTS and m2._engine is not m._engine
+    assert (m2.counts(g) == m.counts(g)).all() and (m2.depth, m2.max_depth) == (m.depth, m.max_depth)
+    assert m2._root.n == m._root.n and m2.value() == m.value()
+    p, v = ol.fake_eval(seed, 0, 999, 7, 3)
+    for x in (m, m2):
+        x.process_results(leaf, v, p, True, True)
+    for x in (m, m2):
+        step[0] = 100
+        x.search(g, nn, 30, True, True)
+    assert (m2.counts(g) == m.counts(g)).all() and (m2.probs(g, 1.0) == m.probs(g, 1.0)).all()
+    assert (m._engine.tape_counters() == m2._engine.tape_counters()).all()
+    ca = [(c.a, c.n, c.q, c.p, c.v) for c in m._root._children]
+    cb = [(c.a, c.n, c.q, c.p, c.v) for c in m2._root._children]
+    assert ca == cb and len(ca) == 7
+    a = m.best_action(g)
+    m.update_root(g, a); m2.update_root(g, a)
+    g.play_action(a)
+    m3 = pickle.loads(pickle.dumps(m2))                              # after a re-root (and its compaction)
+    for x in (m, m3):
+        step[0] = 200
+        x.search(g, nn, 30, False, False)
+    assert (m3.counts(g) == m.counts(g)).all()
+
+
+@pytest.mark.parametrize('game', ['connect4', 'brandubh', 'trimok'])
+def test_mcts_search_on_the_persistent_launch(game):
+    """MCTS.search(gs, nn, sims, noise, temp) with nn = this package's NNetWrapper: ONE launch per call.  connect4: the same tree as
+    the find_leaf / nn(obs) / process_results loop, bit for bit, noise and temperature flags honoured per call.  Sparse-heads
+    networks: the loop form evaluates full-width heads, so the trees agree to rounding -- the visit counts of a 64-simulation
+    search must match on (almost) every action; the exact statement for them is tests/test_gpu_benchsize_oracle.py."""
+    import importlib
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.MCTS import MCTS
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    na = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[game]
+    torch.manual_seed(3)
+    net = N.NNetWrapper(Game, na, device='cuda:0', dtype=torch.float16)
+    args = _args(_num_players=Game.num_players() + 1, numMCTSSims=64)
+    fast, slow = MCTS(args), MCTS(args)
+    calls = [0]
+
+    def plain(obs):                                                  # not an NNetWrapper: the per-simulation loop
+        calls[0] += 1
+        return net.predict(obs)
+    g = Game()
+    for mv in range(4):
+        noise = temp = (mv % 2 == 0)
+        fast.search(g, net, 64, noise, temp)
+        n0 = calls[0]
+        slow.search(g, plain, 64, noise, temp)
+        assert calls[0] - n0 == 64
+        cf, cs = fast.counts(g), slow.counts(g)
+        assert cf.sum() == cs.sum() == fast._root.n - 1
+        if game == 'connect4':
+            assert (cf == cs).all(), mv
+            assert (fast.probs(g, 1.0) == slow.probs(g, 1.0)).all() and fast.value() == slow.value()
+            assert (fast.depth, fast.max_depth) == (slow.depth, slow.max_depth)
+            assert (fast._engine.tape_counters() == slow._engine.tape_counters()).all()
+        else:
+            assert np.abs(cf - cs).sum() <= 4, (mv, cf, cs)
+        a = slow.best_action(g)
+        fast.update_root(g, a); slow.update_root(g, a)
+        g.play_action(a)
+    assert fast._persistent_net(net, fast._engine) is net._hip and fast._persistent_net(plain, fast._engine) is None
+
+
+def test_mcts_node_store_budget():
+    """the default node store of one MCTS object stays under NODE_STORE_BUDGET whatever numMCTSSims promises (brandubh at 1600
+    simulations would take ~1 GB); args._azg_nodes_per_tree overrides; the engine reports the capacity in effect."""
+    from alphazero_general_amd import MCTS as M
+    from alphazero_general_amd.envs.brandubh import Game
+    m = M.MCTS(_args(numMCTSSims=1600))
+    e = m._ensure(Game())
+    assert e.nodes_per_tree * 64 <= M.NODE_STORE_BUDGET and e.nodes_per_tree >= 1600 * 96
+    m2 = M.MCTS(_args(numMCTSSims=1600, _azg_nodes_per_tree=200000))
+    assert m2._ensure(Game()).nodes_per_tree == 200000
+    from alphazero_general_amd.engine import DeviceEngine
+    d = DeviceEngine(0, 4, sims_hint=100)
+    assert d.nodes_per_tree == 16 * 100 * 7 + 64 and d.compact_reserve == 100 * 7                 # the library's defaults, read back

@@ -105,7 +105,7 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
     (full-width heads: softmax over all A, mask, renormalise -- what the reference computes, MCTS.pyx:239-245).  connect4's fused
     heads hand over exact probabilities: bit-identical, asserted.  The sparse heads agree to rounding only: a slot is followed
     until its first differing move; the fraction that never diverged is recorded (gpurun_out/nn_error.jsonl) and must stay
-    above 0.85 (observed: 45 of 48 brandubh slots after 60 moves x 200 simulations, all slots in the other cases)."""
+    at or above 0.95 (observed: 47 of 48 brandubh slots after 60 moves x 200 simulations = 0.979, all slots in the other cases)."""
     import torch
     from alphazero_general_amd.selfplay import SelfPlayRunner
     Game, net = _setup(game, 7)
@@ -157,7 +157,7 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
     if game == 'connect4':
         assert frac == 1.0, (frac, first_div)
     else:
-        assert frac >= 0.85, (frac, first_div)
+        assert frac >= 0.95, (frac, first_div)
         if frac < 1.0:
             return                                              # (diverged slots play different games: the totals below differ)
     c = r.engine.counters()

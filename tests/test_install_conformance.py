@@ -109,3 +109,78 @@ def test_install_rebinds_the_reference_callers():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d['coach'] and d['arena'] and d['players'], d
     assert d['coach_file'].startswith(REF), d                   # it really is the reference's Coach that was rebound
+
+
+_FALLTHROUGH = r"""
+import os, sys, types, json, pickle
+sys.dont_write_bytecode = True
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(ref)r)
+import numpy as np
+tbx = types.ModuleType('tensorboardX')
+class _W:
+    def __init__(self, *a, **k): pass
+    def __getattr__(self, n): return lambda *a, **k: None
+tbx.SummaryWriter = _W
+sys.modules.setdefault('tensorboardX', tbx)
+import pyximport
+os.makedirs('/tmp/pyxbld', exist_ok=True)
+pyximport.install(setup_args={'include_dirs': np.get_include()}, build_dir='/tmp/pyxbld', language_level=3)
+import alphazero_general_amd as azg
+azg.install()
+import alphazero.Coach, alphazero.Arena, alphazero.GenericPlayers
+from alphazero.MCTS import MCTS                       # this package's (dispatching) class
+from alphazero.SelfPlayAgent import SelfPlayAgent
+from alphazero.utils import dotdict
+from alphazero.envs.tictactoe.tictactoe import Game as TicTacToe          # an env WITHOUT device rule kernels
+from alphazero.envs.connect4.connect4 import Game as Connect4             # an env WITH them (recognised by module name)
+import torch, torch.multiprocessing as mp
+args = dotdict(root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1, fpu_reduction=0.2, cpuct=1.25, _num_players=3,
+               numMCTSSims=10, gamesPerIteration=4, probFastSim=0, numFastSims=2, startTemp=1.0, add_root_noise=False,
+               add_root_temp=False, temp_scaling_fn=alphazero.utils.default_temp_scaling)
+out = {}
+g = TicTacToe()
+m = MCTS(args)
+np.random.seed(5); m.raw_search(g, 40, False, False)
+ref_cls = azg.reference_class('MCTS')
+out['ref_module'] = ref_cls.__module__
+out['delegated'] = type(m._ref) is ref_cls and m._engine is None
+r = ref_cls(args)
+np.random.seed(5); r.raw_search(g, 40, False, False)
+out['same_counts'] = bool((np.asarray(m.counts(g)) == np.asarray(r.counts(g))).all()) and int(np.asarray(m.counts(g)).sum()) == 39
+out['same_probs'] = bool((np.asarray(m.probs(g)) == np.asarray(r.probs(g))).all())
+out['depth'] = [m.depth, m.max_depth, r.depth, r.max_depth]
+a = m.best_action(g); m.update_root(g, a); g.play_action(a)
+m2 = pickle.loads(pickle.dumps(m))                    # an MCTSPlayer crossing a process boundary
+out['pickled'] = type(m2) is MCTS and bool((np.asarray(m2.counts(g)) == np.asarray(m.counts(g))).all())
+out['still_ours'] = sys.modules['alphazero.MCTS'].MCTS is MCTS and alphazero.GenericPlayers.MCTS is MCTS \
+    and getattr(sys.modules['alphazero'], 'MCTS', sys.modules['alphazero.MCTS']) is sys.modules['alphazero.MCTS']
+# a whole player of the reference on the fall-through game
+p = alphazero.GenericPlayers.RawMCTSPlayer(TicTacToe, args)
+g2 = TicTacToe(); np.random.seed(1)
+out['player_move_legal'] = bool(g2.valid_moves()[p.play(g2)])
+def agent(game_cls):
+    bt = torch.zeros((4,) + tuple(game_cls.observation_size()))
+    return SelfPlayAgent(0, game_cls, mp.Queue(), mp.Event(), bt, torch.zeros(4, game_cls.action_size()), torch.zeros(4, 3),
+                         mp.Queue(), mp.Queue(), mp.Value('i', 0), mp.Value('i', 0), mp.Event(), mp.Event(), args)
+ref_agent = azg.reference_class('SelfPlayAgent')
+out['agent_ttt_is_reference'] = type(agent(TicTacToe)) is ref_agent and ref_agent.__module__ == 'alphazero.SelfPlayAgent' and ref_agent is not SelfPlayAgent
+out['agent_c4_is_ours'] = type(agent(Connect4)) is SelfPlayAgent
+out['coach_still_ours'] = alphazero.Coach.SelfPlayAgent is SelfPlayAgent and sys.modules['alphazero.SelfPlayAgent'].SelfPlayAgent is SelfPlayAgent
+print(json.dumps(out))
+"""
+
+
+def test_games_without_device_rules_fall_through_to_the_reference():
+    """SURVEY.md 8b "Game plugin": after install() an env without device rule kernels (tictactoe) keeps working -- the MCTS /
+    SelfPlayAgent classes registered under the reference's names hand it to the REFERENCE'S OWN classes (same trees as calling the
+    reference directly under the same numpy seed), the names keep resolving to this package, an MCTS object on the fall-through
+    path pickles (MCTS.pyx:8), and connect4 -- the reference's own Game class -- is still routed to the device engine."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, '-c', _FALLTHROUGH % dict(root=ROOT, ref=REF)], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['ref_module'] == 'alphazero.MCTS', d
+    for k in ('delegated', 'same_counts', 'same_probs', 'pickled', 'still_ours', 'player_move_legal', 'agent_ttt_is_reference',
+              'agent_c4_is_ours', 'coach_still_ours'):
+        assert d[k], (k, d)
+    assert d['depth'][:2] == d['depth'][2:], d
