@@ -38,9 +38,23 @@ from alphazero_general_amd.selfplay import ArenaRunner, SelfPlayRunner  # noqa: 
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
-PMC_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc.json' % r) for r in (3, 2)) if os.path.exists(p)),
-                os.path.join(ROOT, 'profiles', 'r03_pmc.json'))
+PMC_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc.json' % r) for r in (4, 3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, 'profiles', 'r04_pmc.json'))
+PHASE_FILE = os.path.join(ROOT, 'profiles', 'r04_phase_budget.json')
 CALIBRATION_FILE = os.path.join(ROOT, 'profiles', 'cpu_oracle_vs_reference.json')
+CLOCK_GHZ_NOMINAL = 2.4                                                               # MI355X_MICROARCH.md (peak engine clock)
+
+
+def csrc_sha():
+    """content hash of the kernel sources (alphazero_general_amd/csrc/*): the committed PMC summary and phase budget are stamped with
+    the hash of the sources they were measured on (tools/collect_profiles.py); a counter taken on other kernels is not quoted next
+    to this run's launch time (there is no .git on the GPU box, so the stamp is a content hash, not a commit)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'alphazero_general_amd', 'csrc', '*'))):
+        h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 # name: game module, net args, games / GPU, sims / move, cpuct, fpu reduction, typical (children, depth) of the tree bytes model
 WORKLOADS = {
@@ -104,10 +118,12 @@ def measured_traffic(workload, kernel_substr):
     pmc = load_json(PMC_FILE)
     if not pmc:
         return None, None, None
+    same = pmc.get('csrc_sha') == csrc_sha()                          # were the counters taken on the kernels this run times?
     for name, rec in pmc.get('workloads', {}).get(workload, {}).items():
         if kernel_substr in name:
-            return (int(rec['traffic_bytes']), 'profiles/%s @%s (%d dispatches)' % (os.path.basename(PMC_FILE), pmc.get('git', '?'), rec.get('dispatches', 0)),
-                    rec.get('mfma_busy_cycles'))
+            return (int(rec['traffic_bytes']), 'profiles/%s @%s (%d dispatches%s)' % (os.path.basename(PMC_FILE), pmc.get('git', '?'), rec.get('dispatches', 0),
+                                                                                      '' if same else '; kernel sources have changed since'),
+                    rec.get('mfma_busy_cycles') if same else None)
     return None, None, None
 
 
@@ -266,8 +282,10 @@ def build(workload, a, rank, local_rank, dev, rounds):
 def timed_region(c, steps, warmup, world, rank):
     """W warm-up rounds, then EXACTLY `steps` rounds -- every one the product's launch form (a replayed hipGraph unless --no-graph)
     -- and the iteration's exchange step, bracketed by barrier + synchronize; nothing else runs inside."""
+    c.rounds_before = getattr(c, 'rounds_played', 0)                 # (rounds this runner has played before this region)
     for _ in range(warmup):
         c.runner.play_round()
+    c.rounds_played = c.rounds_before + warmup + steps
     c0 = c.counters()
     ex0 = [e.counters()['num_examples'] for e in c.engines] if not c.arena else None
     if world > 1 and not c.arena:                                    # (the collectives' one-time set-up stays out of the timed region)
@@ -294,6 +312,21 @@ def timed_region(c, steps, warmup, world, rank):
     r = dict(dt=dt, steps=steps, rank_ms_per_step_max=D.max_over_ranks(t_search) * 1e3 / steps,
              rank_ms_per_step_min=-D.max_over_ranks(-t_search) * 1e3 / steps, exchange_ms=D.max_over_ranks(t_exchange) * 1e3)
     r['expansions'], r['sims'], r['games'], r['samples'] = [int(x) for x in tall]
+    # steady state: all games start from the empty board at round 0, so the first finishes come in a burst; every slot plays one
+    # move per round, so a game's finishing round is the running sum of its slot's game lengths (result records, read after the
+    # region) -- games that finished in the SECOND half of the timed rounds, over that half's share of the time
+    half = steps // 2
+    late = 0
+    if half > 0:
+        _, turns, slot = c.runner.results() if not c.arena else c.runner.engine.results()
+        rounds_done = warmup + steps + c.rounds_before
+        end = {}
+        for t, sl in zip(turns.tolist(), slot.tolist()):
+            end[sl] = end.get(sl, 0) + int(t)
+            if end[sl] > rounds_done - half:
+                late += 1
+    late = int(D.all_reduce_tallies([late])[0])
+    r['games_second_half'], r['second_half_steps'] = late, half
     return r
 
 
@@ -391,6 +424,144 @@ def rooflines(c, netprof, prof):
     return roofline, roof_tree, roof_net
 
 
+def exact_heads_run(c, a, rank, local_rank, dev, world, steps=8, warmup=2):
+    """configs 3 and 5 once more with the BIT-EXACT hand-over between network and tree: full-width heads (k_heads_fact: all A logits,
+    what NNetWrapper.process computes) -> azg_backup_select_logits (softmax over all A, mask, renormalise: MCTS.pyx:239-245), one
+    tower launch + one heads launch + one tree launch per simulation, the round replayed as one hipGraph.  The timed sparse-heads
+    launch equals this to rounding only; this is what "pi bit-exact against NNetWrapper.process" costs."""
+    hip = c.net._hip
+    if c.arena or hip is None or not hip.fact_head:
+        return None
+    args = selfplay_args(c.W)
+    nsym = len(c.Game().symmetries(np.zeros(c.Game.action_size(), np.float32)))
+    x = Ctx()
+    x.name, x.W, x.B, x.sims, x.Game, x.net, x.nets, x.arena, x.pipelines = c.name + '_exact', c.W, c.B, c.sims, c.Game, c.net, c.nets, False, 1
+    x.runner = SelfPlayRunner(c.Game, c.net, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
+                              use_graph=not a.no_graph, heads='logits',
+                              example_capacity=int(c.B * (steps + warmup) / 5.0 + 2 * c.B) * (c.Game.max_turns() + 1) * nsym)
+    x.engines = [ln.engine for ln in x.runner.lanes]
+    x.counters = x.runner.counters
+    x.fused_search = False
+    x.runner.prepare()
+    t = timed_region(x, steps, warmup, world, rank)
+    out = {'value': round(t['expansions'] / t['dt'], 1), 'unit': 'expansions/s', 'ms_per_step': round(t['dt'] * 1e3 / steps, 3), 'steps': steps,
+           'warmup': warmup, 'form': 'per simulation: k_tower2 (+ 1x1 head convs) -> k_heads_fact (all %d + %d logits) -> k_backup_select2<IN_LOGITS> '
+                                      '(softmax over all A, mask, renormalise); bit-exact against NNetWrapper.process + MCTS.pyx:239-245'
+                                      % (c.Game.action_size(), c.Game.num_players() + 1)}
+    for e in x.engines:
+        e.close()
+    return out
+
+
+def phase_budget(c, roofline):
+    """The bound that applies to a persistent wide-head launch: ONE workgroup per game runs tree phase -> tower -> head convolutions
+    back to back, `sims` times -- a chain of phase latencies, not an MFMA- or HBM-limited stream.  Cycles per simulation and phase
+    come from the s_memtime stamps of the measurement build (tools/wide_search_phases.py -> profiles/r04_phase_budget.json, stamped
+    with the kernel sources' hash); the floors beside them: the tower's MFMA issue time for one board on the workgroup's SIMDs, and
+    the walk's dependent-load chain (one child block per level)."""
+    pb = load_json(PHASE_FILE)
+    if not pb or c.name not in pb.get('workloads', {}) or roofline is None:
+        return None
+    w = dict(pb['workloads'][c.name])
+    w['source'] = 'profiles/%s @%s%s' % (os.path.basename(PHASE_FILE), pb.get('git', '?'), '' if pb.get('csrc_sha') == csrc_sha() else ' (kernel sources have changed since)')
+    cyc = w['tree'] + w['tower'] + w['headconv']
+    w['bound'] = ('phase-latency chain: the game\'s workgroup runs tree phase -> tower -> head convolutions back to back, so a move takes '
+                  'sims x cycles_per_sim / shader clock; the MFMA fraction above only says how much of that chain is the tower')
+    w['cycles_per_sim'], w['sims'], w['chain_cycles_per_move'] = cyc, c.sims, cyc * c.sims
+    w['measured_launch_us'] = roofline['avg_launch_us']
+    w['implied_clock_ghz'] = round(cyc * c.sims / (roofline['avg_launch_us'] * 1e3), 3)      # chain cycles / measured launch time
+    w['chain_us_at_nominal_clock'] = round(cyc * c.sims / (CLOCK_GHZ_NOMINAL * 1e3), 1)
+    # floor of the tower phase: one board's MFMAs issued back to back on the CU's four SIMDs (one v_mfma_f32_16x16x32_f16 = 16 384
+    # FLOP per 16 cycles per SIMD = the 2.5 PFLOP/s peak over 1 024 SIMDs at 2.4 GHz)
+    per_simd_cycle = MFMA_F16_PEAK_TFLOPS * 1e12 / 1024 / (CLOCK_GHZ_NOMINAL * 1e9)
+    w['tower_mfma_floor_cycles'] = int(net_flops_per_leaf(c.Game, c.net.args) / per_simd_cycle / 4)
+    w['tower_over_mfma_floor'] = round(w['tower'] / max(w['tower_mfma_floor_cycles'], 1), 2)
+    w['tower_share_of_chain'] = round(w['tower'] / cyc, 3)
+    return w
+
+
+def compat_run(W, net, seconds=12.0, workers=2):
+    """What an UNMODIFIED Coach gets (compat mode, Coach.py:291-361): `workers` SelfPlayAgent processes with the reference's
+    constructor and queue / event / shared-tensor protocol, each driving a device engine through its worker interpreter, the
+    parent serving their batches with the GPU network exactly like Coach.processSelfPlayBatches (:337-342: ready_queue.get ->
+    nnet.process(input_tensors[id]) -> copy into the shared policy / value tensors -> batch_ready[id].set()).  Every simulation
+    pays two process hops and an H2D + D2H of the batch.  Config 2's games split over the workers; runs for `seconds`."""
+    import importlib
+    import queue
+    import torch.multiprocessing as mp
+    from alphazero_general_amd.SelfPlayAgent import SelfPlayAgent
+    Game = importlib.import_module('alphazero_general_amd.envs.' + W['game']).Game
+    B = W['B'] // workers
+    args = selfplay_args(W)
+    args.update(_num_players=Game.num_players() + 1, _azg_seed=0)
+    C, H, Wd = Game.observation_size()
+    A, NV = Game.action_size(), Game.num_players() + 1
+    ready_queue, file_queue, result_queue = mp.Queue(), mp.Queue(), mp.Queue()
+    completed, games_played = mp.Value('i', 0), mp.Value('i', 0)
+    stop, pause = mp.Event(), mp.Event()
+    inputs, pols, vals, ready, agents = [], [], [], [], []
+    for i in range(workers):                                         # Coach.generateSelfPlayAgents :291-323
+        inputs.append(torch.zeros([B, C, H, Wd]).share_memory_()); pols.append(torch.zeros([B, A]).share_memory_())
+        vals.append(torch.zeros([B, NV]).share_memory_()); ready.append(mp.Event())
+        agents.append(SelfPlayAgent(i, Game, ready_queue, ready[i], inputs[i], pols[i], vals[i], file_queue, result_queue, completed,
+                                    games_played, stop, pause, args))
+        agents[i].daemon = True
+        agents[i].start()
+    served, nsamples, t_first, t_end = 0, 0, None, None
+    deadline = time.time() + 240
+
+    def drain():
+        n = 0
+        for q in (file_queue, result_queue):
+            try:
+                while True:
+                    q.get_nowait(); n += q is file_queue
+            except queue.Empty:
+                pass
+        return n
+    try:
+        while completed.value != workers and time.time() < deadline:
+            nsamples += drain()
+            try:
+                i = ready_queue.get(timeout=0.5)
+            except queue.Empty:
+                continue
+            p, v = net.process(inputs[i])
+            pols[i].copy_(p); vals[i].copy_(v); ready[i].set()
+            if t_first is None:
+                t_first = time.time()                                # (the workers' start-up is not self-play)
+            else:
+                served += 1
+            t_end = time.time()
+            if t_end - t_first >= seconds:
+                break
+    finally:
+        stop.set()
+        for ev in ready:
+            ev.set()
+    t1 = time.time()
+    while time.time() - t1 < 20 and completed.value != workers:
+        drain()
+        try:
+            i = ready_queue.get(timeout=0.2)
+            ready[i].set()
+        except queue.Empty:
+            pass
+    drain()
+    for ag in agents:
+        ag.join(10)
+        if ag.is_alive():
+            ag.terminate()
+    if not served or t_first is None:
+        return {'error': 'no batch was served'}
+    dt = t_end - t_first
+    return {'value': round(served * B / dt, 1), 'unit': 'simulations/s (leaf evaluations served; ~ expansions/s: only revisits of terminal nodes differ)',
+            'workers': workers, 'games_per_worker': B, 'sims_per_move': W['sims'], 'batches_served': served, 'seconds': round(dt, 2),
+            'ms_per_batch': round(dt * 1e3 / served, 3), 'games_finished': int(games_played.value), 'samples_received': nsamples,
+            'path': 'alphazero_general_amd.SelfPlayAgent (reference constructor / queue protocol) x %d processes, parent serves batches like '
+                    'Coach.processSelfPlayBatches with the GPU net: per simulation two process hops + H2D + D2H of the batch' % workers}
+
+
 def workload_label(c):
     return '%s %s, %d games/GPU x %d sims/move, fp16 ResNet %dch x %d, random-init, %s' % (
         c.W['game'], 'arena (two nets)' if c.arena else 'self-play', c.B, c.sims, c.net.args.num_channels, c.net.args.depth,
@@ -421,6 +592,8 @@ def main():
     ap.add_argument('--no-other-workloads', action='store_true',
                     help='skip the short runs of BASELINE configs 3-5 that the default (connect4, 1 GPU) line carries as other_workloads')
     ap.add_argument('--profile-rounds', type=int, default=3, help='eager rounds of the persistent launch timed after the timed region')
+    ap.add_argument('--compat', action='store_true', help='also time compat mode (unmodified-Coach protocol: SelfPlayAgent processes served by the parent)')
+    ap.add_argument('--no-exact-heads', action='store_true', help='skip the bit-exact full-width-heads run of the wide-head workloads')
     a = ap.parse_args()
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -436,6 +609,7 @@ def main():
     c = build(a.workload, a, rank, local_rank, dev, a.steps + a.warmup + a.profile_rounds + 8)
     t = timed_region(c, a.steps, a.warmup, world, rank)
     netprof, prof = profile_rounds(c, a.profile_rounds)              # after the timed region
+    ex = None if a.no_exact_heads else exact_heads_run(c, a, rank, local_rank, dev, world)   # (every rank: it has its own exchange step)
     if rank != 0:
         return 0
     roofline, roof_tree, roof_net = rooflines(c, netprof, prof)
@@ -450,6 +624,9 @@ def main():
                    'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
         'games_per_sec': round(t['games'] / dt, 2), 'simulations_per_sec': round(t['sims'] / dt, 1),
         'games_finished': t['games'], 'samples_gathered': t['samples'],
+        # (all games start from the empty board: the whole-region figure includes the first burst of finishes)
+        'games_per_sec_steady': None if not t['second_half_steps'] else round(t['games_second_half'] / (dt * t['second_half_steps'] / a.steps), 2),
+        'games_finished_second_half': t['games_second_half'],
         # where the step time of an N-rank run goes: the slowest / fastest rank's own rounds, and the iteration's exchange step
         # (example all-gather + tallies, once per timed region)
         'rank_ms_per_step': {'max': round(t['rank_ms_per_step_max'], 3), 'min': round(t['rank_ms_per_step_min'], 3)},
@@ -458,6 +635,11 @@ def main():
     }
     if roof_net is not None and roofline is not roof_net:
         out['net_roofline'] = roof_net
+    pbud = phase_budget(c, roofline)
+    if pbud is not None:
+        roofline['phase_budget'] = pbud
+    if ex is not None:
+        out['exact_heads'] = ex
     if world == 1 and roofline is not None and roofline['bound'] == 'mfma' and not a.no_library_gemm:
         lib_tf = library_gemm_tflops(dev)                            # outside the timed region
         roofline['library_gemm_tflops'] = round(lib_tf, 1)
@@ -475,16 +657,32 @@ def main():
                 ot = timed_region(oc, 8, 2, world, rank)
                 onp, opf = profile_rounds(oc, 1)
                 orf, otr, _ = rooflines(oc, onp, opf)
+                opb = phase_budget(oc, orf)
+                oex = None if a.no_exact_heads else exact_heads_run(oc, a, rank, local_rank, dev, world)
                 others[name] = {'workload': workload_label(oc), 'value': round(ot['expansions'] / ot['dt'], 1), 'unit': 'expansions/s',
                                 'games_per_sec': round(ot['games'] / ot['dt'], 2), 'steps': 8, 'warmup': 2,
                                 'ms_per_step': round(ot['dt'] * 1e3 / 8, 3), 'fused_search_launch': oc.fused_search,
                                 'roofline': None if orf is None else {k: orf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
                                                                                              'executed_frac', 'avg_launch_us', 'launches_timed', 'traffic')},
                                 'tree_launch_us': None if otr is None else otr['avg_launch_us']}
+                if opb is not None:
+                    others[name]['phase_budget'] = opb
+                if oex is not None:
+                    others[name]['exact_heads'] = oex
                 release(oc)
             except Exception as ex:                                  # noqa: BLE001
                 others[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+        try:                                                         # compat mode: what an unmodified Coach gets (config 2's games, 2 workers)
+            torch.manual_seed(0)
+            cnet = NNetWrapper(__import__('alphazero_general_amd.envs.connect4', fromlist=['Game']).Game, nn_mod.CONNECT4_NET_ARGS, device=dev, dtype=torch.float16)
+            cnet.refresh()
+            others['compat'] = compat_run(WORKLOADS['connect4'], cnet)
+            del cnet
+        except Exception as ex:                                      # noqa: BLE001
+            others['compat'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
         out['other_workloads'] = others
+    elif world == 1 and a.compat and not c.arena:
+        out['compat'] = compat_run(c.W, c.net)
     print(json.dumps(out))
     return 0
 

@@ -167,6 +167,38 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     assert 'cpu_baseline' not in d                                       # rank 0, N = 1 only
 
 
+@pytest.mark.parametrize('workload,slots', [('brandubh', 64), ('arena', 64), ('trimok', 64)])
+def test_bench_two_ranks_other_workloads(workload, slots):
+    """the N-rank path of the OTHER bench workloads (BASELINE configs 3-5) before their first contact with a multi-GPU node: two
+    ranks on GPU 0 over gloo, self-launched; brandubh / trimok also run their bit-exact full-width-heads leg on both ranks (its
+    own exchange step), the arena has no example exchange at all."""
+    import json
+    import os
+    import signal
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AZG_DIST_BACKEND='gloo', AZG_SINGLE_DEVICE='1')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', workload, '--steps', '5', '--warmup', '1', '--slots', str(slots),
+           '--profile-rounds', '1']
+    p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        raise
+    lines = [l for l in out.decode(errors='replace').splitlines() if l.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, out.decode(errors='replace')[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['ranks'] == 2 and d['config']['backend'] == 'gloo' and d['value'] > 0
+    assert d['config']['games_per_gpu'] == slots and d['roofline'] is not None
+    sims = {'brandubh': 200, 'arena': 100, 'trimok': 50}[workload]
+    assert d['simulations_per_sec'] * d['ms_per_step'] * 1e-3 * d['steps'] == pytest.approx(2 * slots * sims * 5, rel=1e-3)   # both ranks' work is in the line
+    if workload != 'arena':
+        assert d['exact_heads']['value'] > 0 and d['config']['fused_search_launch']
+
+
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     """one rank launched, --gpus 2 claimed: bench.py must fail instead of printing n_gpus = 2 for a one-GPU run."""
     import os

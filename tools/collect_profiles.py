@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-ROUND = 'r03'
+ROUND = 'r04'
 SCRATCH = os.path.join(ROOT, 'gpurun_out', ROUND + '_prof')
 KEEP = ('k_tower2', 'k_backup_select2', 'k_heads', 'k_select', 'k_backup', 'k_play', 'k_compact', 'k_emit', 'k_finalize', 'k_arena_rows')
 
@@ -87,9 +87,11 @@ def main():
     global REUSE
     REUSE = a.reuse
     os.makedirs(PROF, exist_ok=True); os.makedirs(SCRATCH, exist_ok=True)
-    summary_rows, pmc = [], {'git': a.git, 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
+    sys.path.insert(0, ROOT)
+    import bench
+    summary_rows, pmc = [], {'git': a.git, 'csrc_sha': bench.csrc_sha(), 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
     for w in a.workloads:
-        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm', '--no-other-workloads']
+        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm', '--no-other-workloads', '--no-exact-heads']
         out, line, rc = rocprof('kt_' + w, ['--kernel-trace', '--stats'], base + ['--steps', '12', '--warmup', '2'])
         stats = glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True)
         if stats:
