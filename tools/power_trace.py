@@ -23,10 +23,28 @@ sys.path.insert(0, ROOT)
 
 
 def find_hwmon():
-    for d in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
-        if os.path.exists(os.path.join(d, 'freq1_input')) or os.path.exists(os.path.join(d, 'power1_average')) or os.path.exists(os.path.join(d, 'power1_input')):
-            return d
-    return None
+    """hwmon directory of the GPU this process computes on (the host has several: match HIP device 0's PCI address; if that
+    fails, the card whose gpu_busy_percent is highest while a short burst of work runs here)"""
+    import torch
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        hits = glob.glob('/sys/bus/pci/devices/%s/hwmon/hwmon*' % bdf)
+        if hits:
+            return hits[0]
+    except Exception:                                            # noqa: BLE001
+        pass
+    x = torch.randn(8192, 8192, device='cuda', dtype=torch.float16)
+    best, busy = None, -1
+    for _ in range(20):
+        x @ x
+    for d in sorted(glob.glob('/sys/class/drm/card*/device')):
+        b = read_int(os.path.join(d, 'gpu_busy_percent'))
+        hw = glob.glob(os.path.join(d, 'hwmon', 'hwmon*'))
+        if b is not None and hw and b > busy:
+            best, busy = hw[0], b
+    torch.cuda.synchronize()
+    return best
 
 
 def read_int(path):
@@ -100,14 +118,17 @@ def search_loop(seconds):
     torch.manual_seed(0)
     net = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', dtype=torch.float16); net.refresh()
     B, sims = 2048, 100
-    e = DeviceEngine(0, B, cpuct=4.0, fpu_reduction=0.4, add_root_noise=True, add_root_temp=True, seed=0, sims_hint=sims, example_capacity=0)
+    e = DeviceEngine(0, B, cpuct=4.0, fpu_reduction=0.4, add_root_noise=True, add_root_temp=True, seed=0, sims_hint=sims, example_capacity=B * 43 * 2 * 2)
     for _ in range(3):
-        net._hip.search(e, sims); e.advance(False)
+        net._hip.search(e, sims); e.advance(True)
     torch.cuda.synchronize()
     t0 = time.time(); n = 0
     while time.time() - t0 < seconds:
-        net._hip.search(e, sims); e.advance(False); n += 1
+        net._hip.search(e, sims); e.advance(True); n += 1
+        if n % 8 == 0:
+            e.clear_outputs()
         torch.cuda.synchronize()
+    e.counters()                                                 # (raises on a sticky device error)
     dt = time.time() - t0
     return n, dt, bench.net_flops_per_leaf(Game, net.args) * B * sims * n / dt / 1e12
 
@@ -118,7 +139,8 @@ def main():
     ap.add_argument('--seconds', type=float, default=5.0)
     a = ap.parse_args()
     sm = Sampler()
-    out = {'git': a.git, 'telemetry': sm.kind, 'note': 'clock_from_rate_mhz = TFLOP/s / (1 024 SIMDs x 1 024 FLOP per clock): the clock the MFMA pipes '
+    cap = read_int(os.path.join(sm.hw, 'power1_cap')) if sm.hw else None
+    out = {'git': a.git, 'telemetry': sm.kind, 'power_cap_w': None if cap is None else cap / 1e6, 'note': 'clock_from_rate_mhz = TFLOP/s / (1 024 SIMDs x 1 024 FLOP per clock): the clock the MFMA pipes '
            'must have run at if they issued back to back; sclk / power = device telemetry sampled during the run', 'cases': []}
     sm.start()
     hold = os.path.join(ROOT, 'tools', 'ubench', 'mfma_hold')
