@@ -73,6 +73,8 @@ class SelfPlayAgent(mp.Process):
             self.batch_indices = None
         self.fast = False
         self._conn = None
+        self._more_sims = False          # run(): another simulation of this move follows the processBatch being made
+        self._ahead = None               # the worker already ran that simulation's find_leaf (fused with the backup): its reply
 
     # ---- worker plumbing ----
     def _call(self, cmd, arg=None):
@@ -179,11 +181,15 @@ class SelfPlayAgent(mp.Process):
                 self._check_pause()
                 self.fast = np.random.random_sample() < a.probFastSim
                 sims = a.numFastSims if self.fast else a.numMCTSSims if not self._is_warmup else a.numWarmupSims
-                for _ in range(sims):
+                for i in range(sims):
                     if self.stop_event.is_set(): break
                     self.generateBatch()
                     if self.stop_event.is_set(): break
+                    # (processBatch of simulation i and generateBatch of i + 1 are adjacent and touch the same trees: when another
+                    #  simulation follows, the worker runs them as ONE launch -- azg_backup_select -- and one pipe round trip)
+                    self._more_sims = i + 1 < sims
                     self.processBatch()
+                    self._more_sims = False
                 if self.stop_event.is_set(): break
                 self.playMoves()
         except Exception:
@@ -206,7 +212,10 @@ class SelfPlayAgent(mp.Process):
         if self._is_warmup:
             self._call('select_noobs')
             return
-        rows = self._call('select')
+        if self._ahead is not None:                                    # (done together with the previous processBatch)
+            rows, self._ahead = self._ahead[0], None
+        else:
+            rows = self._call('select')
         shape = tuple(self.game_cls.observation_size())
         if self._is_arena:
             row_of_slot, rpm = rows
@@ -234,7 +243,10 @@ class SelfPlayAgent(mp.Process):
             self.batch_ready.clear()
             self._pol_h[:] = self.policy_tensor.data.numpy()
             self._val_h[:] = self.value_tensor.data.numpy()
-        self._call('backup')
+        if self._more_sims and not self._is_warmup:
+            self._ahead = (self._call('backup_select'),)
+        else:
+            self._call('backup')
 
     def playMoves(self):                                               # :153-202
         self._check_pause()

@@ -46,6 +46,12 @@ def engine_worker(conn, cfg):
                 pol.copy_(_t.from_numpy(pol_h)); val.copy_(_t.from_numpy(val_h))
                 eng.backup(pol, val, row_of_slot if cfg['arena'] else None)
                 conn.send(('ok', None))
+            elif cmd == 'backup_select':                         # processBatch of this simulation + generateBatch of the next: one launch
+                pol.copy_(_t.from_numpy(pol_h)); val.copy_(_t.from_numpy(val_h))
+                # (arena: the movers -- hence the row <-> game map -- do not change until the move is played)
+                eng.backup_select(pol, val, obs, row_of_slot if cfg['arena'] else None)
+                obs_h[:] = obs.reshape(B, -1).cpu().numpy()
+                conn.send(('ok', (row_of_slot.cpu().numpy().copy(), rpm.cpu().numpy().copy()) if cfg['arena'] else None))
             elif cmd == 'advance_begin':
                 fin = eng.advance_begin(record_history=arg)
                 idx = np.flatnonzero(fin)

@@ -4,6 +4,8 @@ between):
   config 2   azg_search_f16        connect4, 2048 games x 100 simulations per move
   config 3   azg_search_wide_f16   brandubh,  512 games x 200 simulations per move (per-GPU shard)
   config 5   azg_search_wide_f16   3-player env, 256 games x 50 simulations per move (per-GPU shard)
+  config 4   ArenaRunner's graph   connect4 arena, 256 games x 100 simulations, two nets (per-GPU shard): one multi-model tower launch +
+                                   one tree launch per simulation, a whole move replayed as one hipGraph
 
 The oracle (oracle/azg_mcts_ref.c + azg_pool_ref.c: SelfPlayAgent.generateBatch / processBatch / playMoves, SelfPlayAgent.pyx:103-202,
 over MCTS.find_leaf / process_results, MCTS.pyx:208-289; pinned to the reference's goldens by tests/test_oracle_golden.py) runs as a
@@ -157,3 +159,47 @@ def test_wide_search_launch_vs_oracle_at_bench_size(game, B, sims, moves):
                              'first_divergence_round': first_div, 'simulations_compared': B * sims * moves}) + '\n')
     assert frac >= 0.95, (frac, first_div)
     ea.close(); ec.close()
+
+
+def test_arena_graph_vs_oracle_at_256x100():
+    """BASELINE config 4 (per-GPU shard) as bench.py times it: 256 arena games x 100 simulations, two differently seeded 128ch x 8
+    nets, arenaTemp 0.25, the native runner's whole-move hipGraph (device-side row split, both models in one launch) against the
+    oracle's arena agent (SelfPlayAgent.pyx:44-47,117-132,142-151 with the reference's row mis-routing off) fed, every simulation, by
+    the same two networks evaluating ITS leaf rows per model: actions every move, then tallies, results, counters -- until games have
+    finished and restarted."""
+    import torch
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import CONNECT4_NET_ARGS, NNetWrapper
+    from alphazero_general_amd.selfplay import ArenaRunner
+    from alphazero_general_amd.utils import dotdict, default_temp_scaling
+    nets = []
+    for sd in (0, 1):
+        torch.manual_seed(sd)
+        n = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', dtype=torch.float16); n.refresh(); nets.append(n)
+    B, sims, moves, seed = 256, 100, 24, 0
+    args = dotdict(numMCTSSims=sims, numFastSims=20, probFastSim=0.0, gamesPerIteration=1 << 30, cpuct=4.0, fpu_reduction=0.4,
+                   root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0, add_root_noise=True, add_root_temp=True,
+                   symmetricSamples=True, mctsResetThreshold=0, startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
+    r = ArenaRunner(Game, nets, args, num_slots=B, seed=seed, result_capacity=8 * B)
+    assert r.device_split and r._graph is not None
+    ag = ol.OAgent(0, B, sims=sims, games_per_iteration=1 << 30, seed=seed, cpuct=4.0, fpu_reduction=0.4, is_arena=True, ref_misroute=False)
+    assert ag.player_to_index() == r.player_to_index
+    for mv in range(moves):
+        ag.begin_round()
+        for _ in range(sims):
+            oobs, rg, rm = ag.generate_batch()
+            pol = np.zeros((B, 7), np.float32); val = np.zeros((B, 3), np.float32)
+            for m, n in enumerate(nets):
+                idx = np.flatnonzero(rm == m)
+                if len(idx):
+                    p, v = n.process(torch.from_numpy(oobs[idx]))
+                    pol[idx], val[idx] = p.cpu().numpy(), v.cpu().numpy()
+            ag.process_batch(pol, val)
+        ag.play_moves()
+        r.play_round()                                            # the timed form: one graph replay per move
+        assert (r.engine.last_actions().cpu().numpy() == ag.last_actions()).all(), mv
+    c = r.engine.counters()
+    assert c['games_played'] == ag.games_played > 0 and c['sims'] == B * sims * moves == ag.sims_done and c['expansions'] == ag.expansions
+    ws, turns, slot = r.engine.results()
+    ows, oturns, oslot = ag.results()
+    assert len(ws) > 0 and (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all()

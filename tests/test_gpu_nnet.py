@@ -193,6 +193,37 @@ def test_tower_tile_shapes_agree(game):
             assert torch.equal(f, feats[0])
 
 
+def test_trimok_tower_tile_shapes_agree():
+    """the 5x5 x 32-channel tower's tile shapes -- 2 boards in two pixel groups (<= 2048 boards), 5 boards unsplit (above); the one-board
+    tile of the persistent search launch is compared with these in tests/test_gpu_fullsize.py -- must give a board bit-identical head
+    features (same MFMA accumulation order per output everywhere)."""
+    import torch
+    from alphazero_general_amd.envs.trimok import Game
+    from alphazero_general_amd.nnet import DEFAULT_NET_ARGS as NA, NNetWrapper
+    rng = np.random.RandomState(4)
+    obs = []
+    for b in range(200):
+        g = Game()
+        for _ in range(rng.randint(0, 12)):
+            if g.win_state().any():
+                break
+            g.play_action(int(rng.choice(np.flatnonzero(g.valid_moves()))))
+        obs.append(g.observation())
+    base = torch.from_numpy(np.array(obs, np.float32))
+    torch.manual_seed(17)
+    net = NNetWrapper(Game, NA, device='cuda:0', backend='hip')
+    _randomize(net.nnet.cpu(), torch, seed=8); net.nnet.to('cuda:0'); net.refresh()
+    hip = net._hip
+    assert hip.fact_head
+    feats = []
+    for n in (200, 1500, 2100, 4300):
+        x = hip.to_nhwc8(base.repeat((n + 199) // 200, 1, 1, 1)[:n].to('cuda:0'))
+        feats.append(hip.forward_features_nhwc8(x, key=n)[:200].clone())
+    assert float(feats[0].float().abs().max()) > 0
+    for f in feats[1:]:
+        assert torch.equal(f, feats[0])
+
+
 def test_mfma_tower_trimok_32ch_vs_fp32_reference():
     """the tower at 32 channels (one wave per workgroup) on the 5x5 three-player board, 5 input planes, default net of
     Coach.py:108-116; heads through the wide-head kernel (A + NV = 29)."""
