@@ -292,11 +292,11 @@ def timed_region(c, steps, warmup, world, rank):
         o_, p_, z_ = c.runner.samples(ex0)
         D.all_gather_examples(o_[:1], p_[:1], z_[:1])
     D.barrier(); torch.cuda.synchronize()
-    t0 = time.time()
+    t0 = time.perf_counter()
     for _ in range(steps):
         c.runner.play_round()
     torch.cuda.synchronize()
-    t_search = time.time() - t0                                      # this rank's own rounds (before it waits for anybody)
+    t_search = time.perf_counter() - t0                                      # this rank's own rounds (before it waits for anybody)
     c1 = c.counters()
     nsamples = 0
     if not c.arena:                                                  # the exchange step of an iteration: all-gather the example shards
@@ -306,9 +306,9 @@ def timed_region(c, steps, warmup, world, rank):
     tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'],
                                  c1['games_played'] - c0['games_played'], nsamples if rank == 0 else 0])
     torch.cuda.synchronize()
-    t_exchange = time.time() - t0 - t_search
+    t_exchange = time.perf_counter() - t0 - t_search
     D.barrier()
-    dt = D.max_over_ranks(time.time() - t0)
+    dt = D.max_over_ranks(time.perf_counter() - t0)
     r = dict(dt=dt, steps=steps, rank_ms_per_step_max=D.max_over_ranks(t_search) * 1e3 / steps,
              rank_ms_per_step_min=-D.max_over_ranks(-t_search) * 1e3 / steps, exchange_ms=D.max_over_ranks(t_exchange) * 1e3)
     r['expansions'], r['sims'], r['games'], r['samples'] = [int(x) for x in tall]
