@@ -61,8 +61,7 @@ def reference_class(name):
             pkg = sys.modules.get('alphazero')
             if pkg is not None:
                 setattr(pkg, name, ours)
-        else:
-            sys.modules.pop(full, None)
+        # (install() was never called and the name was not imported yet: the reference's module simply stays imported)
     _reference[name] = cls
     return cls
 

@@ -506,6 +506,17 @@ extern "C" int azg_slot_import(azg_engine *e, void *stream, int slot, const void
     SnapHead sh; memcpy(&sh, o, sizeof(sh)); o += sizeof(sh);
     if (sh.magic != k_snap_magic || sh.game != e->cfg.game || sh.T != e->v.T || sh.maxd != e->v.maxd)
         return fail(AZG_E_INVALID_ARG, "snapshot does not belong to this kind of engine (game / arena mode)");
+    {                                                        // validate the whole snapshot before anything is written
+        const char *q = o;
+        for (int t = 0; t < sh.T; t++) {
+            if (end - q < (int64_t)(sizeof(TreeHdr) + sizeof(PathEnt) * sh.maxd)) return fail(AZG_E_INVALID_ARG, "snapshot truncated");
+            TreeHdr h; memcpy(&h, q, sizeof(h));
+            if (h.alloc < 0 || h.alloc > e->v.cap) return fail(AZG_E_TREE_FULL, "snapshot holds more nodes than this engine's nodes_per_tree");
+            q += sizeof(TreeHdr) + sizeof(PathEnt) * sh.maxd;
+            if (end - q < (int64_t)sizeof(Node) * h.alloc) return fail(AZG_E_INVALID_ARG, "snapshot truncated");
+            q += sizeof(Node) * h.alloc;
+        }
+    }
     HIPCHK(hipMemcpy(e->v.states + slot, &sh.root, sizeof(azg_state), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->v.leaf_states + slot, &sh.leaf, sizeof(azg_state), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->v.tape_ctr + slot, &sh.ctr, sizeof(uint64_t), hipMemcpyHostToDevice));

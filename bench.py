@@ -46,13 +46,13 @@ CLOCK_GHZ_NOMINAL = 2.4                                                         
 
 
 def csrc_sha():
-    """content hash of the kernel sources (alphazero_general_amd/csrc/*): the committed PMC summary and phase budget are stamped with
+    """content hash of the kernel sources (alphazero_general_amd/csrc/*.h): the committed PMC summary and phase budget are stamped with
     the hash of the sources they were measured on (tools/collect_profiles.py); a counter taken on other kernels is not quoted next
     to this run's launch time (there is no .git on the GPU box, so the stamp is a content hash, not a commit)."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'alphazero_general_amd', 'csrc', '*'))):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'alphazero_general_amd', 'csrc', '*.h'))):       # (the device code; azg_engine.hip is the host side)
         h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read())
     return h.hexdigest()[:16]
 

@@ -118,3 +118,33 @@ def test_mcts_node_store_budget():
     from alphazero_general_amd.engine import DeviceEngine
     d = DeviceEngine(0, 4, sims_hint=100)
     assert d.nodes_per_tree == 16 * 100 * 7 + 64 and d.compact_reserve == 100 * 7                 # the library's defaults, read back
+
+
+def test_slot_snapshot_is_checked_on_import():
+    """azg_slot_import refuses a snapshot of another game, a truncated one, and one that holds more nodes than the receiving engine's
+    node store (AZG_E_TREE_FULL) -- loudly, never a partial restore that would search a broken tree."""
+    import torch
+    from alphazero_general_amd import _abi
+    from alphazero_general_amd.engine import DeviceEngine
+    a = DeviceEngine(0, 2, seed=3, sims_hint=30)
+    pol = torch.full((2, 7), 1 / 7, device=a.device); val = torch.full((2, 3), 1 / 3, device=a.device)
+    for _ in range(30):
+        a.select(None); a.backup(pol, val)
+    blob = a.export_slot(1)
+    used = a.tree_info(1)['nodes_used']
+    assert used > 100 and len(blob) > used * 32
+    b = DeviceEngine(0, 1, seed=9, sims_hint=30)
+    b.import_slot(blob, 0)                                        # slot 1 of one engine -> slot 0 of another
+    assert b.tree_info(0) == a.tree_info(1) and (b.root_counts()[0] == a.root_counts()[1]).all()
+    for x in (a, b):
+        x.select(None); x.backup(pol, val)
+    assert (b.root_counts()[0] == a.root_counts()[1]).all() and b.tape_counters()[0] == a.tape_counters()[1]
+    small = DeviceEngine(0, 1, seed=9, sims_hint=30, nodes_per_tree=64)
+    with pytest.raises(_abi.AzgError) as ei:
+        small.import_slot(blob, 0)
+    assert ei.value.code == _abi.E_TREE_FULL
+    other = DeviceEngine(2, 1, seed=9, sims_hint=30)
+    with pytest.raises(_abi.AzgError):
+        other.import_slot(blob, 0)
+    with pytest.raises(_abi.AzgError):
+        b.import_slot(blob[:200], 0)
