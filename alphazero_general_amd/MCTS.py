@@ -225,7 +225,7 @@ class MCTS:
         launch for this engine's game on this engine's device, else None"""
         from .nnet import NNetWrapper
         w = nn if isinstance(nn, NNetWrapper) else getattr(nn, '__self__', None)
-        if not isinstance(w, NNetWrapper) or not w.fast or w.device != e.device:
+        if not isinstance(w, NNetWrapper) or not w.fast or w.device.type != 'cuda' or w.device.index not in (None, e.device.index):
             return None
         if w._infer is None:
             w.refresh()
