@@ -28,6 +28,8 @@ def encode_state(gs):
     gid = azg_game_id(gs)
     if gid == 0:                   # the reference's own connect4 Game (envs/connect4/connect4.pyx:20-40)
         return np.asarray(gs._board.pieces, np.int8).reshape(-1), gs.player, gs.turns
+    if gid == 1:                   # the reference's own brandubh Game (envs/brandubh/fastafl.pyx:121-131; fastafl/cengine.pyx:24-32,59)
+        return np.asarray(gs._board._state, np.int8).reshape(-1), gs.player, gs.turns, int(gs._board._king_captured)
     raise NotImplementedError('cannot encode %r for the device engine' % type(gs))
 
 
@@ -40,7 +42,15 @@ def decode_state(template, cells, player, turns, aux0=0):
         except TypeError:
             return cls.from_azg_state(cells, player, turns)
     g = template.clone()
-    g._board.pieces = np.asarray(cells, np.intc).reshape(np.asarray(template._board.pieces).shape).copy()
+    if hasattr(g._board, '_state'):                            # the reference's brandubh Game: fastafl Board (boardgame/board.pxd:31-40)
+        shape = np.asarray(template._board._state).shape
+        g._board._state = np.asarray(cells, np.uint8).reshape(shape).copy()
+        g._board.num_turns = int(turns)
+        g._board._king_captured = bool(aux0)
+        g._board._king_escaped = False
+        g._board._king_escaped = bool(g._board.king_escaped())      # (the flag Board.move leaves behind, cengine.pyx:144-148,271)
+    else:
+        g._board.pieces = np.asarray(cells, np.intc).reshape(np.asarray(template._board.pieces).shape).copy()
     g._player, g._turns = int(player), int(turns)
     return g
 

@@ -184,3 +184,57 @@ def test_games_without_device_rules_fall_through_to_the_reference():
               'agent_c4_is_ours', 'coach_still_ours'):
         assert d[k], (k, d)
     assert d['depth'][:2] == d['depth'][2:], d
+
+
+_REF_STATES = r"""
+import os, sys, types, json
+sys.dont_write_bytecode = True
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(ref)r)
+import numpy as np
+tbx = types.ModuleType('tensorboardX')
+class _W:
+    def __init__(self, *a, **k): pass
+    def __getattr__(self, n): return lambda *a, **k: None
+tbx.SummaryWriter = _W
+sys.modules.setdefault('tensorboardX', tbx)
+import pyximport
+os.makedirs('/tmp/pyxbld', exist_ok=True)
+pyximport.install(setup_args={'include_dirs': np.get_include()}, build_dir='/tmp/pyxbld', language_level=3)
+from alphazero.envs.brandubh.fastafl import Game as RefBR
+from alphazero.envs.connect4.connect4 import Game as RefC4
+from alphazero_general_amd.MCTS import encode_state, decode_state
+from alphazero_general_amd.Game import azg_game_id
+from alphazero_general_amd.envs.brandubh import Game as OurBR
+from alphazero_general_amd.envs.connect4 import Game as OurC4
+rng = np.random.RandomState(3)
+out = {'br': 0, 'c4': 0, 'ok': True}
+for Ref, Our, key in ((RefBR, OurBR, 'br'), (RefC4, OurC4, 'c4')):
+    assert azg_game_id(Ref()) == Our.AZG_GAME_ID
+    for game in range(12):
+        r, o = Ref(), Our()
+        for ply in range(60):
+            if np.asarray(r.win_state()).any():
+                break
+            er, eo = encode_state(r), encode_state(o)
+            same = (np.asarray(er[0]) == np.asarray(eo[0])).all() and tuple(int(x) for x in er[1:]) == tuple(int(x) for x in eo[1:])
+            d = decode_state(r, *er)                    # back into the REFERENCE's class
+            same = same and type(d) is Ref and (np.asarray(d.valid_moves()) == np.asarray(r.valid_moves())).all() \
+                and (np.asarray(d.win_state()) == np.asarray(r.win_state())).all() \
+                and (np.asarray(d.observation()) == np.asarray(r.observation())).all() and d.player == r.player and d.turns == r.turns
+            out['ok'] = out['ok'] and bool(same)
+            out[key] += 1
+            a = int(rng.choice(np.flatnonzero(np.asarray(r.valid_moves()))))
+            r.play_action(a); o.play_action(a)
+print(json.dumps(out))
+"""
+
+
+def test_reference_game_objects_encode_and_decode():
+    """GenericPlayers hands `MCTS.search` / `find_leaf` the REFERENCE'S own Game objects (connect4.pyx, brandubh/fastafl.pyx) and expects
+    leaves of the same class back (MCTS.pyx:208-228): their state must cross the ABI both ways -- same azg_state as this package's
+    env after the same moves; decoded objects indistinguishable from the originals (valid moves, win state, observation)."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, '-c', _REF_STATES % dict(root=ROOT, ref=REF)], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['ok'] and d['br'] > 200 and d['c4'] > 100, d
