@@ -81,7 +81,7 @@ def _rebuild_mcts(params, game, blob, depth, max_depth, nodes_used):
     """unpickle (MCTS.__reduce__): same parameters and tape seed; the tree, if there was one, is restored into a fresh engine"""
     from .utils import dotdict
     m = MCTS(dotdict(params))
-    m.depth, m.max_depth = depth, max_depth
+    m.depth, m._max_depth = depth, max_depth
     if blob is not None:
         m._ensure_game(game)
         m._engine.import_slot(blob)
@@ -96,7 +96,7 @@ def _rebuild_ref_mcts(args, blob):
     with reference_module('MCTS'):
         ref = pickle.loads(blob)
     m = MCTS(dotdict(args))
-    m._ref, m.depth, m.max_depth = ref, ref.depth, ref.max_depth
+    m._ref, m.depth, m._max_depth = ref, ref.depth, ref.max_depth
     return m
 
 
@@ -120,7 +120,21 @@ class MCTS:
         self._nodes_used = 0
         self._compact_futile = False
         self.depth = 0
-        self.max_depth = 0
+        self._max_depth = 0
+
+    # max_depth is a public, WRITABLE attribute of the reference's class (MCTS.pyx:130: `cdef public int max_depth`); Evaluator.py:343 resets
+    # it from outside (`self._mcts.max_depth = 0`) before a search of its own made of find_leaf / process_results calls
+    @property
+    def max_depth(self):
+        return self._max_depth
+
+    @max_depth.setter
+    def max_depth(self, v):
+        self._max_depth = int(v)
+        if self._ref is not None:
+            self._ref.max_depth = int(v)
+        elif self._engine is not None and int(v) == 0:
+            self._engine.reset_max_depth()
 
     # ---- pickling (MCTS.pyx:8 auto_pickle=True: the reference pickles _root with its whole Node tree, _curnode, _path, depth, max_depth)
     def __reduce__(self):
@@ -148,7 +162,7 @@ class MCTS:
 
     def _via_ref(self, ref, name, *a):
         out = getattr(ref, name)(*a)
-        self.depth, self.max_depth = ref.depth, ref.max_depth
+        self.depth, self._max_depth = ref.depth, ref.max_depth
         return out
 
     # ---- engine plumbing ----
@@ -195,7 +209,7 @@ class MCTS:
             return self._via_ref(self._ref, 'reset')
         if self._engine is not None:
             self._engine.reset()
-        self.depth = self.max_depth = 0
+        self.depth = self._max_depth = 0
         self._nodes_used, self._compact_futile = 0, False
 
     def __repr__(self):
@@ -222,7 +236,7 @@ class MCTS:
             hip.search(e, int(sims))
             info = e.tree_info(0)
             self._nodes_used = info['nodes_used']
-            self.depth, self.max_depth = info['depth'], info['max_depth']
+            self.depth, self._max_depth = info['depth'], info['max_depth']
             return
         for _ in range(sims):
             leaf = self.find_leaf(gs)
@@ -274,7 +288,7 @@ class MCTS:
         st = e.get_leaf_states(0, 1, full=True)[0]
         info = e.tree_info(0)
         self._nodes_used = info['nodes_used']
-        self.depth, self.max_depth = info['depth'], info['max_depth']
+        self.depth, self._max_depth = info['depth'], info['max_depth']
         return decode_state(gs, *st)
 
     def process_results(self, gs, value, pi, add_root_noise, add_root_temp):   # MCTS.pyx:230-289

@@ -148,3 +148,28 @@ def test_slot_snapshot_is_checked_on_import():
         other.import_slot(blob, 0)
     with pytest.raises(_abi.AzgError):
         b.import_slot(blob[:200], 0)
+
+
+def test_max_depth_is_writable_like_the_reference():
+    """Evaluator.py:343 drives a search of its own -- `mcts.max_depth = 0`, then find_leaf / nn / process_results per simulation (:351-353) --
+    and reads mcts.max_depth afterwards (:357,396): the attribute is public and writable in the reference (MCTS.pyx:130)."""
+    from alphazero_general_amd.MCTS import MCTS
+    from alphazero_general_amd.envs.connect4 import Game
+    m, g = MCTS(_args()), Game()
+    step = [0]
+
+    def run(n):
+        for _ in range(n):
+            leaf = m.find_leaf(g)
+            p, v = ol.fake_eval(7, 0, step[0], 7, 3); step[0] += 1
+            m.process_results(leaf, v, p, False, False)
+    run(60)
+    deep = m.max_depth
+    assert deep >= 2
+    om = ol.OMCTS(0, seed=4242, stream=0)
+    a = m.best_action(g)
+    m.update_root(g, a); g.play_action(a)
+    m.max_depth = 0                                               # Evaluator.run resets it before its loop
+    assert m.max_depth == 0
+    run(3)
+    assert 0 < m.max_depth <= deep and m.max_depth == m._engine.tree_info(0)['max_depth']
