@@ -166,7 +166,6 @@ def test_max_depth_is_writable_like_the_reference():
     run(60)
     deep = m.max_depth
     assert deep >= 2
-    om = ol.OMCTS(0, seed=4242, stream=0)
     a = m.best_action(g)
     m.update_root(g, a); g.play_action(a)
     m.max_depth = 0                                               # Evaluator.run resets it before its loop
