@@ -377,10 +377,12 @@ struct TM {
     static AZG_DEV int valid_list(const S &s, int lane, int *act_lds, int (&my_a)[1]) {
         const uint32_t vm = ~(s.b[0] | s.b[1] | s.b[2]) & 0x1FFFFFFu;
         const int k = __popc(vm);
-        // lane i takes the i-th set bit: select by rank
-        int a = -1;
-        if (lane < k) { uint32_t m = vm; for (int i = 0; i < lane; i++) m &= m - 1; a = __ffs(m) - 1; }
-        my_a[0] = a; (void)act_lds;
+        // lane i takes the i-th set bit: the lane of an empty cell pushes its index to the lane of its rank (one ds_permute; the
+        // other lanes push to lane 63, which nobody reads: k <= 25)
+        const bool empty = ((vm >> (lane & 31)) & 1u) != 0 && lane < CELLS;
+        const int rank = __popc(vm & ((1u << (lane & 31)) - 1u));
+        const int a = __builtin_amdgcn_ds_permute((empty ? rank : 63) << 2, lane);
+        my_a[0] = lane < k ? a : -1; (void)act_lds;
         return k;
     }
     template <typename OT> static AZG_DEV void write_obs(const S &s, OT *out, int lane) {

@@ -246,8 +246,14 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
     NodeR cn = hr.root;
     int depth = 0;
     AZG_TSTAMP(ev, slot, lane, 4);
+#ifdef AZG_TREE_TIMING
+    unsigned long long lv_lat = 0, lv_cmp = 0, lv_pub = 0, lv_t0 = 0;
+#endif
     while (cn.n > 0 && cn.e == 0 && depth < ev.maxd) {                       // MCTS.pyx:213
         const int k = cn.nchild, fc = cn.fc;
+#ifdef AZG_TREE_TIMING
+        lv_t0 = __builtin_amdgcn_s_memtime();
+#endif
         if (k == 0 || fc < 0) { if (lane == 0) raise_error(ev, AZG_E_TREE_FULL); break; }
         if (gate(cur)) ctr = ev.tape_ctr[slot];
         NodeR sel; int bi;
@@ -265,8 +271,18 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
             mail_store(&mb->cnt, gen * 1024 + depth + 1, lane);
         } else G::play(st, cn.a);                                            // :216
         AZG_TSTAMP(ev, slot, lane, 12);
+#ifdef AZG_TREE_TIMING
+        if (ev.dbg && lane == 0) {
+            volatile unsigned long long *d = ev.dbg + (size_t)slot * 16;
+            const unsigned long long t10 = d[10], t11 = d[11], t12 = d[12];
+            lv_lat += t10 - lv_t0; lv_cmp += t11 - t10; lv_pub += t12 - t11;
+        }
+#endif
         depth++;
     }
+#ifdef AZG_TREE_TIMING
+    if (ev.dbg && lane == 0) { ev.dbg[(size_t)slot * 16 + 10] = lv_lat; ev.dbg[(size_t)slot * 16 + 11] = lv_cmp; ev.dbg[(size_t)slot * 16 + 12] = lv_pub; }
+#endif
     if (split) mail_store(&mb->fin, gen * 1024 + (cn.n == 0 ? 512 : 0) + depth, lane);
     int expanded = 0;
     int alloc = hr.alloc;
