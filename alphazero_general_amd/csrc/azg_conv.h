@@ -466,6 +466,11 @@ template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_sa
 // SIMD gets a wave of each of the CU's two workgroups, and a wave's load issue hides under the other's MFMAs.
 // KHALF order (7x7 x 64 channels, every tile shape): out = (bias + sum over the first channel half) + (sum over the second half).
 template <int H, int W, int C> constexpr bool tower_khalf_order() { return H == 7 && W == 7 && C == 64; }
+// One-board tiles keep the layers' biases and the blocks' pre-activation affines in LDS (behind everything else): a tile with one wave
+// per SIMD has nothing to cover the L2 round trip of a parameter fetch (~270 cycles, in every layer, and the persistent launches would
+// repeat it in every simulation).  fp32 biases [2 * nblocks + 1][C], then the affine as the fp16 values the epilogue uses, scale
+// [nblocks][C] and shift [nblocks][C]: sized by the launch (dynamic LDS), (12 * nblocks + 8) * C bytes.
+template <int C, int BOARDS> constexpr int tower_param_bytes(int nblocks) { return BOARDS == 1 ? ((2 * nblocks + 1) * C * 4 + 2 * nblocks * C * 2 + C * 4 + 15) / 16 * 16 : 0; }   // (+ one row of slack: the bias prefetch of the last layer)
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch, int KSPLIT = 1>
 __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
@@ -481,6 +486,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     }();
     static_assert(KSPLIT == 1 || (KSPLIT == 2 && KS == 2 && KHALF), "k-split: 64-channel towers in k-half order");
     constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
+    constexpr bool PLDS = BOARDS == 1;                           // the layers' parameters in LDS (see tower_param_bytes)
+    constexpr int PARAM_OFF = XCHG_OFF + (KSPLIT == 2 ? (C / 32 * PSPLIT * 2) * NSUB * 1024 : 0);
     constexpr bool TAPSKIP = PSPLIT == 1 && GEO::CLASSES > 1;   // (a wave's subtile numbers must be compile-time constants)
     constexpr int HW = GEO::HW, ROWS = GEO::ROWS, TILE = GEO::TILE, RS = GEO::RSTRIDE;
     // LDS scratch in the zero rows above board 0 (restored to zero after use): [0, 4096) heads reduction, then 256 B of
@@ -569,6 +576,13 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
         const int rows_here = min(ROWS, P.boards * HW - row0);
         int nsims = 1;
         if constexpr (IS_SEARCH) nsims = sa.sims + (IS_WIDE ? 1 : 0);  // (wide: the last iteration is the last backup, no tower)
+        [[maybe_unused]] const int sc_off = PARAM_OFF + (2 * P.nblocks + 1) * C * 4, sh_off = sc_off + P.nblocks * C * 2;
+        if constexpr (PLDS) {                                    // this tile's model: biases and affines -> LDS (read after the barrier that precedes the layers)
+            float *pb_ = reinterpret_cast<float *>(smem + PARAM_OFF);
+            _Float16 *psc_ = reinterpret_cast<_Float16 *>(smem + sc_off), *psh_ = reinterpret_cast<_Float16 *>(smem + sh_off);
+            for (int c = tid; c < (2 * P.nblocks + 1) * C; c += NT) pb_[c] = P.bias[c];
+            for (int c = tid; c < P.nblocks * C; c += NT) { psc_[c] = (_Float16)P.pre_scale[c]; psh_[c] = (_Float16)P.pre_shift[c]; }
+        }
         [[maybe_unused]] bool lds_live = false;                  // wide search: the games' tree state is in LDS (written back after the loop)
         for (int sim = 0; sim < nsims; sim++) {
         // (wide search mode: an opaque copy of the lane id, new in every simulation.  Nothing a phase derives from it is invariant in
@@ -805,6 +819,12 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
 #define AZG_WGSTAMP(i) do { } while (0)
 #endif
         AZG_WGSTAMP(4);
+        // (one-board tiles: the biases come out of LDS, a layer's are read before the barrier that ends the previous layer)
+        [[maybe_unused]] floatx4 bnext[2];
+        if constexpr (PLDS) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) bnext[m] = *reinterpret_cast<const floatx4 *>(smem + PARAM_OFF + ((2 * cg + m) * 16 + g * 4) * 4);
+        }
         for (int layer = 0; layer <= 2 * P.nblocks; layer++) {
             AZG_STAMP2(0);
             // The co-resident workgroups of a CU take turns at issue priority, layer by layer.  Left alone the arbiter favours
@@ -820,7 +840,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const int c0 = (2 * cg + m) * 16 + g * 4;
-                floatx4 bv = {bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
+                floatx4 bv;
+                if constexpr (PLDS) bv = bnext[m];
+                else bv = (floatx4){bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
                 if constexpr (KSPLIT == 2) { if (kg && layer) bv = (floatx4){0.f, 0.f, 0.f, 0.f}; }   // (the stem is not split: both k groups run it whole)
 #pragma unroll
                 for (int ps = 0; ps < NSUB; ps++) acc[m][ps] = bv;
@@ -834,11 +856,17 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             for (int j = 0; j < 4; j++) sc[j] = sh[j] = zero2;
             auto fetch_affine = [&]() {
                 if (is_s && has_next) {
-                    const float *ps_ = P.pre_scale + (size_t)nb * C + ecol, *pt_ = P.pre_shift + (size_t)nb * C + ecol;
+                    if constexpr (PLDS) {
+                        const char *ps_ = smem + sc_off + (nb * C + ecol) * 2, *pt_ = smem + sh_off + (nb * C + ecol) * 2;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
-                        sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
+                        for (int j = 0; j < 4; j++) { sc[j] = *reinterpret_cast<const half2v *>(ps_ + 4 * j); sh[j] = *reinterpret_cast<const half2v *>(pt_ + 4 * j); }
+                    } else {
+                        const float *ps_ = P.pre_scale + (size_t)nb * C + ecol, *pt_ = P.pre_shift + (size_t)nb * C + ecol;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            sc[j] = (half2v){(_Float16)ps_[2 * j], (_Float16)ps_[2 * j + 1]};
+                            sh[j] = (half2v){(_Float16)pt_[2 * j], (_Float16)pt_[2 * j + 1]};
+                        }
                     }
                 }
             };
@@ -930,6 +958,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                         }
                     }
                 }
+            }
+            if constexpr (PLDS) {                               // (past the last layer this reads the first affine row: in bounds, unused)
+#pragma unroll
+                for (int m = 0; m < 2; m++) bnext[m] = *reinterpret_cast<const floatx4 *>(smem + PARAM_OFF + ((layer + 1) * C + (2 * cg + m) * 16 + g * 4) * 4);
             }
             AZG_STAMP2(3);
             __syncthreads();

@@ -684,7 +684,11 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
         return (size_t)GEO::TILE;
     }();
     // (+ the k-split exchange area: per wave one 1 KB accumulator tile for each of the 2 x NSUB / 2 tiles its partner finishes)
-    constexpr size_t LDS_BYTES = LDS_IMG + (KSPLIT == 2 ? (size_t)(C / 32 * PSPLIT * 2) * ((GEO::NSUB + PSPLIT - 1) / PSPLIT) * 1024 : 0);
+    constexpr size_t LDS_FIXED = LDS_IMG + (KSPLIT == 2 ? (size_t)(C / 32 * PSPLIT * 2) * ((GEO::NSUB + PSPLIT - 1) / PSPLIT) * 1024 : 0);
+    // (+ the layers' biases and affines of one-board tiles, tower_param_bytes: sized by the network's depth)
+    constexpr size_t LDS_MAX = 160 * 1024;
+    const size_t LDS_BYTES = LDS_FIXED + (size_t)tower_param_bytes<C, BOARDS>(P.nblocks);
+    if (LDS_BYTES > LDS_MAX) return fail(AZG_E_INVALID_ARG, "this tower does not fit the LDS of a one-board tile (too many residual blocks)");
     // per (instantiation, device): the pixel -> (subtile, lane) table, a few hundred bytes that live as long as the process
     // (the table is a pure function of the template arguments); first use is serialised
     static int16_t *d_map[16] = {nullptr};
@@ -700,7 +704,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
             int16_t *d = nullptr;
             HIPCHK(hipMalloc((void **)&d, sizeof(map)));
             HIPCHK(hipMemcpy(d, map, sizeof(map), hipMemcpyHostToDevice));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BOARDS == 1 ? LDS_MAX : LDS_FIXED)));
             d_map[dev] = d;
         }
     }

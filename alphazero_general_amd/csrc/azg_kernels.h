@@ -281,7 +281,7 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
         depth++;
     }
 #ifdef AZG_TREE_TIMING
-    if (ev.dbg && lane == 0) { ev.dbg[(size_t)slot * 16 + 10] = lv_lat; ev.dbg[(size_t)slot * 16 + 11] = lv_cmp; ev.dbg[(size_t)slot * 16 + 12] = lv_pub; }
+    if (ev.dbg && lane == 0) { ev.dbg[(size_t)slot * 16 + 10] = lv_lat; ev.dbg[(size_t)slot * 16 + 11] = lv_cmp; ev.dbg[(size_t)slot * 16 + 12] = lv_pub | ((unsigned long long)depth << 48); }
 #endif
     if (split) mail_store(&mb->fin, gen * 1024 + (cn.n == 0 ? 512 : 0) + depth, lane);
     int expanded = 0;

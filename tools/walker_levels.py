@@ -23,8 +23,9 @@ for mv in range(10):
         rows.append(b[ok])
     e.advance(True)
 b = np.concatenate(rows)
+depth = b[:, 12] >> 48; b[:, 12] &= (1 << 48) - 1
 n = len(b)
-print(game, n, 'samples')
+print(game, n, 'samples, mean depth %.2f' % depth.mean())
 print(' descent total      %9.1f' % (b[:, 5] - b[:, 4]).mean())
 print('   block load waits %9.1f' % b[:, 10].mean())
 print('   best_child math  %9.1f' % b[:, 11].mean())
