@@ -470,7 +470,9 @@ template <int H, int W, int C> constexpr bool tower_khalf_order() { return H == 
 // per SIMD has nothing to cover the L2 round trip of a parameter fetch (~270 cycles, in every layer, and the persistent launches would
 // repeat it in every simulation).  fp32 biases [2 * nblocks + 1][C], then the affine as the fp16 values the epilogue uses, scale
 // [nblocks][C] and shift [nblocks][C]: sized by the launch (dynamic LDS), (12 * nblocks + 8) * C bytes.
-template <int C, int BOARDS> constexpr int tower_param_bytes(int nblocks) { return BOARDS == 1 ? ((2 * nblocks + 1) * C * 4 + 2 * nblocks * C * 2 + C * 4 + 15) / 16 * 16 : 0; }   // (+ one row of slack: the bias prefetch of the last layer)
+template <int C, int BOARDS> constexpr int tower_layer_param_bytes(int nblocks) { return ((2 * nblocks + 1) * C * 4 + 2 * nblocks * C * 2 + C * 4 + 15) / 16 * 16; }   // (+ one row of slack: the bias prefetch of the last layer)
+// (+ the 1x1 head convolutions of the factorised heads: C / 32 k-steps x 2 fragments of 64 lanes x 16 bytes, then their 32 biases)
+template <int C, int BOARDS> constexpr int tower_param_bytes(int nblocks) { return BOARDS == 1 ? tower_layer_param_bytes<C, BOARDS>(nblocks) + (C / 32) * 2 * 1024 + 128 : 0; }
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch, int KSPLIT = 1>
 __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
@@ -577,11 +579,17 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
         int nsims = 1;
         if constexpr (IS_SEARCH) nsims = sa.sims + (IS_WIDE ? 1 : 0);  // (wide: the last iteration is the last backup, no tower)
         [[maybe_unused]] const int sc_off = PARAM_OFF + (2 * P.nblocks + 1) * C * 4, sh_off = sc_off + P.nblocks * C * 2;
+        [[maybe_unused]] const int h1_off = PARAM_OFF + tower_layer_param_bytes<C, BOARDS>(P.nblocks);
         if constexpr (PLDS) {                                    // this tile's model: biases and affines -> LDS (read after the barrier that precedes the layers)
             float *pb_ = reinterpret_cast<float *>(smem + PARAM_OFF);
             _Float16 *psc_ = reinterpret_cast<_Float16 *>(smem + sc_off), *psh_ = reinterpret_cast<_Float16 *>(smem + sh_off);
             for (int c = tid; c < (2 * P.nblocks + 1) * C; c += NT) pb_[c] = P.bias[c];
             for (int c = tid; c < P.nblocks * C; c += NT) { psc_[c] = (_Float16)P.pre_scale[c]; psh_[c] = (_Float16)P.pre_shift[c]; }
+            if (P.head_w == nullptr && P.head1_w != nullptr) {
+                uint4 *h1_ = reinterpret_cast<uint4 *>(smem + h1_off);
+                for (int c = tid; c < KS * 2 * 64; c += NT) h1_[c] = reinterpret_cast<const uint4 *>(P.head1_w)[c];
+                if (tid < 32) reinterpret_cast<float *>(smem + h1_off + KS * 2 * 1024)[tid] = P.head1_b[tid];
+            }
         }
         [[maybe_unused]] bool lds_live = false;                  // wide search: the games' tree state is in LDS (written back after the loop)
         for (int sim = 0; sim < nsims; sim++) {
@@ -982,13 +990,19 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
                     const int c0 = m * 16 + g * 4;
-                    const floatx4 bv = {P.head1_b[c0], P.head1_b[c0 + 1], P.head1_b[c0 + 2], P.head1_b[c0 + 3]};
+                    floatx4 bv;
+                    if constexpr (PLDS) bv = *reinterpret_cast<const floatx4 *>(smem + h1_off + KS * 2 * 1024 + c0 * 4 + opaque);
+                    else bv = (floatx4){P.head1_b[c0], P.head1_b[c0 + 1], P.head1_b[c0 + 2], P.head1_b[c0 + 3]};
 #pragma unroll
                     for (int ps = 0; ps < NOWN; ps++) hacc[m][ps] = bv;
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const half8 a0 = hw1[(size_t)(ks * 2) * 64], a1 = hw1[(size_t)(ks * 2 + 1) * 64];
+                    half8 a0, a1;
+                    if constexpr (PLDS) {
+                        a0 = *reinterpret_cast<const half8 *>(smem + h1_off + ((ks * 2) * 64 + lane) * 16 + opaque);
+                        a1 = *reinterpret_cast<const half8 *>(smem + h1_off + ((ks * 2 + 1) * 64 + lane) * 16 + opaque);
+                    } else { a0 = hw1[(size_t)(ks * 2) * 64]; a1 = hw1[(size_t)(ks * 2 + 1) * 64]; }
 #pragma unroll
                     for (int ps = 0; ps < NOWN; ps++) {
                         const half8 b = *reinterpret_cast<const half8 *>(img + lbo[ps] + (GEO::BIAS + ks * 64));
