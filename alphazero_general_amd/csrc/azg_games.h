@@ -187,6 +187,13 @@ struct BR {
         const int newdst = (dstv == 4 || dstv == 5) ? piece + dstv : piece;                  // add_piece :293-309
         if (lane == src) s.cell = newsrc;
         if (lane == dst) s.cell = newdst;
+        // every capture below starts from a square next to the moved piece that holds an enemy or -- two-sided king capture fires
+        // for any mover (Q20) -- the king: most moves have none, and are done here
+        {
+            const bool black = newdst == 2;                                                  // (the mover; a king on the throne / an escape counts as an attacker for black)
+            const uint64_t relevant = __ballot(lane < CELLS && (black ? is_att(s.cell) : (s.cell == 2 || s.cell == 3)));
+            if ((nbr(1ULL << dst) & relevant) == 0) { s.turns += 1; s.player ^= 1; return; }
+        }
         const int dx4[4] = {0, 1, 0, -1}, dy4[4] = {1, 0, -1, 0};                            // DIRECTIONS :46
         const int mx = dst % 7, my = dst / 7;
         // ---- custodian capture around the moved piece ----
@@ -257,7 +264,7 @@ struct BR {
     // Game.valid_moves (fastafl.pyx:171-178) + Board.legal_moves (cengine.pyx:109-132): ascending action list in LDS.
     // Branch-free per lane: the row of the passable mask and (through the transposed board) its column are 7-bit lines, the
     // reachable runs come from count-trailing-ones / count-leading-zeros, the move types from two shifts; the list offsets
-    // from twelve ballots (v_mbcnt) instead of a wave scan.
+    // from a DPP row scan of the per-lane move counts.
     static AZG_DEV int valid_list(const S &s, int lane, int *act_lds, int (&my_a)[2]) {
         const int team = 2 - (s.turns & 1);                                                  // Board.to_play :330-331
         const bool mine = lane < CELLS && (team == 1 ? is_att(s.cell) : s.cell == 2);
@@ -273,11 +280,20 @@ struct BR {
         // move_type (fastafl.pyx:66-79): vertical ny -> ny or ny - 1, horizontal nx -> 6 + nx or 6 + nx - 1
         const unsigned mvy = (ry & ((1u << y) - 1u)) | ((ry >> (y + 1)) << y), mvx = (rx & ((1u << x) - 1u)) | ((rx >> (x + 1)) << x);
         const unsigned mv = mine ? (mvy | (mvx << 6)) : 0u;                                  // bit = move_type (0..11)
-        int off = 0, k = 0;
+        // list offset of the lane = moves of the lanes below it: an inclusive scan of the per-lane counts inside each row of 16
+        // (four DPP row shifts) + the totals of the rows below; then one predicated store per move type instead of a per-lane loop
+        const int cnt = __popc(mv);
+        int inc = cnt;
+        inc += dpp_i<0x111>(inc); inc += dpp_i<0x112>(inc); inc += dpp_i<0x114>(inc); inc += dpp_i<0x118>(inc);   // row_shr:1, 2, 4, 8
+        const int r0 = rl(inc, 15), r1 = rl(inc, 31), r2 = rl(inc, 47), r3 = rl(inc, 63);
+        const int lrow = lane >> 4;
+        const int off = inc - cnt + (lrow == 0 ? 0 : lrow == 1 ? r0 : lrow == 2 ? r0 + r1 : r0 + r1 + r2);
+        const int k = r0 + r1 + r2 + r3;
 #pragma unroll
-        for (int b = 0; b < 12; b++) { const uint64_t bal = __ballot((mv >> b) & 1u); off += lanes_below(bal); k += __popcll(bal); }
-        int j = 0;
-        for (unsigned m = mv; m; m &= m - 1) { if (off + j < MAXK) act_lds[off + j] = 12 * lane + (__ffs(m) - 1); j++; }
+        for (int b = 0; b < 12; b++) {
+            const int pos = off + __popc(mv & ((1u << b) - 1u));
+            if (((mv >> b) & 1u) && pos < MAXK) act_lds[pos] = 12 * lane + b;
+        }
         wave_sync();
         my_a[0] = lane < k ? act_lds[lane] : -1;
         my_a[1] = 64 + lane < k ? act_lds[64 + lane] : -1;
