@@ -271,3 +271,56 @@ def test_mfma_tower_connect4_default_net_32ch():
         check_probs('c4_32x4_%d' % n, p, torch.exp(lp[:n]), v, torch.exp(lv[:n]))
         outs.append((p[:32].clone(), v[:32].clone()))
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('game,base,depth,boards', [('connect4', 'CONNECT4_NET_ARGS', 1, 200), ('connect4', 'CONNECT4_NET_ARGS', 3, 64),
+                                                    ('brandubh', 'BRANDUBH_NET_ARGS', 1, 300), ('brandubh', 'BRANDUBH_NET_ARGS', 6, 300)])
+def test_one_board_tiles_at_other_depths(game, base, depth, boards):
+    """one-board tiles keep every layer's biases and affines in an LDS area the LAUNCH sizes from the network's depth
+    (csrc/azg_conv.h tower_param_bytes): depths other than the BASELINE networks', small batches (one board per workgroup),
+    against the fp32 reference."""
+    import importlib
+    import torch
+    from alphazero_general_amd import nnet as N
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    from alphazero_general_amd.utils import dotdict
+    args = dotdict(dict(getattr(N, base))); args.depth = depth
+    torch.manual_seed(100 + depth)
+    net = N.NNetWrapper(Game, args, device='cuda:0', backend='hip')
+    _randomize(net.nnet.cpu(), torch, seed=depth); net.nnet.to('cuda:0'); net.refresh()
+    assert net._hip is not None
+    rng = np.random.RandomState(depth)
+    obs = []
+    for b in range(boards):
+        g = Game()
+        for _ in range(rng.randint(0, 25)):
+            if g.win_state().any():
+                break
+            g.play_action(int(rng.choice(np.flatnonzero(g.valid_moves()))))
+        obs.append(g.observation())
+    x = torch.from_numpy(np.array(obs, np.float32))
+    with torch.no_grad():
+        lp, lv = net.nnet(x.to('cuda:0'))
+    p, v = net.process(x)
+    check_probs('%s_depth%d_%d' % (game, depth, boards), p, torch.exp(lp), v, torch.exp(lv))
+
+
+def test_one_board_tile_refuses_a_tower_that_does_not_fit_lds():
+    """(12 * nblocks + 8) * C bytes of parameters beside the image: a 128-channel tower of 110 blocks cannot be a one-board tile --
+    the launch must say so (AZG_E_INVALID_ARG), not overrun LDS."""
+    import ctypes as C
+    import torch
+    from alphazero_general_amd import _abi
+    L = _abi.lib()
+    nb, ch, B = 110, 128, 8
+    dev = 'cuda:0'
+    need = int(L.azg_tower_weights_size(ch, nb))
+    w = torch.zeros(need, dtype=torch.float16, device=dev)
+    bias = torch.zeros((2 * nb + 1) * ch, dtype=torch.float32, device=dev)
+    sc = torch.ones(nb * ch, dtype=torch.float32, device=dev); sh = torch.zeros(nb * ch, dtype=torch.float32, device=dev)
+    x = torch.zeros((B, 42, 8), dtype=torch.float16, device=dev)
+    y = torch.zeros((B, 42, ch), dtype=torch.float16, device=dev)
+    rc = L.azg_resnet_tower_f16(C.c_void_p(torch.cuda.current_stream().cuda_stream), 0, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(y.data_ptr()), B, nb, ch)
+    torch.cuda.synchronize()
+    assert rc == -1, (rc, L.azg_last_error())                  # AZG_E_INVALID_ARG
