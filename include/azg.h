@@ -244,7 +244,9 @@ int  azg_last_actions_dev(azg_engine *e, int32_t **actions_dev);
  * weight prefetch ring runs past the last layer (the k-split tile: up to 16 k-steps); azg_tower_weights_size(C, nblocks) is the
  * number of halves every tower / search launch may read from w_packed; bias: f32 [1 + 2*nblocks][C] (stem, then b1, b2 per block); pre_scale/pre_shift: f32 [nblocks][C];
  * y: [boards*H*W, C] fp16 = the final residual stream (input of the collapsed heads GEMM).
- * The kernel evaluates 1, 2 or 4 boards per workgroup tile, chosen by `boards` (small batches: small tiles, more workgroups). */
+ * The kernel evaluates 1, 2 or 4 boards per workgroup tile, chosen by `boards` (small batches: small tiles, more workgroups).
+ * One-board tiles keep the layers' biases and affines in LDS ((12 * nblocks + 8) * channels bytes beside the image): a tower too deep
+ * for that (about 90 blocks at 128 channels) is refused with AZG_E_INVALID_ARG at small batch sizes. */
 #define AZG_TOWER_W_SLACK_KSTEPS 18
 int64_t azg_tower_weights_size(int channels, int nblocks);      /* host only, no device needed */
 int  azg_resnet_tower_f16(void *stream, int game, const void *x_dev, const void *w_packed_dev, const float *bias_dev,
