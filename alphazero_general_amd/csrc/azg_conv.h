@@ -498,7 +498,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     static_assert(!IS_SEARCH || IS_WIDE || SCRATCH_PV + 1024 <= (GEO::LEAD + GEO::PW) * RS, "scratch must stay inside the pad rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15, lane_k = lane;
+    // (one-board tiles, one or two waves per SIMD and issue bound: the wave number in an SGPR -- everything derived from it, the cout /
+    //  pixel / k group and the wave's slice of the weight stream, is then scalar: fewer VALU instructions and registers around the MFMAs)
+    const int tid = threadIdx.x, lane = tid & 63, wave = BOARDS == 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, g = lane >> 4, i16 = lane & 15, lane_k = lane;
     const int cg = wave % (C / 32), ph = (wave / (C / 32)) % PSPLIT, kg = wave / ((C / 32) * PSPLIT);
     int ntiles = (Pin.boards + BOARDS - 1) / BOARDS;
     if (Pin.rows_per_model) {
