@@ -99,6 +99,7 @@ SYMBOLS = {
     'azg_resnet_tower_features_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
     'azg_policy_value_heads_fact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'azg_search_wide_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
+    'azg_search_wide_exact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_profile_net_enable': (_i, [_i]),
     'azg_profile_net_read': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'azg_profile_enable': (_i, [_vp, _i]),

@@ -434,30 +434,102 @@ template <class G> struct SearchArgs { View ev; int sims; using Game = G; static
 // b, wave BOARDS + b prepares its priors and shuffle (the two-wave scheme of k_backup_select2), the head convolutions leave their
 // features in LDS and the next tree phase computes the logits it needs from them (azg_kernels.h, sparse heads: the value
 // logits by the walker, the policy logits of the leaf's valid actions by the helper) -- the code of the launch-per-phase path.
-template <class G, int MINB = 1> struct SearchWide { View ev; int sims; HeadRows hd; using Game = G; static constexpr bool WIDE = true; static constexpr int MIN_BLOCKS = MINB; };
+// EXACT_: the launch computes ALL A + P + 1 logits of its boards from the head features (hf: the collapsed Linear chains in
+// k_heads_fact's fragment order, heads_full_lds below) -- what NNetWrapper.process returns (NNetWrapper.py:225-232) -- and the tree
+// phase takes softmax over all A, masks and renormalises like MCTS.pyx:239-245: bit-identical to the launch-per-phase form
+// k_tower2 -> k_heads_fact -> k_backup_select2<IN_LOGITS>.  Otherwise the sparse heads (hd: one row per output, azg_kernels.h).
+template <class G, int MINB = 1, bool EXACT_ = false> struct SearchWide {
+    View ev; int sims; HeadRows hd; HeadsFact hf;
+    using Game = G; static constexpr bool WIDE = true; static constexpr int MIN_BLOCKS = MINB; static constexpr bool EXACT = EXACT_;
+};
 
 // per-game LDS scratch of the wide search mode (behind the image)
-template <class G, int HW> struct WideScratch {
+// COMPACT (solo tree phase, several games per workgroup: LDS is what limits the games a CU holds): the softmax output and the masked
+// policy of np.sum take turns in the logits' place -- every stage reads its input into registers before the next one writes (one
+// wavefront, LDS accesses of a wave complete in order), the value logits sit behind the A policy slots and are never overwritten
+template <class G, int HW, bool COMPACT = false> struct WideScratch {
     static constexpr int A = G::A, NV = G::P + 1, OPAD = (A + NV + 15) / 16 * 16, FK = (HW * 16 + 31) / 32 * 32;
-    static constexpr int LG = 0, PI = LG + OPAD * 4, M = PI + A * 4, SCR = M + (A < 8 ? 8 : A) * 4, ACT = SCR + 256,
-                         LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + 512, FEAT = FLAGS + 16,
+    static_assert(!COMPACT || A >= 8, "compact scratch: the masked policy needs A slots");
+    // (COMPACT drops what only the multi-wavefront tree phase uses -- the shuffle masks, the walk's mailbox -- and leaves the path in HBM:
+    //  its reads and writes are one coalesced access per simulation each, off the dependent chain)
+    static constexpr int LG = 0, PI = COMPACT ? LG : LG + OPAD * 4, M = COMPACT ? LG : PI + A * 4, SCR = COMPACT ? LG + OPAD * 4 : M + (A < 8 ? 8 : A) * 4, ACT = SCR + 256,
+                         LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + (COMPACT ? 0 : 512), FEAT = FLAGS + 16,
                          // the game's tree state for the length of the launch (the workgroup owns the game): header, last path, tape
                          // counter + the two per-slot tallies, root state -- read and written in LDS, copied from / to HBM once
-                         HDR = (FEAT + 2 * FK * 2 + 63) / 64 * 64, PATH = HDR + 64, MAXD = G::MAX_TURNS + 2, CTR = PATH + MAXD * 16,
+                         HDR = (FEAT + 2 * FK * 2 + 63) / 64 * 64, PATH = HDR + 64, MAXD = G::MAX_TURNS + 2, CTR = PATH + (COMPACT ? 0 : MAXD * 16),
                          STATE = CTR + 32, MAIL = (STATE + (int)sizeof(azg_state) + 15) / 16 * 16,                 // (WalkMail: azg_kernels.h)
-                         BYTES = (MAIL + (int)sizeof(WalkMail) + 15) / 16 * 16;
+                         BYTES = (MAIL + (COMPACT ? 0 : (int)sizeof(WalkMail)) + 15) / 16 * 16;
 };
 // all of the wide search mode's LDS behind the image: the per-game scratch, an error word, and the value head's P + 1 weight rows
-// + biases (the same for every game and simulation: fetched once per launch instead of once per simulation by every walker)
+// + biases (the same for every game and simulation: fetched once per launch instead of once per simulation by every walker;
+// COMPACT: they stay in global memory)
 template <class G> struct WideMailFits { static_assert(G::MAX_TURNS + 2 <= 128, "WalkMail::act holds one action per level of a find_leaf path"); };
-template <class G, int HW, int BOARDS> struct WideLds : WideMailFits<G> {
-    static constexpr int NV = G::P + 1, FK = WideScratch<G, HW>::FK;
-    static constexpr int ERR = BOARDS * WideScratch<G, HW>::BYTES, VROWS = (ERR + 16 + 15) / 16 * 16, VBIAS = VROWS + NV * FK * 2,
-                         BYTES = (VBIAS + NV * 4 + 15) / 16 * 16;
+template <class G, int HW, int BOARDS, bool COMPACT = false> struct WideLds : WideMailFits<G> {
+    static constexpr int NV = G::P + 1, FK = WideScratch<G, HW, COMPACT>::FK;
+    static constexpr int ERR = BOARDS * WideScratch<G, HW, COMPACT>::BYTES, VROWS = (ERR + 16 + 15) / 16 * 16, VBIAS = VROWS + (COMPACT ? 0 : NV * FK * 2),
+                         BYTES = (VBIAS + (COMPACT ? 0 : NV * 4) + 15) / 16 * 16;
 };
+
+// The full-width heads of a tile's boards inside the persistent launch (EXACT): logits[board][o] for all A policy outputs and the
+// P + 1 value outputs, from the boards' head features in LDS.  Output subtile s (16 outputs; s == OSP: the value outputs over the
+// value half) is ONE wavefront's job: A operand = the boards' features (row m = board m, rows past BOARDS zero), B operand = the
+// subtile's weight fragments streamed from L2 ([k-step][subtile][64 lanes], the layout of k_heads_fact), FOUR accumulation chains,
+// one per contiguous quarter of the k-steps, summed as (q0 + q1) + (q2 + q3) + bias -- exactly k_heads_fact's arithmetic for a board
+// (an MFMA row depends on its own A row only), so the logits are bit-identical to NNetWrapper.process's.  The chains are issued
+// interleaved (independent accumulators), the fragments of the wave's NEXT subtile are requested as the current ones are consumed.
+// The job is the L2 -> L1 stream of the whole matrix (brandubh 0.94 MB per workgroup and simulation), shared by the tile's boards.
+template <class G, int HW, int BOARDS, int NW, bool COMPACT>
+__device__ __forceinline__ void heads_full_lds(char *scr0, const HeadsFact &hf, int wave, int lane) {
+    using WS = WideScratch<G, HW, COMPACT>;
+    constexpr int A = G::A, NV = G::P + 1, FK = WS::FK, KS = FK / 32, KQ = (KS + HEADF_Q - 1) / HEADF_Q, OSP = (A + 15) / 16;
+    static_assert(BOARDS <= 4 && HEADF_Q == 4, "the tile's boards are D rows 0..3 (lane group 0); four K quarters");
+    const int g = lane >> 4, i16 = lane & 15;
+    const bool live = i16 < BOARDS;
+    const char *fb = scr0 + (live ? i16 : 0) * WS::BYTES + WS::FEAT + g * 16;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto frags = [&](int s_) { return s_ == OSP ? hf.wv + lane : hf.wp + (size_t)s_ * 64 + lane; };
+    half8 b[KS];
+    if (wave <= OSP) {
+        const half8 *w0 = frags(wave); const size_t st0 = wave == OSP ? (size_t)64 : (size_t)OSP * 64;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) b[ks] = w0[(size_t)ks * st0];
+    }
+    for (int s_ = wave; s_ <= OSP; s_ += NW) {
+        const bool is_v = s_ == OSP;
+        const int sn = s_ + NW <= OSP ? s_ + NW : s_;                       // (past the end: re-read this subtile's fragments, unused)
+        const half8 *wn = frags(sn); const size_t stn = sn == OSP ? (size_t)64 : (size_t)OSP * 64;
+        const char *f = fb + (is_v ? FK * 2 : 0);
+        floatx4 acc[HEADF_Q];
+#pragma unroll
+        for (int q = 0; q < HEADF_Q; q++) acc[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KQ; j++)
+#pragma unroll
+            for (int q = 0; q < HEADF_Q; q++) {
+                const int ks = q * KQ + j;
+                if (ks < KS && ks < (q + 1) * KQ) {
+                    half8 a = *reinterpret_cast<const half8 *>(f + ks * 64);
+                    if (!live) a = zero8;
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[ks], acc[q], 0, 0, 0);
+                    b[ks] = wn[(size_t)ks * stn];
+                }
+            }
+        const floatx4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const int out = is_v ? A + i16 : s_ * 16 + i16, lim = is_v ? A + NV : A;
+        if (g == 0 && out < lim) {                                          // D[m = board 4 g + r][n = output i16]
+            const float bo = hf.bias[out];
+#pragma unroll
+            for (int r = 0; r < BOARDS; r++) *reinterpret_cast<float *>(scr0 + r * WS::BYTES + WS::LG + out * 4) = sum[r] + bo;
+        }
+    }
+}
 
 // (the wide search mode keeps one workgroup per CU busy for a whole move and mixes three phases with different register needs:
 //  one wave per SIMD, the whole register file)
+// SOLO tree phase (fewer than two wavefronts per game: several games per workgroup at large batches): wave b does ALL of game b's
+// process_results and find_leaf itself -- policy logits, softmax, priors, value, path, walk with the rules, shuffle ranks --, the
+// one-wave functions of k_select / k_backup in the order of k_backup_select2; waves past BOARDS only take part in the tower
+template <int C, int PSPLIT, int KSPLIT, int BOARDS> constexpr bool wide_solo() { return (C / 32) * PSPLIT * KSPLIT < 2 * BOARDS; }
 template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else { if constexpr (SEARCH::WIDE) return SEARCH::MIN_BLOCKS; else return 2; } }
 
 // KSPLIT = 2 (64-channel towers of one board): the two 32-channel k-steps of every tap go to two wave groups -- wave = (cout group
@@ -479,12 +551,14 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     constexpr bool IS_WIDE = []() { if constexpr (IS_SEARCH) return SEARCH::WIDE; else return false; }();
     static_assert(!IS_SEARCH || IS_WIDE || (PSPLIT == 1 && C == 128 && BOARDS == C / 32), "search mode: one wave per game, fused heads");
-    static_assert(!IS_WIDE || (C / 32) * PSPLIT >= 2 * BOARDS, "wide search mode: a walker and a helper wavefront per game");
+    static_assert(!IS_WIDE || (C / 32) * PSPLIT * KSPLIT >= BOARDS, "wide search mode: at least one wavefront per game");
+    constexpr bool SOLO = IS_WIDE && wide_solo<C, PSPLIT, KSPLIT, BOARDS>();
+    constexpr bool EXACT = []() { if constexpr (IS_WIDE) return SEARCH::EXACT; else return false; }();
     TowerParams P = Pin;
     constexpr int NT = C * 2 * PSPLIT * KSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
     constexpr bool KHALF = tower_khalf_order<H, W, C>();
     constexpr int XCHG_OFF = []() {                              // the k-split exchange area: behind the image and the wide search mode's scratch
-        if constexpr (IS_WIDE) return GEO::TILE + WideLds<typename SEARCH::Game, GEO::HW, BOARDS>::BYTES; else return GEO::TILE;
+        if constexpr (IS_WIDE) return GEO::TILE + WideLds<typename SEARCH::Game, GEO::HW, BOARDS, wide_solo<C, PSPLIT, KSPLIT, BOARDS>()>::BYTES; else return GEO::TILE;
     }();
     static_assert(KSPLIT == 1 || (KSPLIT == 2 && KS == 2 && KHALF), "k-split: 64-channel towers in k-half order");
     constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
@@ -500,7 +574,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     char *img = smem;
     // (one-board tiles, one or two waves per SIMD and issue bound: the wave number in an SGPR -- everything derived from it, the cout /
     //  pixel / k group and the wave's slice of the weight stream, is then scalar: fewer VALU instructions and registers around the MFMAs)
-    const int tid = threadIdx.x, lane = tid & 63, wave = BOARDS == 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, g = lane >> 4, i16 = lane & 15, lane_k = lane;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (BOARDS == 1 || IS_WIDE) ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, g = lane >> 4, i16 = lane & 15, lane_k = lane;
     const int cg = wave % (C / 32), ph = (wave / (C / 32)) % PSPLIT, kg = wave / ((C / 32) * PSPLIT);
     int ntiles = (Pin.boards + BOARDS - 1) / BOARDS;
     if (Pin.rows_per_model) {
@@ -509,12 +583,14 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     }
     for (int c = tid; c < TILE / 16; c += NT) reinterpret_cast<uint4 *>(smem)[c] = make_uint4(0, 0, 0, 0);   // pads stay 0
     if constexpr (IS_WIDE) {                                     // (the feature rows' padding must read as zero)
-        using WL = WideLds<typename SEARCH::Game, HW, BOARDS>;
+        using WL = WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>;
         for (int c = tid; c < WL::VROWS / 16; c += NT) reinterpret_cast<uint4 *>(smem + TILE)[c] = make_uint4(0, 0, 0, 0);
         constexpr int A_ = SEARCH::Game::A;
-        const uint4 *vsrc = reinterpret_cast<const uint4 *>(sa.hd.rows + (size_t)A_ * sa.hd.fk);      // rows A .. A + P of the head matrix
-        for (int c = tid; c < WL::NV * WL::FK * 2 / 16; c += NT) reinterpret_cast<uint4 *>(smem + TILE + WL::VROWS)[c] = vsrc[c];
-        if (tid < WL::NV) reinterpret_cast<float *>(smem + TILE + WL::VBIAS)[tid] = sa.hd.bias[A_ + tid];
+        if constexpr (!SOLO && !EXACT) {
+            const uint4 *vsrc = reinterpret_cast<const uint4 *>(sa.hd.rows + (size_t)A_ * sa.hd.fk);      // rows A .. A + P of the head matrix
+            for (int c = tid; c < WL::NV * WL::FK * 2 / 16; c += NT) reinterpret_cast<uint4 *>(smem + TILE + WL::VROWS)[c] = vsrc[c];
+            if (tid < WL::NV) reinterpret_cast<float *>(smem + TILE + WL::VBIAS)[tid] = sa.hd.bias[A_ + tid];
+        }
     }
     unsigned lb[NSUB];
     unsigned livemask = 0;
@@ -613,14 +689,14 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             // workgroup's games, two wavefronts per game exactly like k_backup_select2 (walker + helper, hand-offs through LDS
             // generation flags); the logits of simulation sim - 1 are in LDS, the leaf planes go straight into the image
             using G = typename SEARCH::Game;
-            using WS = WideScratch<G, HW>;
+            using WS = WideScratch<G, HW, SOLO>;
             static_assert(G::CELLS == HW, "game / tower geometry mismatch");
             constexpr int A = G::A, NV = G::P + 1;
             const int bd = wave % BOARDS, role = wave / BOARDS;      // 0: walks the tree of game bd, 1: its helper, else idle
             char *ws = smem + TILE + bd * WS::BYTES;
             float *lg = reinterpret_cast<float *>(ws + WS::LG);
             int *flags = reinterpret_cast<int *>(ws + WS::FLAGS);
-            int *errw = reinterpret_cast<int *>(smem + TILE + WideLds<G, HW, BOARDS>::ERR);
+            int *errw = reinterpret_cast<int *>(smem + TILE + WideLds<G, HW, BOARDS, SOLO>::ERR);
             if (sim == 0 && tid < 2 * BOARDS) reinterpret_cast<int *>(smem + TILE + (tid >> 1) * WS::BYTES + WS::FLAGS)[tid & 1] = 0;
             if ((sim & 15) == 0) {                                   // sticky device error: stop, uniformly over the workgroup
                 if (tid == 0) *errw = sa.ev.gcount[GC_ERROR];
@@ -635,7 +711,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             constexpr bool MASK_WAVE = NT / 64 >= 3 * BOARDS;
             // (and the fourth one runs the game rules one level behind the walk: WalkMail, azg_kernels.h)
             constexpr bool RULES_WAVE = NT / 64 >= 4 * BOARDS;
-            const bool livegame = slot < sa.ev.B && role < (RULES_WAVE ? 4 : MASK_WAVE ? 3 : 2);
+            const bool livegame = slot < sa.ev.B && role < (SOLO ? 1 : RULES_WAVE ? 4 : MASK_WAVE ? 3 : 2);
             [[maybe_unused]] WalkMail *mail = reinterpret_cast<WalkMail *>(ws + WS::MAIL);
             const int tree = slot;                               // (self-play engines only: one tree per slot)
             // The tree functions reach the header, the path, the tape counter, the tallies and the root state through the View's
@@ -644,7 +720,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             // of the walker's 26 k cycles) and the tallies' read-modify-writes never wait for HBM.  Node blocks stay in HBM.
             View evl = sa.ev;
             evl.hdr = reinterpret_cast<TreeHdr *>(ws + WS::HDR) - tree;
-            evl.path = reinterpret_cast<PathEnt *>(ws + WS::PATH) - (size_t)tree * sa.ev.maxd;
+            if constexpr (!SOLO) evl.path = reinterpret_cast<PathEnt *>(ws + WS::PATH) - (size_t)tree * sa.ev.maxd;
             evl.tape_ctr = reinterpret_cast<uint64_t *>(ws + WS::CTR) - slot;
             evl.slot_sims = reinterpret_cast<int64_t *>(ws + WS::CTR + 8) - slot;
             evl.slot_exp = reinterpret_cast<int64_t *>(ws + WS::CTR + 16) - slot;
@@ -684,15 +760,32 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                     select_tree<G>(evl, slot, tree, hr, st, ctr0, lane, act, sink, NoGate{}, NoRanks{});
                 } else {
                     Node *nodes = tree_nodes(sa.ev, tree, hr.base);
+                    if constexpr (SOLO) {                            // the helper's part first: the walk may enter the previous leaf
+                        if (has_policy) {
+                            float *pi = reinterpret_cast<float *>(ws + WS::PI);
+                            if constexpr (!EXACT) {                  // (EXACT: heads_full_lds left all A logits there)
+                                leaf_policy_logits<G, false>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
+                                wave_sync();
+                            }
+                            policy_softmax_row<A>(lg, lane, A, pi);
+                            wave_sync();
+                            backup_policy<G>(evl, slot, hr, nodes, pi, reinterpret_cast<float *>(ws + WS::M), reinterpret_cast<float *>(ws + WS::SCR), lane);
+                            wave_sync();
+                        }
+                    }
                     float val[NV];
                     float pv = 0.f;
                     if (!hr.leaf_e) {                                // (a terminal leaf backs its win state up, not the network)
-                        using WL = WideLds<G, HW, BOARDS>;
+                        using WL = WideLds<G, HW, BOARDS, SOLO>;
                         HeadRows hv = sa.hd;                         // the value rows and biases out of LDS (offset so that row A + r lands on them)
-                        hv.rows = reinterpret_cast<const _Float16 *>(smem + TILE + WL::VROWS) - (size_t)A * sa.hd.fk;
-                        hv.bias = reinterpret_cast<const float *>(smem + TILE + WL::VBIAS) - A;
-                        leaf_value_logits<G>(hv, reinterpret_cast<const _Float16 *>(ws + WS::FEAT) + sa.hd.fk, lg + A, lane);
-                        wave_sync();
+                        if constexpr (!SOLO) {
+                            hv.rows = reinterpret_cast<const _Float16 *>(smem + TILE + WL::VROWS) - (size_t)A * sa.hd.fk;
+                            hv.bias = reinterpret_cast<const float *>(smem + TILE + WL::VBIAS) - A;
+                        }
+                        if constexpr (!EXACT) {
+                            leaf_value_logits<G>(hv, reinterpret_cast<const _Float16 *>(ws + WS::FEAT) + sa.hd.fk, lg + A, lane);
+                            wave_sync();
+                        }
                         pv = value_softmax(lg + A, lane, NV);
                     }
 #pragma unroll
@@ -705,6 +798,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                         wave_sync();
                         bool waited = false;
                         const unsigned long long *less = reinterpret_cast<const unsigned long long *>(ws + WS::LESS);
+                        if constexpr (SOLO) {                        // (the root noise of the backup above drew one tape number)
+                            select_tree<G>(evl, slot, tree, hr, st, ctr0 + (root_noise ? 1 : 0), lane, act, sink, NoGate{}, NoRanks{});
+                        } else
                         select_tree<G>(evl, slot, tree, hr, st, ctr0, lane, act, sink, [&](int node) {
                             if (waited || node != prev_leaf) return false;
                             AZG_TSTAMP(evl, slot, lane, 9);
@@ -744,8 +840,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 if (has_policy) {
                     Node *nodes = tree_nodes(sa.ev, tree, hr.base);
                     float *pi = reinterpret_cast<float *>(ws + WS::PI);
-                    leaf_policy_logits<G, tower_min_blocks<SEARCH>() == 1>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
-                    wave_sync();
+                    if constexpr (!EXACT) {
+                        leaf_policy_logits<G, tower_min_blocks<SEARCH>() == 1>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
+                        wave_sync();
+                    }
                     AZG_HSTAMP(3);
                     policy_softmax_row<A>(lg, lane, A, pi);
                     wave_sync();
@@ -983,7 +1081,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             // first stage of the factorised heads: 32 head channels per pixel, centre tap only; the waves of cout group 0
             // compute them for their own pixel subtiles straight out of the image (the final stream)
             [[maybe_unused]] _Float16 *feat_lds = nullptr;       // wide search mode: the features stay in LDS
-            if constexpr (IS_WIDE) feat_lds = reinterpret_cast<_Float16 *>(smem + TILE + WideScratch<typename SEARCH::Game, HW>::FEAT);
+            if constexpr (IS_WIDE) feat_lds = reinterpret_cast<_Float16 *>(smem + TILE + WideScratch<typename SEARCH::Game, HW, SOLO>::FEAT);
             if (cg == 0) {
                 int opaque = 0;
                 asm volatile("" : "+s"(opaque));                 // (keeps these loop invariants from being hoisted across the layers)
@@ -1021,7 +1119,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                         const int bd = p / HW, pos = p - bd * HW;
                         _Float16 *dst = fg + (size_t)(tile * BOARDS + bd) * 2 * P.feat_k + pos * 16 + g * 4;
                         if constexpr (IS_WIDE)
-                            dst = reinterpret_cast<_Float16 *>(reinterpret_cast<char *>(feat_lds) + bd * WideScratch<typename SEARCH::Game, HW>::BYTES) + pos * 16 + g * 4;
+                            dst = reinterpret_cast<_Float16 *>(reinterpret_cast<char *>(feat_lds) + bd * WideScratch<typename SEARCH::Game, HW, SOLO>::BYTES) + pos * 16 + g * 4;
 #pragma unroll
                         for (int m = 0; m < 2; m++) {
                             const half4 h = {(_Float16)hacc[m][ps][0], (_Float16)hacc[m][ps][1], (_Float16)hacc[m][ps][2], (_Float16)hacc[m][ps][3]};
@@ -1034,6 +1132,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 // (second stage: the next tree phase turns the features into the logits it needs -- sparse heads, azg_kernels.h)
                 __syncthreads();                                 // the features of every board are in LDS
                 AZG_WPHASE(3);
+                if constexpr (EXACT) heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, sa.hf, wave, lane);
                 AZG_WPHASE(4);
 #ifdef AZG_TOWER_TIMING
                 if (P.dbg && tid == 0 && blockIdx.x < 512 && sim >= 8)      // tree (incl. the sparse heads), tower, head conv (cycles, summed over simulations)
@@ -1143,7 +1242,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
         if constexpr (IS_WIDE) {
             // LDS -> HBM: header, tape counter, tallies and the last path of every game, as the launch-per-phase path leaves them
             using G = typename SEARCH::Game;
-            using WS = WideScratch<G, HW>;
+            using WS = WideScratch<G, HW, SOLO>;
             __syncthreads();
             const int bd = wave % BOARDS, role = wave / BOARDS, slot = tile * BOARDS + bd;
             if (lds_live && role == 0 && slot < sa.ev.B) {
@@ -1151,9 +1250,11 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 if (lane < 4) reinterpret_cast<uint4 *>(sa.ev.hdr + slot)[lane] = reinterpret_cast<const uint4 *>(ws + WS::HDR)[lane];
                 static_assert(sizeof(TreeHdr) == 4 * sizeof(uint4) && sizeof(azg_state) % 16 == 0 && sizeof(PathEnt) == sizeof(uint4),
                               "the LDS mirror moves the header, the root state and the path as whole 16-byte chunks");
-                const int depth = *reinterpret_cast<const int *>(ws + WS::HDR + offsetof(TreeHdr, depth));
-                for (int j = lane; j < depth && j < sa.ev.maxd; j += 64)
-                    reinterpret_cast<uint4 *>(sa.ev.path + (size_t)slot * sa.ev.maxd)[j] = reinterpret_cast<const uint4 *>(ws + WS::PATH)[j];
+                if constexpr (!SOLO) {
+                    const int depth = *reinterpret_cast<const int *>(ws + WS::HDR + offsetof(TreeHdr, depth));
+                    for (int j = lane; j < depth && j < sa.ev.maxd; j += 64)
+                        reinterpret_cast<uint4 *>(sa.ev.path + (size_t)slot * sa.ev.maxd)[j] = reinterpret_cast<const uint4 *>(ws + WS::PATH)[j];
+                }
                 if (lane == 0) {
                     sa.ev.tape_ctr[slot] = *reinterpret_cast<const uint64_t *>(ws + WS::CTR);
                     sa.ev.slot_sims[slot] = *reinterpret_cast<const int64_t *>(ws + WS::CTR + 8);

@@ -680,7 +680,7 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     using GEO = TowerGeom<H, W, BOARDS, C>;
     constexpr size_t LDS_IMG = []() {                          // the image (+ the wide search mode's scratch behind it)
-        if constexpr (IS_SEARCH) { if constexpr (SEARCH::WIDE) return (size_t)GEO::TILE + (size_t)WideLds<typename SEARCH::Game, H * W, BOARDS>::BYTES; }
+        if constexpr (IS_SEARCH) { if constexpr (SEARCH::WIDE) return (size_t)GEO::TILE + (size_t)WideLds<typename SEARCH::Game, H * W, BOARDS, wide_solo<C, PSPLIT, KSPLIT, BOARDS>()>::BYTES; }
         return (size_t)GEO::TILE;
     }();
     // (+ the k-split exchange area: per wave one 1 KB accumulator tile for each of the 2 x NSUB / 2 tiles its partner finishes)
@@ -940,25 +940,69 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     return r;
 }
 
-extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
-                                   int nblocks, int channels, const void *head1_w, const float *head1_b, const void *head_rows, const float *head_b,
-                                   int feat_k, int sims) {
-    if (!e || !w || !bias || !head1_w || !head1_b || !head_rows || !head_b || nblocks < 0 || sims < 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
+// the persistent wide-head search launch, sparse heads (EXACT = false: hd) or full-width heads (EXACT = true: hf)
+template <bool EXACT>
+static int search_wide(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift, int nblocks, int channels,
+                       const void *head1_w, const float *head1_b, const HeadRows &hd, const HeadsFact &hf, int feat_k, int sims) {
+    if (!e || !w || !bias || !head1_w || !head1_b || nblocks < 0 || sims < 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     if (e->v.arena) return fail(AZG_E_UNSUPPORTED, "the persistent search launches are built for self-play engines");
     const int A = e->gi.action_size, NV = e->gi.num_players + 1, hw = e->gi.obs_h * e->gi.obs_w;
     if (feat_k != (hw * 16 + 31) / 32 * 32) return fail(AZG_E_INVALID_ARG, "feat_k must be H*W*16 rounded up to 32");
     TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, nullptr, nullptr, nullptr, nullptr, A, NV, nullptr, head1_w, head1_b, nullptr, feat_k,
                   nullptr, 0, {}};
-    const HeadRows hd{(const _Float16 *)head_rows, head_b, feat_k};
     hipStream_t s = (hipStream_t)stream;
     EvPair ep; const bool prof = sims > 0 && netprof_begin(s, ep);
     int r = AZG_E_UNSUPPORTED;
-    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) r = launch_tower<BR::H, BR::W, 1, 64, 1, SearchWide<BR, 2>, 2>(s, P, SearchWide<BR, 2>{e->v, sims, hd}, sims == 0);
-    else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) r = launch_tower<TM::H, TM::W, 1, 32, 2, SearchWide<TM>>(s, P, SearchWide<TM>{e->v, sims, hd}, sims == 0);
-    else { g_kev = nullptr; return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)"); }
+    // Games per workgroup by the engine's size (SelfPlayAgent.pyx:23-26: the batch is whatever the caller made it).  Up to two games
+    // per CU (512 brandubh games, 256 of the 3-player env: BASELINE's 8- / 4-GPU shards) one game per workgroup fills the chip best;
+    // beyond that a CU holds several games anyway and a tile of several boards shares every weight fragment between them, pads fewer
+    // pixel lanes (brandubh: 196 of 208 instead of 49 of 64) and has a main loop long enough to amortise a layer's epilogue and barriers.
+#ifdef AZG_TUNING
+    static const int forced = getenv("AZG_WIDE_BOARDS") ? atoi(getenv("AZG_WIDE_BOARDS")) : 0;
+#else
+    constexpr int forced = 0;
+#endif
+    const bool init = sims == 0;
+    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) {
+        // two workgroups of four wavefronts per CU in every shape: 512 workgroups are one round of the chip
+        using SW = SearchWide<BR, 2, EXACT>;
+        const SW sa{e->v, sims, hd, hf};
+        const int bt = forced ? forced : e->v.B <= 512 ? 1 : e->v.B <= 1024 ? 2 : e->v.B <= 1536 ? 3 : 4;
+        if (bt == 1) r = launch_tower<BR::H, BR::W, 1, 64, 1, SW, 2>(s, P, sa, init);      // four wavefronts per game (walk, priors, masks, rules), k-split tower
+        else if (bt == 2) r = launch_tower<BR::H, BR::W, 2, 64, 2, SW>(s, P, sa, init);    // walker + helper per game
+        else if (bt == 3) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);    // solo tree phase: one wavefront per game
+        else r = launch_tower<BR::H, BR::W, 4, 64, 2, SW>(s, P, sa, init);
+    } else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) {
+        const int bt = forced ? forced : 1;
+        if (bt == 1) r = launch_tower<TM::H, TM::W, 1, 32, 2, SearchWide<TM, 1, EXACT>>(s, P, SearchWide<TM, 1, EXACT>{e->v, sims, hd, hf}, init);
+#ifdef AZG_TUNING
+        else if (bt == 2) r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);
+        else r = launch_tower<TM::H, TM::W, 4, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);
+#endif
+    } else {
+        g_kev = nullptr;
+        return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)");
+    }
     netprof_end(s, 2, prof, ep);
     return r;
+}
+
+extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
+                                   int nblocks, int channels, const void *head1_w, const float *head1_b, const void *head_rows, const float *head_b,
+                                   int feat_k, int sims) {
+    if (!head_rows || !head_b) return fail(AZG_E_INVALID_ARG, "null argument");
+    return search_wide<false>(e, stream, w, bias, pre_scale, pre_shift, nblocks, channels, head1_w, head1_b, HeadRows{(const _Float16 *)head_rows, head_b, feat_k},
+                              HeadsFact{}, feat_k, sims);
+}
+
+extern "C" int azg_search_wide_exact_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
+                                         int nblocks, int channels, const void *head1_w, const float *head1_b, const void *wp_packed, const void *wv_packed,
+                                         const float *head_b, int feat_k, int sims) {
+    if (!e || !wp_packed || !wv_packed || !head_b) return fail(AZG_E_INVALID_ARG, "null argument");
+    const int A = e->gi.action_size, NV = e->gi.num_players + 1;
+    return search_wide<true>(e, stream, w, bias, pre_scale, pre_shift, nblocks, channels, head1_w, head1_b, HeadRows{nullptr, head_b, feat_k},
+                             HeadsFact{(const half8 *)wp_packed, (const half8 *)wv_packed, head_b, feat_k, (A + 15) / 16, A, NV}, feat_k, sims);
 }
 
 extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,

@@ -405,10 +405,12 @@ class HipResNet:
         factorised heads on brandubh x 64 / the 3-player env x 32 channels (azg_search_wide_f16)."""
         return (self.fused_head and self.game == 0 and self.CH == 128) or (self.fact_head and (self.game, self.CH) in ((1, 64), (2, 32)))
 
-    def search(self, engine, sims):
+    def search(self, engine, sims, exact=False):
         """`sims` whole simulations (select -> this network -> backup) on every slot of `engine` in one persistent launch: the
         trees, the leaf planes and the logits / probabilities never leave the GPU's LDS / HBM and nothing is launched per
-        simulation.  Self-play engines only."""
+        simulation.  Self-play engines only.  Factorised heads: exact=True evaluates ALL A + P+1 logits inside the launch (the
+        bits NNetWrapper.process returns; softmax over all A, mask, renormalise: MCTS.pyx:239-245), exact=False only the logits
+        of each leaf's valid actions (sparse heads: equal to rounding).  Fused heads (connect4) are always exact."""
         if not self.can_search:
             raise NotImplementedError('no persistent search launch for this (game, network) -- use select / network / backup')
         import ctypes as C
@@ -417,6 +419,10 @@ class HipResNet:
         if self.fused_head:
             self._check(self.L.azg_search_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
                                               len(self.blocks), vp(self.head_w_packed), vp(self.head_b16), int(sims)))
+        elif exact:
+            self._check(self.L.azg_search_wide_exact_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
+                                                         len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head2_wp),
+                                                         vp(self.head2_wv), vp(self.head2_b), int(self.feat_k), int(sims)))
         else:
             self._check(self.L.azg_search_wide_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
                                                    len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head_rows),

@@ -16,6 +16,9 @@ from .Game import azg_game_id
 from .utils import AGENT_STREAM, default_temp_scaling
 
 
+SEARCH_HEADS_DEFAULT = 'sparse'                                        # (SelfPlayRunner(search_heads=...))
+
+
 class _Lane:
     """One software-pipeline lane: a device engine over a contiguous range of game slots, its own HIP stream and its
     own captured network graph."""
@@ -34,12 +37,16 @@ class SelfPlayRunner:
 
     def __init__(self, game_cls, nnet, args, *, num_slots, seed=0, slot_base=0, device=None, example_capacity=None,
                  use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None, result_capacity=None,
-                 fused_search=None, heads=None, nodes_per_tree=0):
+                 fused_search=None, heads=None, nodes_per_tree=0, search_heads=None):
         """heads: what the tree launch is fed when the search is launched per phase -- None picks the cheapest form the network
         offers ('features' for factorised heads: the launch computes the logits of the valid actions itself; 'logits' for other
         wide heads: softmax inside the launch; else 'probs'); tests pin each form against the oracle.  nodes_per_tree: node
         store of a tree (0 = the library's default, include/azg.h)."""
         assert heads in (None, 'probs', 'logits', 'features')
+        # the persistent launch of a factorised-heads network: 'exact' = all A + P+1 logits inside the launch (NNetWrapper.process's bits),
+        # 'sparse' = only the logits of each leaf's valid actions (equal to rounding)
+        assert search_heads in (None, 'exact', 'sparse')
+        self.search_exact = (search_heads or SEARCH_HEADS_DEFAULT) == 'exact'
         if heads is not None:                                        # a pinned hand-over form IS the launch-per-phase search
             if fused_search:
                 raise ValueError('heads=%r pins a launch-per-phase form; it cannot be combined with fused_search=True' % heads)
@@ -143,7 +150,7 @@ class SelfPlayRunner:
         backup k and select k + 1 sharing a launch (or the whole loop in one persistent launch)."""
         e = ln.engine
         if self.fused_search:
-            self.nnet._hip.search(e, sims)
+            self.nnet._hip.search(e, sims, exact=self.search_exact)
             e.advance(record_history=not fast)
             return
         e.select(ln.obs)
@@ -176,7 +183,7 @@ class SelfPlayRunner:
         if key not in ln.round_graphs:
             e = ln.engine
             if self.fused_search:
-                self.nnet._hip.search(e, 0)                          # one-time setup outside the capture
+                self.nnet._hip.search(e, 0, exact=self.search_exact)  # one-time setup outside the capture
             torch.cuda.synchronize(e.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():

@@ -270,7 +270,7 @@ def build(workload, a, rank, local_rank, dev, rounds):
         per_game = (Game.max_turns() + 1) * nsym
         c.runner = SelfPlayRunner(Game, c.net, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
                                   use_graph=not a.no_graph, pipelines=c.pipelines,
-                                  fused_search=False if (a.no_fused_search or c.pipelines > 1) else None,
+                                  fused_search=False if (a.no_fused_search or c.pipelines > 1) else None, search_heads=a.search_heads,
                                   example_capacity=int(c.B * rounds / 5.0 + 2 * c.B) * per_game)
         c.engines = [ln.engine for ln in c.runner.lanes]
         c.counters = c.runner.counters
@@ -593,6 +593,8 @@ def main():
                     help='skip the short runs of BASELINE configs 3-5 that the default (connect4, 1 GPU) line carries as other_workloads')
     ap.add_argument('--profile-rounds', type=int, default=3, help='eager rounds of the persistent launch timed after the timed region')
     ap.add_argument('--compat', action='store_true', help='also time compat mode (unmodified-Coach protocol: SelfPlayAgent processes served by the parent)')
+    ap.add_argument('--search-heads', default=None, choices=['exact', 'sparse'],
+                    help='wide-head workloads, persistent launch: all A + P+1 logits inside the launch (bit-exact) or the valid actions only')
     ap.add_argument('--no-exact-heads', action='store_true', help='skip the bit-exact full-width-heads run of the wide-head workloads')
     a = ap.parse_args()
 

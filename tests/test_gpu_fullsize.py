@@ -333,7 +333,11 @@ def test_mcts_class_keeps_searching_at_one_root():
 
 
 @pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200), ('brandubh', 1, 2),
-                                           ('trimok', 3, 2), ('trimok', 1, 5)])
+                                           ('trimok', 3, 2), ('trimok', 1, 5),
+                                           # above 512 games: the tile of several boards per workgroup, one wavefront per game's tree (a last
+                                           # tile with one and with two games, then BASELINE config 3's 2-GPU shard)
+                                           ('brandubh', 700, 23), ('brandubh', 515, 9), ('brandubh', 1300, 11), ('brandubh', 1537, 7),
+                                           ('brandubh', 2048, 200)])
 def test_wide_search_launch_equals_phase_launches(game, B, sims):
     """azg_search_wide_f16 (networks with factorised heads: tree walk by two wavefronts per game, tower, head convolutions and the
     sparse heads all inside one persistent launch) against the launch-per-phase path -- azg_select / azg_backup_select_features,
@@ -362,6 +366,49 @@ def test_wide_search_launch_equals_phase_launches(game, B, sims):
         eb.select(obs)
         for s in range(sims):
             eb.backup_select_features(hip.forward_features_nhwc8(obs), hip.head_rows, hip.head2_b, obs, select=s + 1 < sims)
+        assert torch.equal(ea.root_counts(), eb.root_counts()), move
+        assert torch.equal(ea.root_probs(1.0), eb.root_probs(1.0))
+        assert torch.equal(ea.root_value(True), eb.root_value(True))
+        ea.advance(True); eb.advance(True)
+        assert torch.equal(ea.last_actions(), eb.last_actions())
+        assert (ea.tape_counters() == eb.tape_counters()).all()
+    a, b = ea.counters(), eb.counters()
+    assert a == b and a['sims'] == B * sims * moves
+    for x, y in zip(ea.examples(), eb.examples()):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200), ('brandubh', 1, 2), ('trimok', 3, 2),
+                                           ('brandubh', 700, 23), ('brandubh', 1300, 11), ('brandubh', 1537, 7), ('brandubh', 2048, 200)])
+def test_wide_exact_search_launch_equals_logits_phase_launches(game, B, sims):
+    """azg_search_wide_exact_f16 -- the persistent launch that computes ALL A + P+1 logits of its boards itself (heads_full_lds: the
+    fragments and summation order of k_heads_fact) and takes the softmax over all A, masks, renormalises -- against the launch-per-phase
+    form of the same evaluation on a twin engine: azg_select / azg_backup_select_logits fed NNetWrapper.process's logits
+    (azg_resnet_tower_features_f16 + azg_policy_value_heads_fact_f16).  That form is what tests/test_gpu_runner_oracle.py holds to the
+    oracle fed NNetWrapper.process with frac == 1.0; the persistent launch must be bit-identical to it in every tile shape (one, two,
+    three and four games per workgroup by engine size)."""
+    import importlib
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.engine import DeviceEngine
+    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    torch.manual_seed(22)
+    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    net.refresh()
+    hip = net._hip
+    assert hip.fact_head and hip.can_search
+    gid = Game.AZG_GAME_ID
+    kw = dict(cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=5, games_per_iteration=1 << 30,
+              example_capacity=B * 16 * 8, sims_hint=sims)
+    ea, eb = DeviceEngine(gid, B, **kw), DeviceEngine(gid, B, **kw)
+    hw = Game.observation_size()[1] * Game.observation_size()[2]
+    obs = torch.zeros((B, hw, 8), dtype=torch.float16, device=ea.device)
+    moves = 3 if B >= 512 else 14
+    for move in range(moves):
+        hip.search(ea, sims, exact=True)
+        eb.select(obs)
+        for s in range(sims):
+            eb.backup_select_logits(hip.forward_logits_nhwc8(obs), obs, select=s + 1 < sims)
         assert torch.equal(ea.root_counts(), eb.root_counts()), move
         assert torch.equal(ea.root_probs(1.0), eb.root_probs(1.0))
         assert torch.equal(ea.root_value(True), eb.root_value(True))
