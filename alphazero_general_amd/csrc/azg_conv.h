@@ -245,6 +245,8 @@ __device__ __forceinline__ void heads_fact_chains(AF &&afrag, const half8 *wl, s
 // the factorised heads' parameters: subtile s < osp = policy outputs s*16.. from the policy half of the features (weights wp
 // [fk/32][osp][64]), subtile osp = the value outputs from the value half (weights wv [fk/32][64])
 struct HeadsFact { const half8 *wp, *wv; const float *bias; int fk, osp, A, NV; };
+// (the same chains for the persistent exact launch, heads_full_lds: the policy fragments subtile-major)
+struct HeadsFull { const half8 *wps, *wv; const float *bias; };
 __device__ __forceinline__ int heads_fact_kq(int ksteps) { return (ksteps + HEADF_Q - 1) / HEADF_Q; }      // k-steps per quarter
 
 // workgroup = 16 boards x one chunk of HEADF_NS policy subtiles (or the value subtile), wave = K quarter
@@ -439,7 +441,7 @@ template <class G> struct SearchArgs { View ev; int sims; using Game = G; static
 // phase takes softmax over all A, masks and renormalises like MCTS.pyx:239-245: bit-identical to the launch-per-phase form
 // k_tower2 -> k_heads_fact -> k_backup_select2<IN_LOGITS>.  Otherwise the sparse heads (hd: one row per output, azg_kernels.h).
 template <class G, int MINB = 1, bool EXACT_ = false> struct SearchWide {
-    View ev; int sims; HeadRows hd; HeadsFact hf;
+    View ev; int sims; HeadRows hd; HeadsFull hf;
     using Game = G; static constexpr bool WIDE = true; static constexpr int MIN_BLOCKS = MINB; static constexpr bool EXACT = EXACT_;
 };
 
@@ -466,39 +468,54 @@ template <class G, int HW, bool COMPACT = false> struct WideScratch {
 template <class G> struct WideMailFits { static_assert(G::MAX_TURNS + 2 <= 128, "WalkMail::act holds one action per level of a find_leaf path"); };
 template <class G, int HW, int BOARDS, bool COMPACT = false> struct WideLds : WideMailFits<G> {
     static constexpr int NV = G::P + 1, FK = WideScratch<G, HW, COMPACT>::FK;
-    static constexpr int ERR = BOARDS * WideScratch<G, HW, COMPACT>::BYTES, VROWS = (ERR + 16 + 15) / 16 * 16, VBIAS = VROWS + (COMPACT ? 0 : NV * FK * 2),
+    // (ZERO: a feature row of zeros -- the A-operand rows of heads_full_lds that no board stands behind; zeroed once per launch)
+    static constexpr int ERR = BOARDS * WideScratch<G, HW, COMPACT>::BYTES, ZERO = (ERR + 16 + 15) / 16 * 16, VROWS = ZERO + FK * 2, VBIAS = VROWS + (COMPACT ? 0 : NV * FK * 2),
                          BYTES = (VBIAS + (COMPACT ? 0 : NV * 4) + 15) / 16 * 16;
 };
 
 // The full-width heads of a tile's boards inside the persistent launch (EXACT): logits[board][o] for all A policy outputs and the
 // P + 1 value outputs, from the boards' head features in LDS.  Output subtile s (16 outputs; s == OSP: the value outputs over the
-// value half) is ONE wavefront's job: A operand = the boards' features (row m = board m, rows past BOARDS zero), B operand = the
-// subtile's weight fragments streamed from L2 ([k-step][subtile][64 lanes], the layout of k_heads_fact), FOUR accumulation chains,
-// one per contiguous quarter of the k-steps, summed as (q0 + q1) + (q2 + q3) + bias -- exactly k_heads_fact's arithmetic for a board
-// (an MFMA row depends on its own A row only), so the logits are bit-identical to NNetWrapper.process's.  The chains are issued
-// interleaved (independent accumulators), the fragments of the wave's NEXT subtile are requested as the current ones are consumed.
-// The job is the L2 -> L1 stream of the whole matrix (brandubh 0.94 MB per workgroup and simulation), shared by the tile's boards.
+// value half) is ONE wavefront's job: A operand = the boards' features (row m = board m; the lanes of rows past BOARDS read a zero
+// row), B operand = the subtile's weight fragments streamed from L2, FOUR accumulation chains, one per contiguous quarter of the
+// k-steps, summed as (q0 + q1) + (q2 + q3) + bias -- exactly k_heads_fact's arithmetic for a board (an MFMA row depends on its own
+// A row only), so the logits are bit-identical to NNetWrapper.process's.  The chains are issued interleaved (independent
+// accumulators); the fragments AND the bias of the wave's NEXT subtile are requested as the current ones are consumed, in the order
+// they will be used, and the subtile loop is fully unrolled -- vmcnt retires in order, so every MFMA then waits for exactly its own
+// fragment instead of draining the stream (a loop back-edge or a bias load at the point of use both made the compiler wait for
+// vmcnt(0): 36 k cycles per evaluation instead of the 15 k the 0.94 MB take through the CU's L1 path).
+//   wps: the policy chain's fragments SUBTILE-major, [OSP][k-step][64 lanes] x 16 B (k_heads_fact's wp is k-step-major: a wave here
+//   streams one subtile's 25 KB contiguously); wv [k-step][64]; bias f32 [A + P + 1].
 template <class G, int HW, int BOARDS, int NW, bool COMPACT>
-__device__ __forceinline__ void heads_full_lds(char *scr0, const HeadsFact &hf, int wave, int lane) {
+__device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row, const HeadsFull &hf, int wave, int lane) {
     using WS = WideScratch<G, HW, COMPACT>;
     constexpr int A = G::A, NV = G::P + 1, FK = WS::FK, KS = FK / 32, KQ = (KS + HEADF_Q - 1) / HEADF_Q, OSP = (A + 15) / 16;
-    static_assert(BOARDS <= 4 && HEADF_Q == 4, "the tile's boards are D rows 0..3 (lane group 0); four K quarters");
+    constexpr int NIT = (OSP + 1 + NW - 1) / NW;                             // subtiles per wavefront (the last one may be a repeat)
+    static_assert(BOARDS <= 16 && HEADF_Q == 4, "the tile's boards are the D rows; four K quarters");
     const int g = lane >> 4, i16 = lane & 15;
     const bool live = i16 < BOARDS;
-    const char *fb = scr0 + (live ? i16 : 0) * WS::BYTES + WS::FEAT + g * 16;
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto frags = [&](int s_) { return s_ == OSP ? hf.wv + lane : hf.wp + (size_t)s_ * 64 + lane; };
+    const char *fb = live ? scr0 + i16 * WS::BYTES + WS::FEAT + g * 16 : zero_row + g * 16;
+    const int vhalf = live ? FK * 2 : 0;
+    auto frags = [&](int s_) { return s_ == OSP ? hf.wv + lane : hf.wps + (size_t)s_ * (KS * 64) + lane; };
+    // consumption order of the k-steps: the four chains interleaved
     half8 b[KS];
-    if (wave <= OSP) {
-        const half8 *w0 = frags(wave); const size_t st0 = wave == OSP ? (size_t)64 : (size_t)OSP * 64;
+    float bias_cur, bias_nxt = 0.f;
+    {
+        const int s0 = min(wave, OSP);
+        const half8 *w0 = frags(s0);
+        bias_cur = hf.bias[min(s0 == OSP ? A + i16 : s0 * 16 + i16, A + NV - 1)];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) b[ks] = w0[(size_t)ks * st0];
+        for (int j = 0; j < KQ; j++)
+#pragma unroll
+            for (int q = 0; q < HEADF_Q; q++) { const int ks = q * KQ + j; if (ks < KS && ks < (q + 1) * KQ) b[ks] = w0[(size_t)ks * 64]; }
     }
-    for (int s_ = wave; s_ <= OSP; s_ += NW) {
-        const bool is_v = s_ == OSP;
-        const int sn = s_ + NW <= OSP ? s_ + NW : s_;                       // (past the end: re-read this subtile's fragments, unused)
-        const half8 *wn = frags(sn); const size_t stn = sn == OSP ? (size_t)64 : (size_t)OSP * 64;
-        const char *f = fb + (is_v ? FK * 2 : 0);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int s_ = wave + it * NW;                                       // (scalar)
+        const int sc = min(s_, OSP), sn = min(s_ + NW, OSP);                 // (past the end: the value subtile once more, not stored)
+        const bool is_v = sc == OSP;
+        const half8 *wn = frags(sn);
+        const char *f = fb + (is_v ? vhalf : 0);
+        if (it + 1 < NIT) bias_nxt = hf.bias[min(sn == OSP ? A + i16 : sn * 16 + i16, A + NV - 1)];
         floatx4 acc[HEADF_Q];
 #pragma unroll
         for (int q = 0; q < HEADF_Q; q++) acc[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -508,19 +525,24 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const HeadsFact &hf, 
             for (int q = 0; q < HEADF_Q; q++) {
                 const int ks = q * KQ + j;
                 if (ks < KS && ks < (q + 1) * KQ) {
-                    half8 a = *reinterpret_cast<const half8 *>(f + ks * 64);
-                    if (!live) a = zero8;
+                    const half8 a = *reinterpret_cast<const half8 *>(f + ks * 64);
                     acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[ks], acc[q], 0, 0, 0);
-                    b[ks] = wn[(size_t)ks * stn];
+                    if (it + 1 < NIT) b[ks] = wn[(size_t)ks * 64];
+                    // (pin the interleave: one fragment request behind every MFMA, in consumption order -- left alone the scheduler
+                    //  bunches the requests at the end of the subtile and the next one starts by draining them)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (it + 1 < NIT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
+        __builtin_amdgcn_sched_barrier(0);
         const floatx4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        const int out = is_v ? A + i16 : s_ * 16 + i16, lim = is_v ? A + NV : A;
-        if (g == 0 && out < lim) {                                          // D[m = board 4 g + r][n = output i16]
-            const float bo = hf.bias[out];
+        const int out = is_v ? A + i16 : sc * 16 + i16, lim = is_v ? A + NV : A;
+        if (s_ <= OSP && 4 * g < BOARDS && out < lim) {                      // D[m = board 4 g + r][n = output i16]
 #pragma unroll
-            for (int r = 0; r < BOARDS; r++) *reinterpret_cast<float *>(scr0 + r * WS::BYTES + WS::LG + out * 4) = sum[r] + bo;
+            for (int r = 0; r < 4; r++)
+                if (4 * g + r < BOARDS) *reinterpret_cast<float *>(scr0 + (4 * g + r) * WS::BYTES + WS::LG + out * 4) = sum[r] + bias_cur;
         }
+        bias_cur = bias_nxt;
     }
 }
 
@@ -544,7 +566,11 @@ template <int H, int W, int C> constexpr bool tower_khalf_order() { return H == 
 // [nblocks][C] and shift [nblocks][C]: sized by the launch (dynamic LDS), (12 * nblocks + 8) * C bytes.
 template <int C, int BOARDS> constexpr int tower_layer_param_bytes(int nblocks) { return ((2 * nblocks + 1) * C * 4 + 2 * nblocks * C * 2 + C * 4 + 15) / 16 * 16; }   // (+ one row of slack: the bias prefetch of the last layer)
 // (+ the 1x1 head convolutions of the factorised heads: C / 32 k-steps x 2 fragments of 64 lanes x 16 bytes, then their 32 biases)
-template <int C, int BOARDS> constexpr int tower_param_bytes(int nblocks) { return BOARDS == 1 ? tower_layer_param_bytes<C, BOARDS>(nblocks) + (C / 32) * 2 * 1024 + 128 : 0; }
+// (tiles of several games of the persistent wide launch, SOLO: the layers' parameters only -- their global fetches were exposed at the top of
+//  every layer and behind every residual layer's main loop, and what LDS the games leave holds them but not the head fragments too)
+template <int C, int BOARDS, bool SOLO = false> constexpr int tower_param_bytes(int nblocks) {
+    return BOARDS == 1 ? tower_layer_param_bytes<C, BOARDS>(nblocks) + (C / 32) * 2 * 1024 + 128 : SOLO ? tower_layer_param_bytes<C, BOARDS>(nblocks) : 0;
+}
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch, int KSPLIT = 1>
 __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()) void k_tower2(TowerParams Pin, const int16_t *pixmap, SEARCH sa) {
     using GEO = TowerGeom<H, W, BOARDS, C>;
@@ -562,7 +588,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     }();
     static_assert(KSPLIT == 1 || (KSPLIT == 2 && KS == 2 && KHALF), "k-split: 64-channel towers in k-half order");
     constexpr int NSUBT = GEO::NSUB, NSUB = (NSUBT + PSPLIT - 1) / PSPLIT;   // subtiles of the tile / of one wave
-    constexpr bool PLDS = BOARDS == 1;                           // the layers' parameters in LDS (see tower_param_bytes)
+    constexpr bool PLDS = BOARDS == 1 || SOLO;                   // the layers' parameters in LDS (see tower_param_bytes)
+    constexpr bool PLDS_H1 = BOARDS == 1;                        // ... and the 1x1 head convolutions' fragments
     constexpr int PARAM_OFF = XCHG_OFF + (KSPLIT == 2 ? (C / 32 * PSPLIT * 2) * NSUB * 1024 : 0);
     constexpr bool TAPSKIP = PSPLIT == 1 && GEO::CLASSES > 1;   // (a wave's subtile numbers must be compile-time constants)
     constexpr int HW = GEO::HW, ROWS = GEO::ROWS, TILE = GEO::TILE, RS = GEO::RSTRIDE;
@@ -663,7 +690,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             _Float16 *psc_ = reinterpret_cast<_Float16 *>(smem + sc_off), *psh_ = reinterpret_cast<_Float16 *>(smem + sh_off);
             for (int c = tid; c < (2 * P.nblocks + 1) * C; c += NT) pb_[c] = P.bias[c];
             for (int c = tid; c < P.nblocks * C; c += NT) { psc_[c] = (_Float16)P.pre_scale[c]; psh_[c] = (_Float16)P.pre_shift[c]; }
-            if (P.head_w == nullptr && P.head1_w != nullptr) {
+            if (PLDS_H1 && P.head_w == nullptr && P.head1_w != nullptr) {
                 uint4 *h1_ = reinterpret_cast<uint4 *>(smem + h1_off);
                 for (int c = tid; c < KS * 2 * 64; c += NT) h1_[c] = reinterpret_cast<const uint4 *>(P.head1_w)[c];
                 if (tid < 32) reinterpret_cast<float *>(smem + h1_off + KS * 2 * 1024)[tid] = P.head1_b[tid];
@@ -1091,7 +1118,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 for (int m = 0; m < 2; m++) {
                     const int c0 = m * 16 + g * 4;
                     floatx4 bv;
-                    if constexpr (PLDS) bv = *reinterpret_cast<const floatx4 *>(smem + h1_off + KS * 2 * 1024 + c0 * 4 + opaque);
+                    if constexpr (PLDS_H1) bv = *reinterpret_cast<const floatx4 *>(smem + h1_off + KS * 2 * 1024 + c0 * 4 + opaque);
                     else bv = (floatx4){P.head1_b[c0], P.head1_b[c0 + 1], P.head1_b[c0 + 2], P.head1_b[c0 + 3]};
 #pragma unroll
                     for (int ps = 0; ps < NOWN; ps++) hacc[m][ps] = bv;
@@ -1099,7 +1126,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     half8 a0, a1;
-                    if constexpr (PLDS) {
+                    if constexpr (PLDS_H1) {
                         a0 = *reinterpret_cast<const half8 *>(smem + h1_off + ((ks * 2) * 64 + lane) * 16 + opaque);
                         a1 = *reinterpret_cast<const half8 *>(smem + h1_off + ((ks * 2 + 1) * 64 + lane) * 16 + opaque);
                     } else { a0 = hw1[(size_t)(ks * 2) * 64]; a1 = hw1[(size_t)(ks * 2 + 1) * 64]; }
@@ -1132,7 +1159,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 // (second stage: the next tree phase turns the features into the logits it needs -- sparse heads, azg_kernels.h)
                 __syncthreads();                                 // the features of every board are in LDS
                 AZG_WPHASE(3);
-                if constexpr (EXACT) heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, sa.hf, wave, lane);
+                if constexpr (EXACT) heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave, lane);
                 AZG_WPHASE(4);
 #ifdef AZG_TOWER_TIMING
                 if (P.dbg && tid == 0 && blockIdx.x < 512 && sim >= 8)      // tree (incl. the sparse heads), tower, head conv (cycles, summed over simulations)

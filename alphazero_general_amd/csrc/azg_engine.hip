@@ -686,12 +686,13 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
     // (+ the k-split exchange area: per wave one 1 KB accumulator tile for each of the 2 x NSUB / 2 tiles its partner finishes)
     constexpr size_t LDS_FIXED = LDS_IMG + (KSPLIT == 2 ? (size_t)(C / 32 * PSPLIT * 2) * ((GEO::NSUB + PSPLIT - 1) / PSPLIT) * 1024 : 0);
     // (+ the layers' biases and affines of one-board tiles, tower_param_bytes: sized by the network's depth)
-    constexpr size_t LDS_MAX = 160 * 1024;
-    const size_t LDS_BYTES = LDS_FIXED + (size_t)tower_param_bytes<C, BOARDS>(P.nblocks);
-    if (LDS_BYTES > LDS_MAX) return fail(AZG_E_INVALID_ARG, "this tower does not fit the LDS of a one-board tile (too many residual blocks)");
+    constexpr bool WSOLO = []() { if constexpr (IS_SEARCH) { if constexpr (SEARCH::WIDE) return wide_solo<C, PSPLIT, KSPLIT, BOARDS>(); } return false; }();
+    constexpr bool DYN_PARAMS = BOARDS == 1 || WSOLO;          // (tower_param_bytes: sized by the network's depth)
+    const size_t LDS_BYTES = LDS_FIXED + (size_t)tower_param_bytes<C, BOARDS, WSOLO>(P.nblocks);
     // per (instantiation, device): the pixel -> (subtile, lane) table, a few hundred bytes that live as long as the process
     // (the table is a pure function of the template arguments); first use is serialised
     static int16_t *d_map[16] = {nullptr};
+    static int d_lds[16] = {0};
     static std::mutex d_map_mu;
     int dev = 0, cus = 256;
     HIPCHK(hipGetDevice(&dev));
@@ -704,15 +705,21 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
             int16_t *d = nullptr;
             HIPCHK(hipMalloc((void **)&d, sizeof(map)));
             HIPCHK(hipMemcpy(d, map, sizeof(map), hipMemcpyHostToDevice));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BOARDS == 1 ? LDS_MAX : LDS_FIXED)));
+            // (the LDS a workgroup may take on THIS device -- 160 KB on gfx950 --, not a constant: a device with less refuses loudly below)
+            int lds_limit = 0;
+            HIPCHK(hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+            if ((size_t)lds_limit < LDS_FIXED) return fail(AZG_E_UNSUPPORTED, "this tile shape needs more LDS per workgroup than the device has");
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_PARAMS ? (size_t)lds_limit : LDS_FIXED)));
+            d_lds[dev] = lds_limit;
             d_map[dev] = d;
         }
     }
+    if (LDS_BYTES > (size_t)d_lds[dev]) return fail(AZG_E_INVALID_ARG, "this tower does not fit the LDS of its tile (too many residual blocks)");
     if (init_only) return AZG_OK;                            // (first-use allocations must not happen inside a stream capture)
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS + (P.rows_per_model ? P.nmodels - 1 : 0);
     {                                                        // one LDS image, residual stream in registers, >= 2 workgroups per CU
-        const int per_cu = (int)(160 * 1024 / LDS_BYTES) > 0 ? (int)(160 * 1024 / LDS_BYTES) : 1;
+        const int per_cu = (int)((size_t)d_lds[dev] / LDS_BYTES) > 0 ? (int)((size_t)d_lds[dev] / LDS_BYTES) : 1;
         // (search mode: every tile is its own workgroup for the whole launch -- they never synchronise, later ones just start later)
         const int grid = IS_SEARCH || ntiles < per_cu * cus ? ntiles : per_cu * cus;
 #ifdef AZG_TOWER_TIMING
@@ -943,7 +950,7 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
 // the persistent wide-head search launch, sparse heads (EXACT = false: hd) or full-width heads (EXACT = true: hf)
 template <bool EXACT>
 static int search_wide(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift, int nblocks, int channels,
-                       const void *head1_w, const float *head1_b, const HeadRows &hd, const HeadsFact &hf, int feat_k, int sims) {
+                       const void *head1_w, const float *head1_b, const HeadRows &hd, const HeadsFull &hf, int feat_k, int sims) {
     if (!e || !w || !bias || !head1_w || !head1_b || nblocks < 0 || sims < 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
     if (nblocks > 0 && (!pre_scale || !pre_shift)) return fail(AZG_E_INVALID_ARG, "pre_scale/pre_shift required");
     if (e->v.arena) return fail(AZG_E_UNSUPPORTED, "the persistent search launches are built for self-play engines");
@@ -972,14 +979,19 @@ static int search_wide(azg_engine *e, void *stream, const void *w, const float *
         if (bt == 1) r = launch_tower<BR::H, BR::W, 1, 64, 1, SW, 2>(s, P, sa, init);      // four wavefronts per game (walk, priors, masks, rules), k-split tower
         else if (bt == 2) r = launch_tower<BR::H, BR::W, 2, 64, 2, SW>(s, P, sa, init);    // walker + helper per game
         else if (bt == 3) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);    // solo tree phase: one wavefront per game
+#ifdef AZG_TUNING
+        else if (bt == 8) r = launch_tower<BR::H, BR::W, 8, 64, 4, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);   // one workgroup of eight wavefronts per CU
+#endif
         else r = launch_tower<BR::H, BR::W, 4, 64, 2, SW>(s, P, sa, init);
     } else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) {
-        const int bt = forced ? forced : 1;
+        // (measured, M expansions/s at 256 / 512 / 1024 games: one game per workgroup 20.7 / 37.4 / 39.4, two 16.3 / 31.3 / 48.0, four -- solo --
+        //  - / 23.3 / 44.4: profiles/r05_wide_tile_sweep.txt)
+        const int bt = forced ? forced : e->v.B <= 512 ? 1 : 2;
         if (bt == 1) r = launch_tower<TM::H, TM::W, 1, 32, 2, SearchWide<TM, 1, EXACT>>(s, P, SearchWide<TM, 1, EXACT>{e->v, sims, hd, hf}, init);
 #ifdef AZG_TUNING
-        else if (bt == 2) r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);
-        else r = launch_tower<TM::H, TM::W, 4, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);
+        else if (bt == 4) r = launch_tower<TM::H, TM::W, 4, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);
 #endif
+        else r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);   // walker + helper per game
     } else {
         g_kev = nullptr;
         return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)");
@@ -993,16 +1005,15 @@ extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, c
                                    int feat_k, int sims) {
     if (!head_rows || !head_b) return fail(AZG_E_INVALID_ARG, "null argument");
     return search_wide<false>(e, stream, w, bias, pre_scale, pre_shift, nblocks, channels, head1_w, head1_b, HeadRows{(const _Float16 *)head_rows, head_b, feat_k},
-                              HeadsFact{}, feat_k, sims);
+                              HeadsFull{}, feat_k, sims);
 }
 
 extern "C" int azg_search_wide_exact_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,
-                                         int nblocks, int channels, const void *head1_w, const float *head1_b, const void *wp_packed, const void *wv_packed,
+                                         int nblocks, int channels, const void *head1_w, const float *head1_b, const void *wps_packed, const void *wv_packed,
                                          const float *head_b, int feat_k, int sims) {
-    if (!e || !wp_packed || !wv_packed || !head_b) return fail(AZG_E_INVALID_ARG, "null argument");
-    const int A = e->gi.action_size, NV = e->gi.num_players + 1;
+    if (!e || !wps_packed || !wv_packed || !head_b) return fail(AZG_E_INVALID_ARG, "null argument");
     return search_wide<true>(e, stream, w, bias, pre_scale, pre_shift, nblocks, channels, head1_w, head1_b, HeadRows{nullptr, head_b, feat_k},
-                             HeadsFact{(const half8 *)wp_packed, (const half8 *)wv_packed, head_b, feat_k, (A + 15) / 16, A, NV}, feat_k, sims);
+                             HeadsFull{(const half8 *)wps_packed, (const half8 *)wv_packed, head_b}, feat_k, sims);
 }
 
 extern "C" int azg_policy_value_heads_f16(void *stream, const void *y, const void *head_w_packed, const float *head_b, int boards, int k,

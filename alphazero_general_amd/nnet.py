@@ -313,6 +313,8 @@ class HipResNet:
                 frag = lambda w, osub: w.reshape(FK // 32, 4, 8, osub, 16).permute(0, 3, 1, 4, 2).contiguous().reshape(-1) \
                                         .to(self.device, torch.float16).contiguous()
                 self.head2_wp, self.head2_wv = frag(w2p, OSP), frag(w2v, 1)
+                # (the same policy fragments subtile-major, [OSP][FK/32][64 lanes][8]: what the persistent exact launch streams)
+                self.head2_wps = self.head2_wp.reshape(FK // 32, OSP, 64 * 8).permute(1, 0, 2).contiguous().reshape(-1)
                 self.head2_b = torch.zeros(OS * 16, **f32)
                 self.head2_b[:A] = bp; self.head2_b[A:A + NV] = bv
                 # the same chains one ROW per output (policy outputs over the policy features, then the value outputs over the
@@ -421,7 +423,7 @@ class HipResNet:
                                               len(self.blocks), vp(self.head_w_packed), vp(self.head_b16), int(sims)))
         elif exact:
             self._check(self.L.azg_search_wide_exact_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),
-                                                         len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head2_wp),
+                                                         len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head2_wps),
                                                          vp(self.head2_wv), vp(self.head2_b), int(self.feat_k), int(sims)))
         else:
             self._check(self.L.azg_search_wide_f16(engine.h, st, vp(self.tower_w), vp(self.tower_b), vp(self.tower_ps), vp(self.tower_pt),

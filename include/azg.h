@@ -295,14 +295,16 @@ int  azg_search_wide_f16(azg_engine *e, void *stream, const void *w_packed_dev, 
 
 /* The same persistent launch with the BIT-EXACT hand-over between network and tree (NNetWrapper.py:225-232 -> MCTS.pyx:239-245): after
  * the head convolutions the launch computes ALL A + P+1 logits of its boards -- the collapsed Linear chains of
- * azg_policy_value_heads_fact_f16, same fragments (wp_packed / wv_packed / head_b as there), same summation order, so the same bits --
+ * azg_policy_value_heads_fact_f16, same fragments, same summation order, so the same bits (wv_packed / head_b as there; wps_packed =
+ * the policy chain's fragments SUBTILE-major, [ceil(A/16)][feat_k/32][64 lanes][8 halves], i.e. wp_packed with its first two axes
+ * swapped: a wavefront of the launch streams one output subtile's fragments contiguously) --
  * and the next tree phase takes the softmax over all A, masks and renormalises.  Results are identical to `sims` x [azg_select /
  * azg_backup_select_logits, azg_resnet_tower_features_f16 + azg_policy_value_heads_fact_f16 (logits only)] + a final
  * azg_backup_select_logits without select, i.e. to the reference's evaluation fed NNetWrapper.process.  sims == 0: one-time setup only.
  * The engine's size picks the tile like azg_search_wide_f16 (games per workgroup). */
 int  azg_search_wide_exact_f16(azg_engine *e, void *stream, const void *w_packed_dev, const float *bias_dev, const float *pre_scale_dev,
                                const float *pre_shift_dev, int nblocks, int channels, const void *head1_w_packed_dev,
-                               const float *head1_b_dev, const void *wp_packed_dev, const void *wv_packed_dev, const float *head_b_dev,
+                               const float *head1_b_dev, const void *wps_packed_dev, const void *wv_packed_dev, const float *head_b_dev,
                                int feat_k, int sims);
 
 /* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same

@@ -2,8 +2,9 @@
 between):
 
   config 2   azg_search_f16        connect4, 2048 games x 100 simulations per move
-  config 3   azg_search_wide_f16   brandubh,  512 games x 200 simulations per move (per-GPU shard)
-  config 5   azg_search_wide_f16   3-player env, 256 games x 50 simulations per move (per-GPU shard)
+  config 3   azg_search_wide_exact_f16 (and the sparse-heads azg_search_wide_f16)   brandubh, 512 games x 200 simulations per move (the
+             8-GPU shard), 1024 and 2048 games (the 4- and 2-GPU shards: two and four games per workgroup)
+  config 5   the same launches     3-player env, 256 games x 50 simulations per move (4-GPU shard), 1024 games (1-GPU shard)
   config 4   ArenaRunner's graph   connect4 arena, 256 games x 100 simulations, two nets (per-GPU shard): one multi-model tower launch +
                                    one tree launch per simulation, a whole move replayed as one hipGraph
 
@@ -159,6 +160,53 @@ def test_wide_search_launch_vs_oracle_at_bench_size(game, B, sims, moves):
                              'first_divergence_round': first_div, 'simulations_compared': B * sims * moves}) + '\n')
     assert frac >= 0.95, (frac, first_div)
     ea.close(); ec.close()
+
+
+@pytest.mark.parametrize('game,B,sims,moves', [('brandubh', 512, 200, 5), ('brandubh', 1024, 200, 2), ('brandubh', 2048, 200, 3),
+                                                 ('trimok', 256, 50, 8), ('trimok', 1024, 50, 5)])
+def test_wide_exact_search_launch_vs_oracle_at_bench_size(game, B, sims, moves):
+    """BASELINE configs 3 and 5 as bench.py times them by default, at their 8- / 4-GPU shard size and at the 2- and 1-GPU shard sizes
+    (one, two and four games per workgroup): azg_search_wide_exact_f16 -- all A + P+1 logits inside the launch, softmax over all A, mask,
+    renormalise -- against the oracle pool fed NNetWrapper.process of ITS OWN leaves (NNetWrapper.py:225-232 -> MCTS.pyx:239-245, what
+    the reference computes).  No slot may diverge: visit counts of every root and pi every move, sampled actions, tape counters,
+    samples (as multisets), results, counters -- identical."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    Game, net = _net(game, 7)
+    hip = net._hip
+    gid, seed = Game.AZG_GAME_ID, 31
+    gi = ol.game_info(gid)
+    eng = DeviceEngine(gid, B, cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=seed, games_per_iteration=1 << 30,
+                       example_capacity=B * (moves + 1) * gi.num_symmetries, sims_hint=sims)
+    pool = _pool(gid, B, sims, seed, 1.25, 0.2)
+    probe = list(range(0, B, 29))
+    for mv in range(moves):
+        hip.search(eng, sims, exact=True)                         # the timed launch
+        pool.begin_round()
+        for _ in range(sims):
+            p, v = net.process(torch.from_numpy(pool.generate()))
+            pool.process(p.cpu().numpy(), v.cpu().numpy())
+        assert (eng.root_counts().cpu().numpy() == pool.root_counts()).all(), mv
+        assert (eng.root_probs(1.0).cpu().numpy()[probe] == pool.root_probs(probe, 1.0)).all(), mv
+        pool.play(); eng.advance(True)
+        assert (eng.last_actions().cpu().numpy() == pool.last_actions()).all(), mv
+    c = eng.counters()
+    assert c['sims'] == B * sims * moves == pool.sims_done and c['expansions'] == pool.expansions
+    assert c['games_played'] == pool.games_played
+    eo, ep, ez = [t.cpu().numpy() for t in eng.examples()]
+    oo, op, oz = pool.samples()
+    assert eo.shape[0] == oo.shape[0]
+    if eo.shape[0]:
+        assert (_sorted_rows(eo, ep, ez) == _sorted_rows(oo, op, oz)).all()
+    ws, turns, slot = eng.results()
+    ows, oturns, oslot = pool.results()
+    key = lambda w, t, s: sorted(zip(s.tolist(), t.tolist(), [tuple(x) for x in w.tolist()]))
+    assert key(ws, turns, slot) == key(ows, oturns, oslot)
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/nn_error.jsonl', 'a') as fh:
+        fh.write(json.dumps({'test': 'bench_size_exact_search_vs_oracle_' + game, 'slots': B, 'sims': sims, 'rounds': moves,
+                             'vs_oracle_fed_NNetWrapper_process': 'identical', 'simulations_compared': B * sims * moves}) + '\n')
+    eng.close()
 
 
 def test_arena_graph_vs_oracle_at_256x100():

@@ -1,6 +1,6 @@
 """Cycles per simulation and phase (tree, tower, head convolutions, logits GEMM) of the persistent wide-head search launch --
 needs the measurement build (hipcc ... -DAZG_TOWER_TIMING -o alphazero_general_amd/lib/libazg_timing.so; AZG_LIB_PATH=<that>).
-The library prints the phase means to stderr after every launch.  usage: wide_search_phases.py [games] [brandubh|trimok]"""
+The library prints the phase means to stderr after every launch.  usage: wide_search_phases.py [games] [brandubh|trimok] [exact]"""
 import os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch
@@ -15,5 +15,5 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else (512 if game == 'brandubh' else 2
 sims = 200 if game == 'brandubh' else 50
 e = DeviceEngine(Game.AZG_GAME_ID, B, cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=0, sims_hint=sims, example_capacity=B * 808 * 2)
 for mv in range(6):
-    net._hip.search(e, sims); e.advance(True)
+    net._hip.search(e, sims, exact=len(sys.argv) > 3 and sys.argv[3] == 'exact'); e.advance(True)
 torch.cuda.synchronize()
