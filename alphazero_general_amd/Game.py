@@ -126,8 +126,16 @@ def azg_game_id(game_cls_or_state):
     for suffix, g in _REFERENCE_ENVS.items():
         if mod.endswith(suffix):
             return g
-    raise NotImplementedError('%s.%s has no device rule kernels registered (csrc/azg_games.h); the MI355X engine has '
-                              'no CPU search fallback' % (mod, cls.__name__))
+    msg = '%s.%s has no device rule kernels registered (csrc/azg_games.h); the MI355X engine has no CPU search fallback' % (mod, cls.__name__)
+    # (such games are handed to the reference's own classes on the reference side -- alphazero_general_amd.reference_class; if that import
+    #  failed, say why: a missing checkout, pyximport, a Cython build error)
+    from . import reference_import_error
+    for name in ('MCTS', 'SelfPlayAgent'):
+        ex = reference_import_error(name)
+        if ex is not None:
+            err = NotImplementedError('%s, and the hand-over to the reference\'s own alphazero.%s failed: %s: %s' % (msg, name, type(ex).__name__, ex))
+            raise err from ex
+    raise NotImplementedError(msg)
 
 
 def has_device_rules(game_cls_or_state):

@@ -123,7 +123,10 @@ class MCTS:
         self._max_depth = 0
 
     # max_depth is a public, WRITABLE attribute of the reference's class (MCTS.pyx:130: `cdef public int max_depth`); Evaluator.py:343 resets
-    # it from outside (`self._mcts.max_depth = 0`) before a search of its own made of find_leaf / process_results calls
+    # it from outside (`self._mcts.max_depth = 0`) before a search of its own made of find_leaf / process_results calls.  Semantics here:
+    # assigning 0 resets the device-side maximum as well (the one use the reference's callers make of the setter); any other value is
+    # kept on this object only until the next find_leaf / search, whose result -- the device's running maximum -- replaces it, exactly
+    # as the reference's find_leaf would overwrite an assigned value that a deeper path exceeds
     @property
     def max_depth(self):
         return self._max_depth
@@ -228,14 +231,24 @@ class MCTS:
         if hip is not None and sims > 0:
             # `nn` is this package's NNetWrapper and a persistent search launch exists for (game, network): all `sims` simulations
             # -- find_leaf, the network on MFMA, process_results -- in ONE launch instead of 3 launches + a host sync each
-            # (GenericPlayers.py:133-134 calls this once per move).  Same trees as the loop below: connect4 bit for bit (a board's
-            # probabilities do not depend on the launch form), the sparse-heads networks to rounding (include/azg.h)
+            # (GenericPlayers.py:133-134 calls this once per move).  Same trees as the loop below, bit for bit: a board's evaluation does
+            # not depend on the launch form (wide-head networks: the exact launch, all A + P+1 logits inside it -- include/azg.h)
             self._sync_root_state(gs)
-            self._make_room(sims * self._max_children)
-            e.set_search_flags(add_root_noise, add_root_temp)
-            hip.search(e, int(sims))
-            info = e.tree_info(0)
-            self._nodes_used = info['nodes_used']
+            e.set_search_flags(add_root_noise, add_root_temp)      # (per call; the engine's own defaults are restored below)
+            try:
+                left = int(sims)
+                while left > 0:
+                    # a launch cannot compact in the middle: it gets as many simulations as are sure to fit the store (each adds at most
+                    # max_children nodes), the dropped siblings are reclaimed between launches -- the same tree, launch by launch
+                    self._make_room(left * self._max_children)
+                    fit = (e.nodes_per_tree - self._nodes_used) // self._max_children
+                    n = min(left, fit) if fit >= 1 else left       # (not one expansion fits even after a compaction: let AZG_E_TREE_FULL surface)
+                    hip.search(e, n, exact=True)
+                    left -= n
+                    info = e.tree_info(0)
+                    self._nodes_used = info['nodes_used']
+            finally:
+                e.set_search_flags(False, False)                   # DeviceEngine's defaults for this class's one-slot engine (_ensure_game)
             self.depth, self._max_depth = info['depth'], info['max_depth']
             return
         for _ in range(sims):

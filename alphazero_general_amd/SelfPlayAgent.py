@@ -120,17 +120,33 @@ class SelfPlayAgent(mp.Process):
         # into a multiprocessing Connection with the same authkey handshake multiprocessing.connection.Listener.accept performs
         import socket
         import tempfile
-        from multiprocessing.connection import Connection, answer_challenge, deliver_challenge
+        try:                                                       # (public names of multiprocessing.connection since Python 3.3; their
+            from multiprocessing.connection import Connection, answer_challenge, deliver_challenge   # signatures are (connection, authkey) in 3.8-3.13)
+        except ImportError as ex:
+            raise RuntimeError('this Python\'s multiprocessing.connection lacks Connection / deliver_challenge / answer_challenge (%s): the '
+                               'compat agent needs CPython 3.8-3.13' % ex) from ex
         key = os.urandom(16)
+        # an AF_UNIX path is limited to ~107 bytes: a long TMPDIR falls back to /tmp
         sockdir = tempfile.mkdtemp(prefix='azg-agent-')
         address = os.path.join(sockdir, 'worker.sock')
+        if len(address.encode()) > 100:
+            try:
+                os.rmdir(sockdir)
+            except OSError:
+                pass
+            sockdir = tempfile.mkdtemp(prefix='azg-agent-', dir='/tmp')
+            address = os.path.join(sockdir, 'worker.sock')
         srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-        srv.bind(address); srv.listen(1); srv.settimeout(1.0)
-        env = dict(os.environ, AZG_WORKER_KEY=key.hex(),
-                   PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
-        self._worker = subprocess.Popen([sys.executable, '-m', 'alphazero_general_amd._engine_worker', address], env=env)
         deadline = time.time() + float(os.environ.get('AZG_WORKER_START_TIMEOUT', '300'))
         try:
+            try:
+                srv.bind(address); srv.listen(1); srv.settimeout(1.0)
+            except OSError as ex:
+                raise RuntimeError('cannot bind the agent <-> worker rendezvous socket at %r (%s; AF_UNIX paths are limited to ~107 bytes: '
+                                   'check TMPDIR)' % (address, ex)) from ex
+            env = dict(os.environ, AZG_WORKER_KEY=key.hex(),
+                       PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+            self._worker = subprocess.Popen([sys.executable, '-m', 'alphazero_general_amd._engine_worker', address], env=env)
             while True:
                 try:
                     peer, _ = srv.accept()
@@ -145,7 +161,10 @@ class SelfPlayAgent(mp.Process):
         finally:
             srv.close()
             try:
-                os.unlink(address); os.rmdir(sockdir)
+                if sockdir:
+                    if os.path.exists(address):
+                        os.unlink(address)
+                    os.rmdir(sockdir)
             except OSError:
                 pass
         peer.setblocking(True)

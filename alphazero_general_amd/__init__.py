@@ -8,6 +8,9 @@ __version__ = '0.1.0'
 _installed = {}        # 'MCTS' / 'SelfPlayAgent' -> this package's module registered under the reference's name by install()
 _reference = {}        # 'MCTS' / 'SelfPlayAgent' -> the reference's own class, loaded on first need (reference_class)
 _reference_mod = {}    # ... and the module it lives in
+_reference_error = {}  # ... or the exception its import raised (reference_import_error)
+import threading as _threading
+_reference_lock = _threading.RLock()
 
 
 def install():
@@ -43,27 +46,36 @@ def reference_class(name):
     import importlib
     import sys
     full = 'alphazero.' + name
-    ours = sys.modules.get(full)
-    if ours is not None and not (getattr(ours, '__name__', '') or '').startswith(__name__):
-        _reference[name], _reference_mod[name] = getattr(ours, name, None), ours   # install() was never called: the name IS the reference's module
-        return _reference[name]
-    cls = None
-    try:
-        sys.modules.pop(full, None)
-        mod = importlib.import_module(full)
-        cls = getattr(mod, name, None)
-        _reference_mod[name] = mod
-    except Exception:                                          # noqa: BLE001 (no reference checkout, no pyximport, build failure)
+    with _reference_lock:                                      # (the swap below must not interleave with another thread's import of the name)
+        if name in _reference:
+            return _reference[name]
+        ours = sys.modules.get(full)
+        if ours is not None and not (getattr(ours, '__name__', '') or '').startswith(__name__):
+            _reference[name], _reference_mod[name] = getattr(ours, name, None), ours   # install() was never called: the name IS the reference's module
+            return _reference[name]
         cls = None
-    finally:
-        if ours is not None:
-            sys.modules[full] = ours
-            pkg = sys.modules.get('alphazero')
-            if pkg is not None:
-                setattr(pkg, name, ours)
-        # (install() was never called and the name was not imported yet: the reference's module simply stays imported)
-    _reference[name] = cls
-    return cls
+        try:
+            sys.modules.pop(full, None)
+            mod = importlib.import_module(full)
+            cls = getattr(mod, name, None)
+            _reference_mod[name] = mod
+        except Exception as ex:                                # noqa: BLE001 (no reference checkout, no pyximport, build failure)
+            cls = None
+            _reference_error[name] = ex                        # kept: the caller's NotImplementedError names the real cause
+        finally:
+            if ours is not None:
+                sys.modules[full] = ours
+                pkg = sys.modules.get('alphazero')
+                if pkg is not None:
+                    setattr(pkg, name, ours)
+            # (install() was never called and the name was not imported yet: the reference's module simply stays imported)
+        _reference[name] = cls
+        return cls
+
+
+def reference_import_error(name):
+    """why reference_class(name) returned None (the exception its import raised), or None"""
+    return _reference_error.get(name)
 
 
 class reference_module:

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                             AZG_TSTAMP(evl, slot, lane, 0);
                             return root_noise;
                         }, [&](int k, int ln, int &pos) {
-                            if (k > 64) return false;
+                            if (k > 64 || sa.ev.perm_tape) return false;
                             AZG_TSTAMP(evl, slot, lane, 2);
                             flag_wait_gen(sa.ev, &flags[1], sim);
                             AZG_TSTAMP(evl, slot, lane, 15);

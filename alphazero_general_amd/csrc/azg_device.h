@@ -82,6 +82,10 @@ struct View {
     int32_t add_noise, add_temp, symmetric, reset_thr, games_cap, max_hist;
     float cpuct, fpu_reduction, noise_frac, root_temp, arena_temp;
     uint64_t seed, slot_base;
+    // recorded shuffles (azg_set_shuffle_tape; null = the counter-based tape): ranks [B][perm_len] int16, the rank of child i of the
+    // expansion that starts at tape counter c is perm_tape[slot][c + i] -- the replay of np.random.shuffle permutations RECORDED from
+    // the reference running on its own MT19937 stream (np.random.seed(s)), MCTS.pyx:79
+    const int16_t *perm_tape; int32_t perm_len;
     unsigned long long *dbg;   // AZG_TREE_TIMING builds only: s_memtime stamps [B][16] of the last simulation of every slot
 };
 

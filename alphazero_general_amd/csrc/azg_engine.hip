@@ -33,6 +33,7 @@ struct azg_engine {
     View v;
     std::vector<void *> allocs;
     int32_t *d_p2i = nullptr, *d_ok = nullptr;
+    int16_t *d_perm = nullptr;                                 // azg_set_shuffle_tape
     bool profile = false;
     std::vector<EvPair> ev[3];
     double ms[3] = {0, 0, 0};
@@ -189,6 +190,7 @@ extern "C" int azg_engine_destroy(azg_engine *e) {
     prof_drain(e);
     for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void *p : e->allocs) (void)hipFree(p);
+    if (e->d_perm) (void)hipFree(e->d_perm);
     delete e;
     return AZG_OK;
 }
@@ -458,6 +460,20 @@ extern "C" int azg_engine_info(azg_engine *e, int32_t *out8) {
     return AZG_OK;
 }
 
+extern "C" int azg_set_shuffle_tape(azg_engine *e, void *stream, const int16_t *ranks_host, int len) {
+    if (!e || len < 0) return fail(AZG_E_INVALID_ARG, "null engine or negative length");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));
+    if (e->d_perm) { (void)hipFree(e->d_perm); e->d_perm = nullptr; }
+    e->v.perm_tape = nullptr; e->v.perm_len = 0;
+    if (!ranks_host || len == 0) return AZG_OK;
+    const size_t n = (size_t)e->v.B * (size_t)len;
+    HIPCHK(hipMalloc((void **)&e->d_perm, n * sizeof(int16_t)));
+    HIPCHK(hipMemcpy(e->d_perm, ranks_host, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    e->v.perm_tape = e->d_perm; e->v.perm_len = len;
+    return AZG_OK;
+}
+
 extern "C" int azg_set_root_flags(azg_engine *e, int flags) {
     if (!e || flags < 0) return fail(AZG_E_INVALID_ARG, "null engine or negative flags");
     e->v.add_noise = ((flags & AZG_FLAG_NOISE) && !e->v.arena) ? 1 : 0; e->v.add_temp = ((flags & AZG_FLAG_TEMP) && !e->v.arena) ? 1 : 0;
@@ -467,7 +483,9 @@ extern "C" int azg_set_root_flags(azg_engine *e, int flags) {
 // ---- snapshot of one slot's search state (pickling of the single-tree MCTS class: MCTS.pyx:8 auto_pickle) ----
 // layout: int64 magic, int32 game, T, maxd, pad | azg_state root, leaf | uint64 tape_ctr | per tree: TreeHdr, PathEnt[maxd], Node[alloc]
 static const int64_t k_snap_magic = 0x315A4E53475A41LL;     // "AZGSNZ1"
-struct SnapHead { int64_t magic; int32_t game, T, maxd, pad; azg_state root, leaf; uint64_t ctr; };
+struct SnapHead { int64_t magic; int32_t game, T, maxd, layout; azg_state root, leaf; uint64_t ctr; };
+// (layout: the record sizes and the ABI version the snapshot was written with -- a change of Node / TreeHdr / PathEnt invalidates old pickles)
+static const int32_t k_snap_layout = (int32_t)(sizeof(Node) | (sizeof(TreeHdr) << 8) | (sizeof(PathEnt) << 16) | ((unsigned)AZG_ABI_VERSION << 24));
 
 extern "C" int64_t azg_slot_export(azg_engine *e, void *stream, int slot, void *host_buf, int64_t nbytes) {
     int r = check_range(e, slot, 1); if (r) return r;
@@ -482,7 +500,7 @@ extern "C" int64_t azg_slot_export(azg_engine *e, void *stream, int slot, void *
     if (nbytes < need) return fail(AZG_E_INVALID_ARG, "snapshot buffer too small");
     char *o = (char *)host_buf;
     SnapHead sh; memset(&sh, 0, sizeof(sh));
-    sh.magic = k_snap_magic; sh.game = e->cfg.game; sh.T = T; sh.maxd = maxd;
+    sh.magic = k_snap_magic; sh.game = e->cfg.game; sh.T = T; sh.maxd = maxd; sh.layout = k_snap_layout;
     HIPCHK(hipMemcpy(&sh.root, e->v.states + slot, sizeof(azg_state), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&sh.leaf, e->v.leaf_states + slot, sizeof(azg_state), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&sh.ctr, e->v.tape_ctr + slot, sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -506,6 +524,7 @@ extern "C" int azg_slot_import(azg_engine *e, void *stream, int slot, const void
     SnapHead sh; memcpy(&sh, o, sizeof(sh)); o += sizeof(sh);
     if (sh.magic != k_snap_magic || sh.game != e->cfg.game || sh.T != e->v.T || sh.maxd != e->v.maxd)
         return fail(AZG_E_INVALID_ARG, "snapshot does not belong to this kind of engine (game / arena mode)");
+    if (sh.layout != k_snap_layout) return fail(AZG_E_INVALID_ARG, "snapshot was written by a library with another record layout / ABI version");
     {                                                        // validate the whole snapshot before anything is written
         const char *q = o;
         for (int t = 0; t < sh.T; t++) {
@@ -514,6 +533,24 @@ extern "C" int azg_slot_import(azg_engine *e, void *stream, int slot, const void
             if (h.alloc < 0 || h.alloc > e->v.cap) return fail(AZG_E_TREE_FULL, "snapshot holds more nodes than this engine's nodes_per_tree");
             q += sizeof(TreeHdr) + sizeof(PathEnt) * sh.maxd;
             if (end - q < (int64_t)sizeof(Node) * h.alloc) return fail(AZG_E_INVALID_ARG, "snapshot truncated");
+            // every index the kernels will follow must stay inside the live nodes: a corrupted or hand-made pickle must not become an
+            // out-of-bounds device access on the next find_leaf / process_results
+            const unsigned lk = h.leaf_info & 0xFFFFu;
+            if (h.depth < 0 || h.depth > sh.maxd || h.max_depth < 0 || h.leaf < LEAF_IS_ROOT || h.leaf >= h.alloc || h.leaf_fc < -1 ||
+                (h.leaf_fc >= 0 && (int64_t)h.leaf_fc + (int64_t)lk > h.alloc))
+                return fail(AZG_E_INVALID_ARG, "snapshot header points outside its nodes");
+            if (h.root.first_child < -1 || (h.root.first_child >= 0 && (int64_t)h.root.first_child + h.root.nchild > h.alloc))
+                return fail(AZG_E_INVALID_ARG, "snapshot root points outside its nodes");
+            const PathEnt *pe = reinterpret_cast<const PathEnt *>(q - sizeof(PathEnt) * sh.maxd);
+            for (int d = 0; d < h.depth; d++) {
+                PathEnt ent; memcpy(&ent, pe + d, sizeof(ent));
+                if ((int)(ent.idx_mover & 0x0FFFFFFFu) >= h.alloc) return fail(AZG_E_INVALID_ARG, "snapshot path points outside its nodes");
+            }
+            for (int i = 0; i < h.alloc; i++) {
+                Node nd; memcpy(&nd, q + sizeof(Node) * (size_t)i, sizeof(nd));
+                if (nd.first_child < -1 || (nd.first_child >= 0 && (int64_t)nd.first_child + nd.nchild > h.alloc))
+                    return fail(AZG_E_INVALID_ARG, "snapshot node points outside its nodes");
+            }
             q += sizeof(Node) * h.alloc;
         }
     }

@@ -67,7 +67,11 @@ AZG_DEV int add_children(const View &ev, int slot, Node *nodes, int &alloc, int 
     const int fc = alloc;
     if (fc + k > ev.cap) { if (lane == 0) raise_error(ev, AZG_E_TREE_FULL); return -1; }
     int pos[NC];
-    if (!(NC == 1 && ranks(k, lane, pos[0]))) {                              // (the two-wave launch has them ready)
+    if (ev.perm_tape) {                                                      // recorded shuffles replayed (see View::perm_tape)
+        if (ctr + (uint64_t)k > (uint64_t)ev.perm_len) { if (lane == 0) raise_error(ev, AZG_E_INVALID_ARG); return -1; }
+#pragma unroll
+        for (int c = 0; c < NC; c++) pos[c] = c * 64 + lane < k ? (int)ev.perm_tape[(size_t)slot * ev.perm_len + ctr + (uint64_t)(c * 64 + lane)] : 0;
+    } else if (!(NC == 1 && ranks(k, lane, pos[0]))) {                       // (the two-wave launch has them ready)
         uint64_t key[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) key[c] = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr + (uint64_t)(c * 64 + lane));
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(128) void k_backup_select2(View ev, const float *po
         flag_wait_gen(ev, &flags[0], 1); waited = true;                      // the previous leaf's priors are complete from here on
         return root_noise;                                                   // (the tape counter moved)
     }, [&](int k, int ln, int &pos) {                                        // ranks of the k new children
-        if (k > 64) return false;
+        if (k > 64 || ev.perm_tape) return false;
         flag_wait_gen(ev, &flags[1], 1);
         pos = __popcll(less_lds[ln] & (k == 64 ? ~0ULL : ((1ULL << k) - 1ULL)));
         return true;

@@ -86,6 +86,36 @@ def all_reduce_tallies(values, group=None):
     return t.cpu()
 
 
+def describe_ranks(local_rank, group=None):
+    """One record per rank, rank order -- which physical GPU every rank computes on (PCI bus id, name, CU count, memory), the
+    host and process, and the collective library's version -- so that an N-GPU line explains its own placement; and the check
+    that matters before any scaling number: two ranks on ONE device would still run (every rank then gets a share of it) and
+    report a curve that looks like poor scaling.  Raises RuntimeError unless AZG_SINGLE_DEVICE (the one-GPU test rig) is set."""
+    import socket
+    rec = {'rank': dist.get_rank(group) if dist.is_initialized() else 0, 'local_rank': int(local_rank), 'host': socket.gethostname(), 'pid': os.getpid()}
+    if torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(local_rank)
+        bus = '%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), getattr(p, 'pci_bus_id', -1) & 0xFF, getattr(p, 'pci_device_id', 0) & 0xFF)
+        rec.update(device=p.name, pci_bus_id=bus, uuid=str(getattr(p, 'uuid', '')), compute_units=p.multi_processor_count,
+                   memory_gb=round(p.total_memory / 2 ** 30, 1), visible_devices=os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES')))
+    try:
+        rec['rccl_version'] = '.'.join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:                                       # noqa: BLE001 (a build without the nccl bindings)
+        rec['rccl_version'] = None
+    recs = [rec]
+    if dist.is_initialized():
+        recs = [None] * dist.get_world_size(group)
+        dist.all_gather_object(recs, rec, group=group)
+    seen = {}
+    for r in recs:
+        key = (r['host'], r.get('pci_bus_id'), r.get('uuid'))
+        if 'pci_bus_id' in r and key in seen and not os.environ.get('AZG_SINGLE_DEVICE'):
+            raise RuntimeError('ranks %d and %d share one GPU (%s on %s): one process per GPU -- check LOCAL_RANK / HIP_VISIBLE_DEVICES'
+                               % (seen[key], r['rank'], r['pci_bus_id'], r['host']))
+        seen[key] = r['rank']
+    return recs
+
+
 def max_over_ranks(x, group=None):
     if not dist.is_initialized():
         return float(x)

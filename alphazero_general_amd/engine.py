@@ -116,6 +116,16 @@ class DeviceEngine:
         _abi.check(self.L.azg_get_tape_counters(self.h, _stream(), 0, self.B, out))
         return np.array(out[:], np.uint64)
 
+    def set_shuffle_tape(self, ranks):
+        """replay RECORDED child shuffles instead of the counter-based tape (azg_set_shuffle_tape): ranks int16 [B, L], the rank of
+        child i of the expansion that starts at tape counter c of slot s = ranks[s, c + i]; None: back to the counter-based tape."""
+        if ranks is None:
+            _abi.check(self.L.azg_set_shuffle_tape(self.h, _stream(), None, 0))
+            return
+        r = np.ascontiguousarray(ranks, np.int16)
+        assert r.ndim == 2 and r.shape[0] == self.B
+        _abi.check(self.L.azg_set_shuffle_tape(self.h, _stream(), r.ctypes.data_as(C.c_void_p), int(r.shape[1])))
+
     def set_tape_counters(self, ctr, first=0):
         arr = (C.c_uint64 * len(ctr))(*[int(c) for c in ctr])
         _abi.check(self.L.azg_set_tape_counters(self.h, _stream(), first, len(ctr), arr))

@@ -16,7 +16,10 @@ from .Game import azg_game_id
 from .utils import AGENT_STREAM, default_temp_scaling
 
 
-SEARCH_HEADS_DEFAULT = 'sparse'                                        # (SelfPlayRunner(search_heads=...))
+# The persistent launch of a wide-head network hands the tree NNetWrapper.process's own bits by default ('exact': visit counts and pi
+# bit-exact against the reference's evaluation, BASELINE north_star); 'sparse' (the logits of the valid actions only: equal to rounding,
+# 10-35 % faster by shard size) is the opt-in: SelfPlayRunner(search_heads='sparse')
+SEARCH_HEADS_DEFAULT = 'exact'
 
 
 class _Lane:
@@ -38,10 +41,11 @@ class SelfPlayRunner:
     def __init__(self, game_cls, nnet, args, *, num_slots, seed=0, slot_base=0, device=None, example_capacity=None,
                  use_graph=True, obs_dtype=torch.float16, warmup=False, pipelines=1, round_graph=None, result_capacity=None,
                  fused_search=None, heads=None, nodes_per_tree=0, search_heads=None):
-        """heads: what the tree launch is fed when the search is launched per phase -- None picks the cheapest form the network
-        offers ('features' for factorised heads: the launch computes the logits of the valid actions itself; 'logits' for other
-        wide heads: softmax inside the launch; else 'probs'); tests pin each form against the oracle.  nodes_per_tree: node
-        store of a tree (0 = the library's default, include/azg.h)."""
+        """heads: what the tree launch is fed when the search is launched per phase -- None follows search_heads ('exact', the default:
+        'logits' for wide heads -- all A + P+1 logits, softmax inside the tree launch --, else 'probs'; 'sparse': 'features' for
+        factorised heads -- the launch computes the logits of the valid actions itself); tests pin each form against the oracle.
+        search_heads: the same choice for the persistent launch of a factorised-heads network.  nodes_per_tree: node store of a tree
+        (0 = the library's default, include/azg.h)."""
         assert heads in (None, 'probs', 'logits', 'features')
         # the persistent launch of a factorised-heads network: 'exact' = all A + P+1 logits inside the launch (NNetWrapper.process's bits),
         # 'sparse' = only the logits of each leaf's valid actions (equal to rounding)
@@ -156,6 +160,8 @@ class SelfPlayRunner:
         e.select(ln.obs)
         logits_path = not self.warmup and ln.net.run_logits is not None    # wide heads: softmax inside the tree launch
         feat_path = not self.warmup and getattr(ln.net, 'run_features', None) is not None   # factorised: the heads too
+        if feat_path and logits_path and self.search_exact:       # (the default hand-over is the exact one in every launch form)
+            feat_path = False
         if self.heads is not None and not self.warmup:
             if (self.heads == 'features' and not feat_path) or (self.heads == 'logits' and not logits_path):
                 raise NotImplementedError('this network has no %s hand-over to the tree launch' % self.heads)

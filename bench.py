@@ -65,6 +65,9 @@ WORKLOADS = {
 }
 
 
+WORKLOAD_TOTAL_GAMES = {'brandubh': 4096, 'trimok': 1024, 'arena': 512}              # BASELINE.json configs 3, 5, 4 (whole job)
+
+
 def selfplay_args(W, games=1 << 30):
     return dotdict(cpuct=W['cpuct'], fpu_reduction=W['fpu'], root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0,
                    numMCTSSims=W['sims'], numFastSims=20, numWarmupSims=5, probFastSim=0.0, gamesPerIteration=games,
@@ -232,19 +235,21 @@ def self_launch(n):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode
+    # (NCCL_DEBUG=VERSION: RCCL prints its version line once on stderr -- the first thing to read when an N-GPU run misbehaves)
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                                        NCCL_DEBUG=os.environ.get('NCCL_DEBUG', 'VERSION'))).returncode
 
 
 class Ctx:
     """one workload set up on this rank's GPU: runner, network(s), engines"""
 
 
-def build(workload, a, rank, local_rank, dev, rounds):
+def build(workload, a, rank, local_rank, dev, rounds, slots=0, search_heads=None):
     import importlib
     c = Ctx()
     c.name = workload
     c.W = W = dict(WORKLOADS[workload])
-    c.B = W['B'] = (a.slots if workload == a.workload else 0) or W['B']
+    c.B = W['B'] = slots or (a.slots if workload == a.workload else 0) or W['B']
     c.sims = W['sims']
     c.Game = Game = importlib.import_module('alphazero_general_amd.envs.' + W['game']).Game
     netargs = getattr(nn_mod, W['net'])
@@ -263,6 +268,7 @@ def build(workload, a, rank, local_rank, dev, rounds):
         c.engines = [c.runner.engine]
         c.counters = c.runner.engine.counters
         c.fused_search = False
+        c.search_heads = None
     else:
         torch.manual_seed(0)                                         # same random-init weights on every rank
         c.net = NNetWrapper(Game, netargs, device=dev, dtype=torch.float16)
@@ -270,11 +276,12 @@ def build(workload, a, rank, local_rank, dev, rounds):
         per_game = (Game.max_turns() + 1) * nsym
         c.runner = SelfPlayRunner(Game, c.net, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
                                   use_graph=not a.no_graph, pipelines=c.pipelines,
-                                  fused_search=False if (a.no_fused_search or c.pipelines > 1) else None, search_heads=a.search_heads,
+                                  fused_search=False if (a.no_fused_search or c.pipelines > 1) else None, search_heads=search_heads or a.search_heads,
                                   example_capacity=int(c.B * rounds / 5.0 + 2 * c.B) * per_game)
         c.engines = [ln.engine for ln in c.runner.lanes]
         c.counters = c.runner.counters
         c.fused_search = bool(c.runner.fused_search)
+        c.search_heads = ('exact' if c.runner.search_exact else 'sparse') if (c.fused_search and c.net._hip is not None and c.net._hip.fact_head) else None
         c.runner.prepare()                                           # graph capture stays out of the timed region even at --warmup 0
     return c
 
@@ -392,7 +399,8 @@ def rooflines(c, netprof, prof):
             r['executed_frac'] = round(ex / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
         return r
 
-    skind = ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else ('Wide', W['game'], 'azg_search_wide_f16')
+    skind = ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else \
+        ('Wide', W['game'], 'azg_search_wide_exact_f16' if c.search_heads == 'exact' else 'azg_search_wide_f16')
     roof_search = mfma_roof('search', 'k_tower2<...,Search%s<%s>> (%s: %d x [find_leaf, ResNet + heads, backup] on every game, one persistent launch '
                             'per move)' % (skind + (sims,)), 'Search' + skind[0] + '<', Bl * sims)
     roof_net = mfma_roof('tower', 'k_tower2 (%s, one launch per simulation)' % ('both models on their row ranges' if arena else 'ResNet tower'
@@ -424,30 +432,29 @@ def rooflines(c, netprof, prof):
     return roofline, roof_tree, roof_net
 
 
-def exact_heads_run(c, a, rank, local_rank, dev, world, steps=8, warmup=2):
-    """configs 3 and 5 once more with the BIT-EXACT hand-over between network and tree: full-width heads (k_heads_fact: all A logits,
-    what NNetWrapper.process computes) -> azg_backup_select_logits (softmax over all A, mask, renormalise: MCTS.pyx:239-245), one
-    tower launch + one heads launch + one tree launch per simulation, the round replayed as one hipGraph.  The timed sparse-heads
-    launch equals this to rounding only; this is what "pi bit-exact against NNetWrapper.process" costs."""
+def sparse_heads_run(c, a, rank, local_rank, dev, world, steps=8, warmup=2):
+    """configs 3 and 5 once more with the OPT-IN sparse heads (SelfPlayRunner(search_heads='sparse'), azg_search_wide_f16): the tree
+    phase computes only the logits of each leaf's valid actions and takes the softmax over those -- equal to the default exact
+    launch (all A + P+1 logits inside the launch: NNetWrapper.process's bits, MCTS.pyx:239-245) to rounding only (~1e-8 on a prior;
+    a PUCT near-tie flips about once per 5e5 simulations) -- and saves the stream of the full head matrix."""
     hip = c.net._hip
-    if c.arena or hip is None or not hip.fact_head:
+    if c.arena or hip is None or not hip.fact_head or c.search_heads != 'exact':
         return None
     args = selfplay_args(c.W)
     nsym = len(c.Game().symmetries(np.zeros(c.Game.action_size(), np.float32)))
     x = Ctx()
-    x.name, x.W, x.B, x.sims, x.Game, x.net, x.nets, x.arena, x.pipelines = c.name + '_exact', c.W, c.B, c.sims, c.Game, c.net, c.nets, False, 1
+    x.name, x.W, x.B, x.sims, x.Game, x.net, x.nets, x.arena, x.pipelines = c.name + '_sparse', c.W, c.B, c.sims, c.Game, c.net, c.nets, False, 1
     x.runner = SelfPlayRunner(c.Game, c.net, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
-                              use_graph=not a.no_graph, heads='logits',
+                              use_graph=not a.no_graph, search_heads='sparse',
                               example_capacity=int(c.B * (steps + warmup) / 5.0 + 2 * c.B) * (c.Game.max_turns() + 1) * nsym)
     x.engines = [ln.engine for ln in x.runner.lanes]
     x.counters = x.runner.counters
-    x.fused_search = False
+    x.fused_search = bool(x.runner.fused_search)
     x.runner.prepare()
     t = timed_region(x, steps, warmup, world, rank)
     out = {'value': round(t['expansions'] / t['dt'], 1), 'unit': 'expansions/s', 'ms_per_step': round(t['dt'] * 1e3 / steps, 3), 'steps': steps,
-           'warmup': warmup, 'form': 'per simulation: k_tower2 (+ 1x1 head convs) -> k_heads_fact (all %d + %d logits) -> k_backup_select2<IN_LOGITS> '
-                                      '(softmax over all A, mask, renormalise); bit-exact against NNetWrapper.process + MCTS.pyx:239-245'
-                                      % (c.Game.action_size(), c.Game.num_players() + 1)}
+           'warmup': warmup, 'form': 'azg_search_wide_f16: the same persistent launch, policy logits of the leaf\'s valid actions only (softmax over '
+                                      'those); equal to the exact launch to rounding, not bit for bit'}
     for e in x.engines:
         e.close()
     return out
@@ -595,7 +602,9 @@ def main():
     ap.add_argument('--compat', action='store_true', help='also time compat mode (unmodified-Coach protocol: SelfPlayAgent processes served by the parent)')
     ap.add_argument('--search-heads', default=None, choices=['exact', 'sparse'],
                     help='wide-head workloads, persistent launch: all A + P+1 logits inside the launch (bit-exact) or the valid actions only')
-    ap.add_argument('--no-exact-heads', action='store_true', help='skip the bit-exact full-width-heads run of the wide-head workloads')
+    ap.add_argument('--no-exact-heads', '--no-sparse-heads', dest='no_sparse_heads', action='store_true',
+                    help='skip the second run of the wide-head workloads with the opt-in sparse heads')
+    ap.add_argument('--no-shards', action='store_true', help='skip the 1 / 2 / 4-GPU shard sizes of configs 3-5 on the default line')
     a = ap.parse_args()
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -607,11 +616,12 @@ def main():
         assert torch.cuda.device_count() >= world, '%d ranks but only %d visible GPU(s)' % (world, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    rank_devices = D.describe_ranks(local_rank)                       # (raises if two ranks share a GPU; the records go on the line)
 
     c = build(a.workload, a, rank, local_rank, dev, a.steps + a.warmup + a.profile_rounds + 8)
     t = timed_region(c, a.steps, a.warmup, world, rank)
     netprof, prof = profile_rounds(c, a.profile_rounds)              # after the timed region
-    ex = None if a.no_exact_heads else exact_heads_run(c, a, rank, local_rank, dev, world)   # (every rank: it has its own exchange step)
+    ex = None if a.no_sparse_heads else sparse_heads_run(c, a, rank, local_rank, dev, world)   # (every rank: it has its own exchange step)
     if rank != 0:
         return 0
     roofline, roof_tree, roof_net = rooflines(c, netprof, prof)
@@ -622,8 +632,9 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 tree / f16 net', 'data': 'synthetic',
         'config': {'workload': workload_label(c),
                    'games_per_gpu': c.B, 'sims_per_move': c.sims, 'hipgraph_rounds': not a.no_graph, 'stream_pipelines': a.pipelines,
-                   'fused_search_launch': c.fused_search, 'mfma_tower': c.net._hip is not None, 'ranks': world,
-                   'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
+                   'fused_search_launch': c.fused_search, 'search_heads': c.search_heads, 'mfma_tower': c.net._hip is not None, 'ranks': world,
+                   'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                   'rank_devices': rank_devices},
         'games_per_sec': round(t['games'] / dt, 2), 'simulations_per_sec': round(t['sims'] / dt, 1),
         'games_finished': t['games'], 'samples_gathered': t['samples'],
         # (all games start from the empty board: the whole-region figure includes the first burst of finishes)
@@ -641,7 +652,7 @@ def main():
     if pbud is not None:
         roofline['phase_budget'] = pbud
     if ex is not None:
-        out['exact_heads'] = ex
+        out['sparse_heads'] = ex
     if world == 1 and roofline is not None and roofline['bound'] == 'mfma' and not a.no_library_gemm:
         lib_tf = library_gemm_tflops(dev)                            # outside the timed region
         roofline['library_gemm_tflops'] = round(lib_tf, 1)
@@ -660,17 +671,17 @@ def main():
                 onp, opf = profile_rounds(oc, 1)
                 orf, otr, _ = rooflines(oc, onp, opf)
                 opb = phase_budget(oc, orf)
-                oex = None if a.no_exact_heads else exact_heads_run(oc, a, rank, local_rank, dev, world)
+                oex = None if a.no_sparse_heads else sparse_heads_run(oc, a, rank, local_rank, dev, world)
                 others[name] = {'workload': workload_label(oc), 'value': round(ot['expansions'] / ot['dt'], 1), 'unit': 'expansions/s',
                                 'games_per_sec': round(ot['games'] / ot['dt'], 2), 'steps': 8, 'warmup': 2,
-                                'ms_per_step': round(ot['dt'] * 1e3 / 8, 3), 'fused_search_launch': oc.fused_search,
+                                'ms_per_step': round(ot['dt'] * 1e3 / 8, 3), 'fused_search_launch': oc.fused_search, 'search_heads': oc.search_heads,
                                 'roofline': None if orf is None else {k: orf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
                                                                                              'executed_frac', 'avg_launch_us', 'launches_timed', 'traffic')},
                                 'tree_launch_us': None if otr is None else otr['avg_launch_us']}
                 if opb is not None:
                     others[name]['phase_budget'] = opb
                 if oex is not None:
-                    others[name]['exact_heads'] = oex
+                    others[name]['sparse_heads'] = oex
                 release(oc)
             except Exception as ex:                                  # noqa: BLE001
                 others[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
@@ -683,6 +694,27 @@ def main():
         except Exception as ex:                                      # noqa: BLE001
             others['compat'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
         out['other_workloads'] = others
+        if not a.no_shards:
+            # BASELINE's metric is "at 1/2/4/8 MI355X" and configs 3-5 name TOTAL games: their 1- / 2- / 4-GPU points are larger shards
+            # per GPU (config 3: 4096 / 2048 / 1024 brandubh games, config 5: 1024 / 512, config 4: 512).  Each timed here on ONE GPU, 4
+            # graph-replayed rounds after 1 warm-up round (the shard sizes in other_workloads above are the 8- / 4- / 2-GPU points)
+            shards = {}
+            for name, sizes in (('brandubh', (4096, 2048, 1024)), ('trimok', (1024, 512)), ('arena', (512,))):
+                for Bs in sizes:
+                    key = '%s_%d' % (name, Bs)
+                    try:
+                        oc = build(name, a, rank, local_rank, dev, 4 + 1 + 1 + 8, slots=Bs)
+                        ot = timed_region(oc, 4, 1, world, rank)
+                        onp, opf = profile_rounds(oc, 1)
+                        orf, _, _ = rooflines(oc, onp, opf)
+                        shards[key] = {'workload': workload_label(oc), 'games_per_gpu': Bs, 'gpus_at_this_shard_size': WORKLOAD_TOTAL_GAMES[name] // Bs,
+                                       'value': round(ot['expansions'] / ot['dt'], 1), 'unit': 'expansions/s', 'games_per_sec': round(ot['games'] / ot['dt'], 2),
+                                       'steps': 4, 'warmup': 1, 'ms_per_step': round(ot['dt'] * 1e3 / 4, 3), 'search_heads': oc.search_heads,
+                                       'roofline': None if orf is None else {k: orf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'launches_timed')}}
+                        release(oc)
+                    except Exception as ex:                          # noqa: BLE001
+                        shards[key] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+            out['strong_scaling_shards'] = shards
     elif world == 1 and a.compat and not c.arena:
         out['compat'] = compat_run(c.W, c.net)
     print(json.dumps(out))

@@ -366,6 +366,16 @@ uint64_t azg_tape_u64(uint64_t seed, uint64_t stream, uint64_t ctr);
 double   azg_tape_uniform(uint64_t seed, uint64_t stream, uint64_t ctr);
 void     azg_tape_shuffle_pos(uint64_t seed, uint64_t stream, uint64_t ctr, int k, int32_t *pos);
 
+/* "Identical seeds", literally (second tier): Node.add_children shuffles with np.random.shuffle on numpy's global MT19937
+ * stream (MCTS.pyx:76-79).  The engine's own shuffles come from the counter-based tape; this call makes the engine REPLAY recorded
+ * permutations instead: ranks_host int16 [num_slots][len], where the rank (position in the shuffled list) of child i -- children in
+ * ascending action order -- of the expansion that begins at tape counter c of a slot is ranks_host[slot][c + i] (the counter advances
+ * by the number of children per expansion, so a slot's recorded permutations are simply concatenated in expansion order).  The
+ * fixtures under tests/golden/c4_mt19937.npz were recorded from the reference running under np.random.seed(s) with np.random.shuffle
+ * observed, not replaced.  ranks_host == NULL or len == 0: back to the counter-based tape.  An expansion past the end of the tape
+ * raises the sticky AZG_E_INVALID_ARG.  Root noise (np.random.dirichlet) is not replayed: use with add_root_noise = 0. */
+int  azg_set_shuffle_tape(azg_engine *e, void *stream, const int16_t *ranks_host, int len);
+
 #ifdef __cplusplus
 }
 #endif

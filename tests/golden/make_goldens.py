@@ -5,6 +5,7 @@ Outputs (small .npz fixtures, committed):
   c4_rules.npz   connect4 rule tables: random playouts -> valid_moves / board / win_state / observation
   c4_tree.npz    single-tree MCTS traces (find_leaf paths, per-sim root stats, counts / probs / value)
   c4_agent.npz   SelfPlayAgent lock-step self-play traces (actions, leaf-obs checksums, samples, results)
+  c4_mt19937.npz MCTS.search under np.random.seed(s) on numpy's own MT19937 stream: recorded child shuffles + counts / pi (second tier)
 Every run of the reference is under the random tape (refharness.Tape) and the synthetic evaluator
 (oracle azo_fake_eval), so the fixtures hold seeds + expected outputs only.
 """
@@ -177,6 +178,92 @@ def gen_tree(game_cls, game_id, name, n_roots, seed=7, configs=TREE_CONFIGS, max
     out['prob_temps'] = np.array(PROB_TEMPS, np.float32)
     np.savez_compressed(os.path.join(OUT, name + '_tree.npz'), **out)
     print('%s_tree: %d roots x %s' % (name, n_roots, [c[0] for c in configs]))
+
+
+def gen_c4_mt19937(n_roots=64, sims=100, seed=20250929, eval_seed=77):
+    """The MT19937 tier of "identical seeds" (SURVEY.md 8c): the reference's MCTS.search on connect4 under np.random.seed(seed) with
+    numpy's global legacy stream UNTOUCHED -- np.random.shuffle is observed (the real function is called, its result recorded), not
+    replaced.  Per root: the recorded permutations (rank of every child, children in ascending action order, expansions concatenated
+    in order), then counts / probs / root children / values.  tests/test_oracle_golden.py checks on the CPU that the recorded ranks
+    ARE what np.random.RandomState(seed).shuffle produces for lists of those lengths in that order; tests/test_gpu_parity.py replays
+    them on the device (azg_set_shuffle_tape)."""
+    from alphazero.MCTS import MCTS
+    from alphazero.envs.connect4.connect4 import Game
+    A, NV = 7, 3
+    rng = np.random.RandomState(4321)
+    prefixes = []
+    for r in range(n_roots):
+        g = Game(); seq = []
+        for _ in range(0 if r == 0 else rng.randint(0, 30)):
+            v = np.flatnonzero(np.asarray(g.valid_moves()))
+            a = int(rng.choice(v))
+            g2 = g.clone(); g2.play_action(a)
+            if np.asarray(g2.win_state()).any():
+                break
+            g = g2; seq.append(a)
+        prefixes.append(seq)
+    PL = max(len(p) for p in prefixes) + 1
+    pre = np.full((n_roots, PL), -1, np.int16)
+    for r, p in enumerate(prefixes):
+        pre[r, :len(p)] = p
+    args = rh.ref_args(Game, cpuct=1.25, fpu_reduction=0.2)
+    real_shuffle = np.random.shuffle
+    log = []
+
+    def observed(lst):
+        before = list(lst)
+        real_shuffle(lst)                                   # the reference's own draw from the global MT19937 stream
+        pos = [-1] * len(before)
+        for new_i, obj in enumerate(lst):
+            for old_i, b in enumerate(before):
+                if b is obj:
+                    pos[old_i] = new_i
+        assert sorted(pos) == list(range(len(before)))
+        log.append(pos)
+    ranks, lens, fin = [], [], {k: [] for k in ('a', 'n', 'q', 'p', 'v', 'counts', 'probs1', 'probs0', 'vmax', 'vavg', 'root_n', 'maxdepth')}
+    np.random.seed(seed)
+    np.random.shuffle = observed
+    try:
+        for r in range(n_roots):
+            g = Game()
+            for a in prefixes[r]:
+                g.play_action(a)
+            m = MCTS(args)
+            step = [0]
+
+            def nn(obs, r=r, step=step):
+                p, v = ol.fake_eval(eval_seed, r, step[0], A, NV)
+                step[0] += 1
+                return p, v
+            del log[:]
+            m.search(g, nn, sims, False, False)                 # MCTS.pyx:165-173
+            assert step[0] == sims
+            ranks.append([x for perm in log for x in perm]); lens.append([len(perm) for perm in log])
+            ch = m._root._children
+            fin['a'].append(np.array([c.a for c in ch] + [-1] * (A - len(ch)), np.int16))
+            fin['n'].append(np.array([c.n for c in ch] + [0] * (A - len(ch)), np.int32))
+            for f in ('q', 'p', 'v'):
+                fin[f].append(np.array([getattr(c, f) for c in ch] + [0] * (A - len(ch)), np.float32))
+            fin['counts'].append(np.asarray(m.counts(g)).astype(np.int32))
+            fin['probs1'].append(np.asarray(m.probs(g, 1.0), np.float32)); fin['probs0'].append(np.asarray(m.probs(g, 0), np.float32))
+            fin['vmax'].append(m.value(False)); fin['vavg'].append(m.value(True))
+            fin['root_n'].append(m._root.n); fin['maxdepth'].append(m.max_depth)
+    finally:
+        np.random.shuffle = real_shuffle
+    L = max(len(x) for x in ranks)
+    tape = np.zeros((n_roots, L), np.int16)
+    for r, x in enumerate(ranks):
+        tape[r, :len(x)] = x
+    NE = max(len(x) for x in lens)
+    klen = np.zeros((n_roots, NE), np.int16)
+    for r, x in enumerate(lens):
+        klen[r, :len(x)] = x
+    out = dict(prefix=pre, seed=np.uint64(seed), eval_seed=np.uint64(eval_seed), sims=np.int32(sims), cfg=np.array([1.25, 0.2], np.float64),
+               ranks=tape, expansion_children=klen)
+    for k, v in fin.items():
+        out[k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, 'c4_mt19937.npz'), **out)
+    print('c4_mt19937: %d roots x %d sims under np.random.seed(%d), %d recorded shuffles' % (n_roots, sims, seed, sum(len(x) for x in lens)))
 
 
 # ------------------------------------------------------------------------------------------------ agent
@@ -428,6 +515,8 @@ def main():
         gen_agent(C4, ol.GAME_CONNECT4, 'c4')
     if 'c4_arena' in which:
         gen_arena(C4, ol.GAME_CONNECT4, 'c4')
+    if 'c4_mt19937' in which:
+        gen_c4_mt19937()
     if 'c4_net' in which:
         gen_net()
     if 'c4_ckpt' in which:

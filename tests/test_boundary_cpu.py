@@ -43,6 +43,34 @@ def test_compat_agent_fails_fast_when_the_device_side_cannot_start():
     ag._stop_worker()
 
 
+def test_compat_agent_rendezvous_survives_a_long_tmpdir(tmp_path, monkeypatch):
+    """an AF_UNIX path holds ~107 bytes: under a long TMPDIR the rendezvous socket moves to /tmp instead of failing in bind with an
+    OSError about the path; the hand-shake then proceeds as usual (here: up to the worker reporting that there is no GPU), and the
+    temporary socket directory is removed either way."""
+    import glob
+    import tempfile
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import torch.multiprocessing as mp
+    from alphazero_general_amd.SelfPlayAgent import SelfPlayAgent
+    from alphazero_general_amd.envs.connect4 import Game
+    deep = tmp_path / ('d' * 60) / ('e' * 60)
+    deep.mkdir(parents=True)
+    monkeypatch.setenv('TMPDIR', str(deep))
+    monkeypatch.setattr(tempfile, 'tempdir', None)               # (tempfile caches the directory)
+    assert len(tempfile.gettempdir()) > 110
+    before = set(glob.glob('/tmp/azg-agent-*'))
+    bt = torch.zeros((4,) + tuple(Game.observation_size()))
+    ag = SelfPlayAgent(0, Game, mp.Queue(), mp.Event(), bt, torch.zeros(4, 7), torch.zeros(4, 3), mp.Queue(), mp.Queue(), mp.Value('i', 0),
+                       mp.Value('i', 0), mp.Event(), mp.Event(), _args())
+    with pytest.raises(RuntimeError, match='device engine worker failed to start'):
+        ag._start_worker()
+    ag._stop_worker()
+    assert set(glob.glob('/tmp/azg-agent-*')) == before and not list(deep.iterdir())
+    monkeypatch.setattr(tempfile, 'tempdir', None)
+
+
 def test_tower_weight_buffer_contract():
     """azg_tower_weights_size = stem + layers + the slack the prefetch ring may read; the slack covers the k-split tile's ring
     (conv_main2<WR = 9, KSTR = 2>: 16 k-steps past the last layer)."""

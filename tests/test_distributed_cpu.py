@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -73,6 +74,50 @@ def test_gloo_allgather_examples_world2():
         assert r[4].shape == (n0 + n1, 3)
         assert r[5][1] == n0 + n1 and r[6] == 2.0
     assert (res[0][2] == res[1][2]).all()
+
+
+def _worker_unequal(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from alphazero_general_amd import distributed as D
+    D.init_from_env(backend='gloo')
+    n = [0, 1, 0, 977][rank] if world == 4 else 0
+    g = torch.Generator().manual_seed(100 + rank)
+    obs, pi, z = torch.rand((n, 5, 7, 7), generator=g), torch.rand((n, 588), generator=g), torch.rand((n, 3), generator=g)
+    outs = []
+    for rnd in range(2):                                     # twice: the second iteration's exchange reuses the group
+        gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
+        outs.append((gobs.numpy(), gpi.numpy(), gz.numpy()))
+    tall = D.all_reduce_tallies([n, rank])
+    recs = D.describe_ranks(rank)
+    D.barrier()
+    q.put((rank, obs.numpy(), outs, tall.numpy(), [r['rank'] for r in recs]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 3])
+def test_gloo_allgather_with_empty_and_lopsided_shards(world):
+    """the exchange step after a SHORT iteration: ranks that finished no game at all (n_i = 0, first and in the middle), one with a single
+    sample, one holding nearly everything -- and every rank empty (world 3: the padded gather of zero rows).  Rank order and each
+    rank's own order are kept, empty ranks contribute nothing, the tallies add up, describe_ranks returns one record per rank."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unequal, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.concatenate([r[1] for r in res])
+    total = want.shape[0]
+    assert total == (978 if world == 4 else 0)
+    for r in res:
+        for gobs, gpi, gz in r[2]:
+            assert gobs.shape == (total, 5, 7, 7) and gpi.shape == (total, 588) and gz.shape == (total, 3)
+            assert (gobs == want).all()
+        assert r[3][0] == total and r[3][1] == sum(range(world)) and r[4] == list(range(world))
 
 
 def test_sharding_invariance_oracle():

@@ -64,10 +64,9 @@ def test_mcts_pickle_round_trip_continues_bit_for_bit():
 
 @pytest.mark.parametrize('game', ['connect4', 'brandubh', 'trimok'])
 def test_mcts_search_on_the_persistent_launch(game):
-    """MCTS.search(gs, nn, sims, noise, temp) with nn = this package's NNetWrapper: ONE launch per call.  connect4: the same tree as
-    the find_leaf / nn(obs) / process_results loop, bit for bit, noise and temperature flags honoured per call.  Sparse-heads
-    networks: the loop form evaluates full-width heads, so the trees agree to rounding -- the visit counts of a 64-simulation
-    search must match on (almost) every action; the exact statement for them is tests/test_gpu_benchsize_oracle.py."""
+    """MCTS.search(gs, nn, sims, noise, temp) with nn = this package's NNetWrapper: ONE launch per call, the same tree as the
+    find_leaf / nn(obs) / process_results loop bit for bit -- connect4's fused heads and the wide-head networks' exact launch
+    (azg_search_wide_exact_f16: all A + P+1 logits inside the launch) alike --, noise and temperature flags honoured per call."""
     import importlib
     import torch
     from alphazero_general_amd import nnet as N
@@ -92,17 +91,50 @@ def test_mcts_search_on_the_persistent_launch(game):
         assert calls[0] - n0 == 64
         cf, cs = fast.counts(g), slow.counts(g)
         assert cf.sum() == cs.sum() == fast._root.n - 1
-        if game == 'connect4':
-            assert (cf == cs).all(), mv
-            assert (fast.probs(g, 1.0) == slow.probs(g, 1.0)).all() and fast.value() == slow.value()
-            assert (fast.depth, fast.max_depth) == (slow.depth, slow.max_depth)
-            assert (fast._engine.tape_counters() == slow._engine.tape_counters()).all()
-        else:
-            assert np.abs(cf - cs).sum() <= 4, (mv, cf, cs)
+        assert (cf == cs).all(), (mv, cf, cs)
+        assert (fast.probs(g, 1.0) == slow.probs(g, 1.0)).all() and fast.value() == slow.value()
+        assert (fast.depth, fast.max_depth) == (slow.depth, slow.max_depth)
+        assert (fast._engine.tape_counters() == slow._engine.tape_counters()).all()
         a = slow.best_action(g)
         fast.update_root(g, a); slow.update_root(g, a)
         g.play_action(a)
     assert fast._persistent_net(net, fast._engine) is net._hip and fast._persistent_net(plain, fast._engine) is None
+
+
+def test_mcts_search_splits_the_launch_when_the_store_is_small():
+    """a persistent launch cannot compact in the middle: MCTS.search hands it as many simulations as are sure to fit the node store and
+    reclaims the dropped siblings between launches.  An object whose store holds less than one call's worth of expansions (brandubh:
+    96 nodes per expansion at most) must grow the same tree, move after move, as one with the default store -- and the engine's
+    default root flags are what they were before the call."""
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.MCTS import MCTS
+    from alphazero_general_amd.envs.brandubh import Game
+    torch.manual_seed(5)
+    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    small, big = MCTS(_args(numMCTSSims=120, _azg_nodes_per_tree=96 * 90)), MCTS(_args(numMCTSSims=120))   # (a call may add 120 x 96 nodes; it adds ~5 000)
+    g = Game()
+    launches = [0]
+    hip = (net.refresh() or True) and net._hip
+    orig = hip.search
+
+    def counting(e, sims, exact=False):
+        launches[0] += e is small._engine
+        return orig(e, sims, exact=exact)
+    hip.search = counting
+    try:
+        for mv in range(5):
+            small.search(g, net, 120, mv == 0, mv == 0)
+            big.search(g, net, 120, mv == 0, mv == 0)
+            assert (small.counts(g) == big.counts(g)).all(), mv
+            assert (small.probs(g, 1.0) == big.probs(g, 1.0)).all()
+            assert (small._engine.tape_counters() == big._engine.tape_counters()).all()
+            a = big.best_action(g)
+            small.update_root(g, a); big.update_root(g, a)
+            g.play_action(a)
+    finally:
+        hip.search = orig
+    assert launches[0] > 5                                       # (the small store needed more than one launch per call)
 
 
 def test_mcts_node_store_budget():
@@ -148,6 +180,30 @@ def test_slot_snapshot_is_checked_on_import():
         other.import_slot(blob, 0)
     with pytest.raises(_abi.AzgError):
         b.import_slot(blob[:200], 0)
+    # a snapshot whose indices point outside its own nodes (corrupted, hand-made, or written by a library with another record layout)
+    # must be refused before anything is written -- not imported and searched into an out-of-bounds device access
+    import struct
+    head = 8 + 4 * 4 + 80 * 2 + 8                                  # SnapHead: magic, game / T / maxd / layout, root and leaf state, tape counter
+    bad = bytearray(blob)
+    struct.pack_into('<i', bad, head + 32 + 8, 10 ** 6)             # TreeHdr.depth far beyond max_turns + 2
+    with pytest.raises(_abi.AzgError):
+        b.import_slot(bytes(bad), 0)
+    bad = bytearray(blob)
+    struct.pack_into('<i', bad, head + 16, used + 5)                # the root's first_child + nchild past the live nodes
+    with pytest.raises(_abi.AzgError):
+        b.import_slot(bytes(bad), 0)
+    bad = bytearray(blob)
+    node0 = head + 64 + 16 * 44                                     # TreeHdr, then PathEnt[max_turns + 2 = 44], then the nodes
+    struct.pack_into('<i', bad, node0 + 32 * 3 + 16, used)          # node 3's child block starts past the end
+    struct.pack_into('<H', bad, node0 + 32 * 3 + 22, 7)
+    with pytest.raises(_abi.AzgError):
+        b.import_slot(bytes(bad), 0)
+    bad = bytearray(blob)
+    struct.pack_into('<i', bad, 8 + 12, 0)                          # layout word of another library version
+    with pytest.raises(_abi.AzgError):
+        b.import_slot(bytes(bad), 0)
+    b.import_slot(blob, 0)                                          # (the refusals left the engine usable)
+    assert b.tree_info(0)['nodes_used'] == used
 
 
 def test_max_depth_is_writable_like_the_reference():

@@ -104,6 +104,63 @@ def test_c4_tree_vs_reference_goldens(torch_mod, cname):
     eng.close()
 
 
+def test_c4_search_under_numpys_mt19937_seed(torch_mod):
+    """"Identical seeds", literally: tests/golden/c4_mt19937.npz was produced by the reference's MCTS.search (MCTS.pyx:165-173) under
+    np.random.seed(s) on numpy's own MT19937 stream, with every np.random.shuffle of Node.add_children (:76-79) observed (test_oracle_golden.py
+    re-derives the recorded permutations from the seed alone).  The engine replays the recorded shuffles (azg_set_shuffle_tape) and must
+    reproduce the reference's trees: root children in list order with a / n / q / p / v, counts, pi at T = 1 and T = 0, values, depth."""
+    torch = torch_mod
+    d = dict(np.load(os.path.join(G, 'c4_mt19937.npz')))
+    R, sims, eseed = d['prefix'].shape[0], int(d['sims']), int(d['eval_seed'])
+    A, NV = 7, 3
+    eng = engine(B=R, cpuct=float(d['cfg'][0]), fpu_reduction=float(d['cfg'][1]), add_root_noise=False, add_root_temp=False, seed=12345, sims_hint=sims)
+    states = []
+    for r in range(R):
+        g = ol.OGame(C4)
+        for a in d['prefix'][r]:
+            if a >= 0:
+                g.play(a)
+        states.append(ostate(g))
+    eng.set_states(states)
+    eng.set_shuffle_tape(d['ranks'])
+    obs = eng.new_obs()
+    for launch in ('phase', 'fused'):
+        if launch == 'fused':                              # the two-wavefront launch (backup k + select k + 1) replays the same tape
+            eng.set_states(states); eng.set_tape_counters([0] * R)
+        if launch == 'phase':
+            for s in range(sims):
+                eng.select(obs)
+                pol, val = fake_batch(torch, eseed, range(R), s, A, NV, eng.device)
+                eng.backup(pol, val)
+        else:
+            eng.select(obs)
+            for s in range(sims):
+                pol, val = fake_batch(torch, eseed, range(R), s, A, NV, eng.device)
+                if s + 1 < sims:
+                    eng.backup_select(pol, val, obs)
+                else:
+                    eng.backup(pol, val)
+        for r in range(R):
+            ch = eng.root_children(r)
+            k = len(ch['a'])
+            assert (ch['a'] == d['a'][r][:k]).all() and (d['a'][r][k:] == -1).all(), (launch, r)
+            assert (ch['n'] == d['n'][r][:k]).all(), (launch, r)
+            for f in ('q', 'p', 'v'):
+                assert (ch[f] == d[f][r][:k]).all(), (launch, f, r)
+            info = eng.tree_info(r)
+            assert info['n'] == d['root_n'][r] and info['max_depth'] == d['maxdepth'][r]
+        assert (eng.root_counts().cpu().numpy() == d['counts']).all()
+        assert (eng.root_probs(1.0).cpu().numpy() == d['probs1']).all() and (eng.root_probs(0.0).cpu().numpy() == d['probs0']).all()
+        assert (eng.root_value(False).cpu().numpy() == d['vmax']).all() and (eng.root_value(True).cpu().numpy() == d['vavg']).all()
+        used = (d['expansion_children'] > 0).sum(1)
+        assert (eng.tape_counters() == d['expansion_children'].sum(1)).all() and used.min() > 0
+    eng.set_shuffle_tape(None)                             # back to the counter-based tape
+    eng.set_states(states); eng.set_tape_counters([0] * R)
+    eng.select(obs)
+    eng.counters()
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ agent goldens
 AGENT_CFGS = {
     'plain': dict(),

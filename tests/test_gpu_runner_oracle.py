@@ -98,6 +98,7 @@ def test_runner_phase_launches_vs_oracle_with_real_net(game, heads, B, sims):
     ('brandubh', 'search', 48, 200, 60), ('brandubh', 'features', 48, 40, 110),
     ('trimok', 'search', 64, 50, 60), ('trimok', 'features', 64, 24, 60),
     ('connect4', 'search', 64, 100, 50),
+    ('brandubh', 'exact', 48, 200, 60), ('trimok', 'exact', 64, 50, 60),
 ])
 def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, rounds):
     """The launches bench.py times (--workload brandubh | trimok: azg_search_wide_f16 with sparse heads at 200 / 50 simulations per
@@ -105,7 +106,9 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
     (full-width heads: softmax over all A, mask, renormalise -- what the reference computes, MCTS.pyx:239-245).  connect4's fused
     heads hand over exact probabilities: bit-identical, asserted.  The sparse heads agree to rounding only: a slot is followed
     until its first differing move; the fraction that never diverged is recorded (gpurun_out/nn_error.jsonl) and must stay
-    at or above 0.95 (observed: 47 of 48 brandubh slots after 60 moves x 200 simulations = 0.979, all slots in the other cases)."""
+    at or above 0.95 (observed: 47 of 48 brandubh slots after 60 moves x 200 simulations = 0.979, all slots in the other cases).
+    form 'exact' = azg_search_wide_exact_f16, the runners' and bench.py's default for configs 3 and 5 since round 5 (all A + P+1 logits
+    inside the persistent launch): like connect4, no slot may ever diverge."""
     import torch
     from alphazero_general_amd.selfplay import SelfPlayRunner
     Game, net = _setup(game, 7)
@@ -114,8 +117,9 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
     gi = ol.game_info(Game.AZG_GAME_ID)
     cap = B * (rounds + 1) * gi.num_symmetries
     r = SelfPlayRunner(Game, net, _args(sims, games, **kw), num_slots=B, seed=seed, example_capacity=cap,
-                       fused_search=(form == 'search'), heads=(None if form == 'search' else form))
-    assert r.fused_search == (form == 'search')
+                       fused_search=(form in ('search', 'exact')), heads=(None if form in ('search', 'exact') else form),
+                       search_heads='exact' if form == 'exact' else 'sparse')
+    assert r.fused_search == (form in ('search', 'exact'))
     ag = ol.OAgent(Game.AZG_GAME_ID, B, sims=sims, games_per_iteration=games, seed=seed, add_root_noise=True, add_root_temp=True,
                    cpuct=kw.get('cpuct', 1.25), fpu_reduction=kw.get('fpu_reduction', 0.2))
     same = np.ones(B, bool)
@@ -129,8 +133,8 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
             ag.process_batch(p.cpu().numpy(), v.cpu().numpy())
         # one round of the runner WITHOUT its advance: the root statistics are compared before the move is played
         e = r.engine
-        if form == 'search':
-            net._hip.search(e, sims)
+        if form in ('search', 'exact'):
+            net._hip.search(e, sims, exact=(form == 'exact'))
         else:
             e.select(r.lanes[0].obs)
             for i in range(sims):
@@ -154,7 +158,7 @@ def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, roun
                              'slots_never_diverged': frac, 'first_divergence_round': first_div,
                              'games_finished': int(ag.games_played)}) + '\n')
     assert ag.games_played > 0
-    if game == 'connect4':
+    if game == 'connect4' or form == 'exact':
         assert frac == 1.0, (frac, first_div)
     else:
         assert frac >= 0.95, (frac, first_div)

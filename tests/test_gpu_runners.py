@@ -170,8 +170,8 @@ def test_bench_two_ranks_on_one_gpu(launcher):
 @pytest.mark.parametrize('workload,slots', [('brandubh', 64), ('arena', 64), ('trimok', 64)])
 def test_bench_two_ranks_other_workloads(workload, slots):
     """the N-rank path of the OTHER bench workloads (BASELINE configs 3-5) before their first contact with a multi-GPU node: two
-    ranks on GPU 0 over gloo, self-launched; brandubh / trimok also run their bit-exact full-width-heads leg on both ranks (its
-    own exchange step), the arena has no example exchange at all."""
+    ranks on GPU 0 over gloo, self-launched; brandubh / trimok (timed on the exact persistent launch) also run their opt-in sparse-heads
+    leg on both ranks (its own exchange step), the arena has no example exchange at all."""
     import json
     import os
     import signal
@@ -196,7 +196,7 @@ def test_bench_two_ranks_other_workloads(workload, slots):
     sims = {'brandubh': 200, 'arena': 100, 'trimok': 50}[workload]
     assert d['simulations_per_sec'] * d['ms_per_step'] * 1e-3 * d['steps'] == pytest.approx(2 * slots * sims * 5, rel=1e-3)   # both ranks' work is in the line
     if workload != 'arena':
-        assert d['exact_heads']['value'] > 0 and d['config']['fused_search_launch']
+        assert d['sparse_heads']['value'] > 0 and d['config']['fused_search_launch'] and d['config']['search_heads'] == 'exact'
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
@@ -228,7 +228,7 @@ def test_wide_head_runner_graph_equals_eager_launches(game):
     outs = []
     for eager in (False, True):
         r = SelfPlayRunner(Game, net, _args(numMCTSSims=9, cpuct=1.25, fpu_reduction=0.2), num_slots=40, seed=6, use_graph=True,
-                           fused_search=False, example_capacity=40 * 101 * 8 * 2)
+                           fused_search=False, search_heads='sparse', example_capacity=40 * 101 * 8 * 2)
         assert r.lanes[0].net.run_features is not None and not r.fused_search
         for _ in range(14):
             r.play_round(eager=eager)
@@ -240,10 +240,11 @@ def test_wide_head_runner_graph_equals_eager_launches(game):
         assert x.shape == y.shape and (x == y).all()
 
 
-@pytest.mark.parametrize('game', ['brandubh', 'trimok'])
-def test_wide_head_runner_persistent_launch_with_fast_rounds_and_resets(game):
-    """The persistent wide-head launch inside the native runner (azg_search_wide_f16: brandubh with four wavefronts per game -- k-split
-    tower, shuffle masks and the rules of the walk on wavefronts of their own) against the launch-per-phase runner, with what changes
+@pytest.mark.parametrize('game,heads', [('brandubh', 'exact'), ('trimok', 'exact'), ('brandubh', 'sparse'), ('trimok', 'sparse')])
+def test_wide_head_runner_persistent_launch_with_fast_rounds_and_resets(game, heads):
+    """The persistent wide-head launches inside the native runner (azg_search_wide_exact_f16, the default, and azg_search_wide_f16:
+    brandubh with four wavefronts per game -- k-split tower, shuffle masks and the rules of the walk on wavefronts of their own)
+    against the launch-per-phase runner of the same hand-over (logits / features), with what changes
     the shape of a round riding along: fast rounds (a second simulation count, no history: SelfPlayAgent.pyx:83-92) and periodic tree
     resets (mctsResetThreshold, :172-174).  Samples, results, actions, counters identical."""
     import importlib
@@ -257,8 +258,8 @@ def test_wide_head_runner_persistent_launch_with_fast_rounds_and_resets(game):
     outs = []
     for fused in (True, False):
         r = SelfPlayRunner(Game, net, _args(numMCTSSims=12, numFastSims=5, probFastSim=0.4, mctsResetThreshold=3, cpuct=1.25, fpu_reduction=0.2),
-                           num_slots=B, seed=4, use_graph=True, fused_search=fused, example_capacity=B * 101 * 8 * 3)
-        assert r.fused_search == fused
+                           num_slots=B, seed=4, use_graph=True, fused_search=fused, search_heads=heads, example_capacity=B * 101 * 8 * 3)
+        assert r.fused_search == fused and r.search_exact == (heads == 'exact')
         for _ in range(rounds):
             r.play_round()
         o, p, z = r.samples()
@@ -413,9 +414,59 @@ assert torch.equal(o, obs) and torch.equal(p, pi) and torch.equal(v, z)
 o, p, v = D.all_gather_examples(obs[:0], pi[:0], z[:0])
 assert o.shape[0] == 0 and p.shape == (0, 7)
 assert D.max_over_ranks(2.5) == 2.5 and D.all_reduce_tallies([3, 4]).tolist() == [3, 4]
+recs = D.describe_ranks(0)                       # all_gather_object over RCCL
+assert len(recs) == 1 and recs[0]['rank'] == 0 and recs[0]['compute_units'] > 0 and recs[0]['pci_bus_id'] and recs[0]['rccl_version']
 D.barrier(); D.shutdown()
 print('RCCL_OK')
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     assert r.returncode == 0 and b'RCCL_OK' in r.stdout, r.stdout.decode(errors='replace')[-2000:]
+
+
+def test_two_ranks_on_one_gpu_are_refused():
+    """distributed.describe_ranks (bench.py calls it before anything is timed): two ranks whose device is the same physical GPU must
+    fail loudly -- they would otherwise share it and report a curve that looks like poor scaling; AZG_SINGLE_DEVICE (the one-GPU
+    test rig of test_bench_two_ranks_on_one_gpu) is the explicit way around it."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.multiprocessing as mp
+
+def work(rank, port, single, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
+    if single:
+        os.environ['AZG_SINGLE_DEVICE'] = '1'
+    else:
+        os.environ.pop('AZG_SINGLE_DEVICE', None)
+    import torch.distributed as dist
+    from alphazero_general_amd import distributed as D
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    try:
+        recs = D.describe_ranks(0)
+        q.put((rank, 'ok', len(recs)))
+    except RuntimeError as ex:
+        q.put((rank, 'refused', str(ex)))
+    dist.destroy_process_group()
+
+if __name__ == '__main__':
+    import socket
+    ctx = mp.get_context('spawn')
+    for single in (False, True):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        q = ctx.Queue()
+        ps = [ctx.Process(target=work, args=(r, port, single, q)) for r in range(2)]
+        [p.start() for p in ps]
+        res = sorted(q.get(timeout=120) for _ in ps)
+        [p.join(60) for p in ps]
+        if single:
+            assert all(r[1] == 'ok' and r[2] == 2 for r in res), res
+        else:
+            assert all(r[1] == 'refused' and 'share one GPU' in r[2] for r in res), res
+    print('REFUSAL_OK')
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b'REFUSAL_OK' in r.stdout, r.stdout.decode(errors='replace')[-2000:]

@@ -122,6 +122,31 @@ def test_dirichlet_statistics():
 
 
 # ------------------------------------------------------------------------------------------------- tree
+def test_c4_mt19937_fixture_is_numpys_own_stream():
+    """tests/golden/c4_mt19937.npz (the second tier of "identical seeds") holds child shuffles RECORDED from the
+    reference searching under np.random.seed(seed) on numpy's untouched global MT19937 stream.  A search without root noise draws from
+    that stream through np.random.shuffle only (MCTS.pyx:79), so the recorded ranks must be exactly what the legacy generator seeded
+    the same way produces for lists of those lengths in that order -- checked here without the reference: the fixture is pinned to the
+    literal seed, not to a capture nobody can re-derive."""
+    d = dict(np.load(os.path.join(G, 'c4_mt19937.npz')))
+    rs = np.random.RandomState(int(d['seed']))             # np.random.seed(s) seeds exactly this legacy generator
+    total = 0
+    for r in range(d['ranks'].shape[0]):
+        off = 0
+        for k in d['expansion_children'][r]:
+            k = int(k)
+            if k == 0:
+                continue                                    # (padding; an empty list draws nothing either)
+            x = list(range(k))
+            rs.shuffle(x)                                   # x[new position] = old index
+            pos = np.empty(k, np.int16)
+            pos[np.array(x)] = np.arange(k)
+            assert (pos == d['ranks'][r, off:off + k]).all(), (r, off)
+            off += k; total += 1
+        assert (d['ranks'][r, off:] == 0).all()
+    assert total > 3000
+
+
 TREE_CFGS = ['default', 'c4train', 'noise', 'noise_temp']
 
 

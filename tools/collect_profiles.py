@@ -91,7 +91,7 @@ def main():
     import bench
     summary_rows, pmc = [], {'git': a.git, 'csrc_sha': bench.csrc_sha(), 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
     for w in a.workloads:
-        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm', '--no-other-workloads', '--no-exact-heads']
+        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm', '--no-other-workloads', '--no-sparse-heads']
         out, line, rc = rocprof('kt_' + w, ['--kernel-trace', '--stats'], base + ['--steps', '12', '--warmup', '2'])
         stats = glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True)
         if stats:
