@@ -424,7 +424,7 @@ print('RCCL_OK')
     assert r.returncode == 0 and b'RCCL_OK' in r.stdout, r.stdout.decode(errors='replace')[-2000:]
 
 
-def test_two_ranks_on_one_gpu_are_refused():
+def test_two_ranks_on_one_gpu_are_refused(tmp_path):
     """distributed.describe_ranks (bench.py calls it before anything is timed): two ranks whose device is the same physical GPU must
     fail loudly -- they would otherwise share it and report a curve that looks like poor scaling; AZG_SINGLE_DEVICE (the one-GPU
     test rig of test_bench_two_ranks_on_one_gpu) is the explicit way around it."""
@@ -468,5 +468,7 @@ if __name__ == '__main__':
             assert all(r[1] == 'refused' and 'share one GPU' in r[2] for r in res), res
     print('REFUSAL_OK')
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    script = tmp_path / 'two_ranks.py'                              # (a file: spawned children re-import the main module)
+    script.write_text(code)
+    r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b'REFUSAL_OK' in r.stdout, r.stdout.decode(errors='replace')[-2000:]
