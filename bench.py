@@ -38,9 +38,10 @@ from alphazero_general_amd.selfplay import ArenaRunner, SelfPlayRunner  # noqa: 
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
-PMC_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc.json' % r) for r in (4, 3, 2)) if os.path.exists(p)),
-                os.path.join(ROOT, 'profiles', 'r04_pmc.json'))
-PHASE_FILE = os.path.join(ROOT, 'profiles', 'r04_phase_budget.json')
+PMC_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc.json' % r) for r in (5, 4, 3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, 'profiles', 'r05_pmc.json'))
+PHASE_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_phase_budget.json' % r) for r in (5, 4)) if os.path.exists(p)),
+                  os.path.join(ROOT, 'profiles', 'r05_phase_budget.json'))
 CALIBRATION_FILE = os.path.join(ROOT, 'profiles', 'cpu_oracle_vs_reference.json')
 CLOCK_GHZ_NOMINAL = 2.4                                                               # MI355X_MICROARCH.md (peak engine clock)
 
@@ -113,6 +114,11 @@ def load_json(path):
             return json.load(f)
     except (OSError, ValueError):
         return None
+
+
+def profile_key(c):
+    """the key of a workload in the committed PMC / phase files: its name at the default shard size, name_<games> at another"""
+    return c.name if c.B == WORKLOADS[c.name]['B'] else '%s_%d' % (c.name, c.B)
 
 
 def measured_traffic(workload, kernel_substr):
@@ -386,7 +392,7 @@ def rooflines(c, netprof, prof):
             return None
         us = netprof[fam + '_ms'] * 1e3 / n
         tf = flops_leaf * units / (us * 1e-6) / 1e12
-        traffic, src, busy = measured_traffic(c.name, kmatch)
+        traffic, src, busy = measured_traffic(profile_key(c), kmatch)
         r = {'kernel': kname, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
              'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
              'algorithmic_flops_per_launch': flops_leaf * units, 'mfma_issued_over_algorithmic': issued_frac(),
@@ -414,7 +420,7 @@ def rooflines(c, netprof, prof):
         sel_b, bak_b, shared_b = tree_bytes_per_sim(Game, W, feat_k)
         us = prof['backup_ms'] * 1e3 / prof['backup_n']              # backup k + select k + 1 share a launch
         gbs = ((sel_b + bak_b) * Bl + shared_b) / (us * 1e-6) / 1e9
-        traffic, src, _ = measured_traffic(c.name, 'k_backup_select2')
+        traffic, src, _ = measured_traffic(profile_key(c), 'k_backup_select2')
         roof_tree = {'kernel': 'k_backup_select2 (process_results of simulation k + find_leaf of k + 1, two wavefronts per tree%s)'
                                % (', sparse heads on the head features' if feat_k else ''),
                      'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 6),
@@ -463,17 +469,21 @@ def sparse_heads_run(c, a, rank, local_rank, dev, world, steps=8, warmup=2):
 def phase_budget(c, roofline):
     """The bound that applies to a persistent wide-head launch: ONE workgroup per game runs tree phase -> tower -> head convolutions
     back to back, `sims` times -- a chain of phase latencies, not an MFMA- or HBM-limited stream.  Cycles per simulation and phase
-    come from the s_memtime stamps of the measurement build (tools/wide_search_phases.py -> profiles/r04_phase_budget.json, stamped
+    come from the s_memtime stamps of the measurement build (tools/phase_budget.py -> profiles/r05_phase_budget.json, stamped
     with the kernel sources' hash); the floors beside them: the tower's MFMA issue time for one board on the workgroup's SIMDs, and
     the walk's dependent-load chain (one child block per level)."""
     pb = load_json(PHASE_FILE)
-    if not pb or c.name not in pb.get('workloads', {}) or roofline is None:
+    if not pb or profile_key(c) not in pb.get('workloads', {}) or roofline is None:
         return None
-    w = dict(pb['workloads'][c.name])
+    w = dict(pb['workloads'][profile_key(c)])
+    if w.get('search_heads', 'sparse') != (c.search_heads or 'sparse'):
+        return None
     w['source'] = 'profiles/%s @%s%s' % (os.path.basename(PHASE_FILE), pb.get('git', '?'), '' if pb.get('csrc_sha') == csrc_sha() else ' (kernel sources have changed since)')
-    cyc = w['tree'] + w['tower'] + w['headconv']
-    w['bound'] = ('phase-latency chain: the game\'s workgroup runs tree phase -> tower -> head convolutions back to back, so a move takes '
-                  'sims x cycles_per_sim / shader clock; the MFMA fraction above only says how much of that chain is the tower')
+    cyc = w['tree'] + w['tower'] + w['headconv'] + w.get('heads', 0)
+    gpw = int(w.get('games_per_workgroup', 1))
+    w['bound'] = ('phase-latency chain: a workgroup (%d game%s) runs tree phase -> tower -> head convolutions%s back to back, so a move takes '
+                  'sims x cycles_per_sim / shader clock; the MFMA fraction above only says how much of that chain is the tower'
+                  % (gpw, '' if gpw == 1 else 's', ' -> full-width heads' if w.get('heads') else ''))
     w['cycles_per_sim'], w['sims'], w['chain_cycles_per_move'] = cyc, c.sims, cyc * c.sims
     w['measured_launch_us'] = roofline['avg_launch_us']
     w['implied_clock_ghz'] = round(cyc * c.sims / (roofline['avg_launch_us'] * 1e3), 3)      # chain cycles / measured launch time
@@ -481,7 +491,7 @@ def phase_budget(c, roofline):
     # floor of the tower phase: one board's MFMAs issued back to back on the CU's four SIMDs (one v_mfma_f32_16x16x32_f16 = 16 384
     # FLOP per 16 cycles per SIMD = the 2.5 PFLOP/s peak over 1 024 SIMDs at 2.4 GHz)
     per_simd_cycle = MFMA_F16_PEAK_TFLOPS * 1e12 / 1024 / (CLOCK_GHZ_NOMINAL * 1e9)
-    w['tower_mfma_floor_cycles'] = int(net_flops_per_leaf(c.Game, c.net.args) / per_simd_cycle / 4)
+    w['tower_mfma_floor_cycles'] = int(gpw * net_flops_per_leaf(c.Game, c.net.args) / per_simd_cycle / 4)   # (the workgroup's boards)
     w['tower_over_mfma_floor'] = round(w['tower'] / max(w['tower_mfma_floor_cycles'], 1), 2)
     w['tower_share_of_chain'] = round(w['tower'] / cyc, 3)
     return w

@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-ROUND = 'r04'
+ROUND = 'r05'
 SCRATCH = os.path.join(ROOT, 'gpurun_out', ROUND + '_prof')
 KEEP = ('k_tower2', 'k_backup_select2', 'k_heads', 'k_select', 'k_backup', 'k_play', 'k_compact', 'k_emit', 'k_finalize', 'k_arena_rows')
 
@@ -81,7 +81,7 @@ def pmc_averages(outdir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--git', default=os.environ.get('AZG_GIT', 'unknown'))
-    ap.add_argument('--workloads', nargs='*', default=['connect4', 'brandubh', 'arena', 'trimok'])
+    ap.add_argument('--workloads', nargs='*', default=['connect4', 'brandubh', 'brandubh@2048', 'arena', 'trimok', 'trimok@1024'])
     ap.add_argument('--reuse', action='store_true', help='rebuild profiles/<round>_* from the raw output already under gpurun_out/<round>_prof')
     a = ap.parse_args()
     global REUSE
@@ -91,7 +91,10 @@ def main():
     import bench
     summary_rows, pmc = [], {'git': a.git, 'csrc_sha': bench.csrc_sha(), 'unit': 'bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024', 'workloads': {}}
     for w in a.workloads:
-        base = ['--workload', w, '--no-cpu-baseline', '--no-library-gemm', '--no-other-workloads', '--no-sparse-heads']
+        # (name or name@slots: a shard size of the workload, e.g. brandubh@2048 -- config 3's 2-GPU shard, four games per workgroup)
+        wname, _, wslots = w.partition('@')
+        base = ['--workload', wname, '--no-cpu-baseline', '--no-library-gemm', '--no-other-workloads', '--no-sparse-heads'] + (['--slots', wslots] if wslots else [])
+        w = w.replace('@', '_')
         out, line, rc = rocprof('kt_' + w, ['--kernel-trace', '--stats'], base + ['--steps', '12', '--warmup', '2'])
         stats = glob.glob(os.path.join(out, '**', '*kernel_stats.csv'), recursive=True)
         if stats:
