@@ -431,7 +431,13 @@ __device__ __forceinline__ void conv_main2(const char *in, const unsigned (&lb)[
 // times.  Workgroups never synchronise with each other.  (Measured: the same throughput as three launches per simulation --
 // the tower is bound by LDS-read issue and power, not by launch gaps; staggering the two workgroups of a CU changed nothing.)
 struct NoSearch {};
-template <class G> struct SearchArgs { View ev; int sims; using Game = G; static constexpr bool WIDE = false; };
+template <class G> struct SearchArgs { View ev; int sims; using Game = G; static constexpr bool WIDE = false; static constexpr bool ARENA = false; };
+// The same for the batched Arena (Arena.pyx:208-328; SelfPlayAgent.pyx arena mode :62-73,117-132): one game per workgroup -- arena shards are
+// small (256 games per GPU), a one-board tile per CU is what fills the chip --, wave 0 walks the MOVER's tree (tree_of_slot), the
+// workgroup evaluates the leaf with the MOVER's model: model = player_to_index[mover] (seat.v, SelfPlayAgent.pyx:44-47) or the slot's own
+// seating (seat_of_slot: 4 bits per player), parameters of model m > 0 in TowerParams::alt[m - 1].  The mover -- hence tree and model --
+// is fixed for the length of the launch (one move).
+template <class G> struct SearchArena { View ev; int sims; SeatMap seat; const uint32_t *seat_of_slot; using Game = G; static constexpr bool WIDE = false; static constexpr bool ARENA = true; };
 // The same for networks with factorised heads (wide action spaces, any tower width): BOARDS games per workgroup, wave b walks game
 // b, wave BOARDS + b prepares its priors and shuffle (the two-wave scheme of k_backup_select2), the head convolutions leave their
 // features in LDS and the next tree phase computes the logits it needs from them (azg_kernels.h, sparse heads: the value
@@ -576,7 +582,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     using GEO = TowerGeom<H, W, BOARDS, C>;
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     constexpr bool IS_WIDE = []() { if constexpr (IS_SEARCH) return SEARCH::WIDE; else return false; }();
-    static_assert(!IS_SEARCH || IS_WIDE || (PSPLIT == 1 && C == 128 && BOARDS == C / 32), "search mode: one wave per game, fused heads");
+    static_assert(!IS_SEARCH || IS_WIDE || (PSPLIT == 1 && C == 128 && BOARDS <= C / 32), "search mode: one wave per game, fused heads");
+    constexpr bool IS_ARENA = []() { if constexpr (IS_SEARCH) { if constexpr (!SEARCH::WIDE) return SEARCH::ARENA; } return false; }();
+    static_assert(!IS_ARENA || BOARDS == 1, "arena search: one game (one mover, one model) per workgroup");
     static_assert(!IS_WIDE || (C / 32) * PSPLIT * KSPLIT >= BOARDS, "wide search mode: at least one wavefront per game");
     constexpr bool SOLO = IS_WIDE && wide_solo<C, PSPLIT, KSPLIT, BOARDS>();
     constexpr bool EXACT = []() { if constexpr (IS_WIDE) return SEARCH::EXACT; else return false; }();
@@ -671,6 +679,17 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             if (Pin.y) P.y = reinterpret_cast<char *>(Pin.y) + (size_t)first * HW * C * 2;
             if (Pin.policy) { P.policy = Pin.policy + (size_t)first * Pin.A; P.value = Pin.value + (size_t)first * Pin.NV; }
             if (m > 0) {
+                const TowerParams::Model &M = Pin.alt[m - 1];
+                P.w = M.w; P.bias = M.bias; P.pre_scale = M.pre_scale; P.pre_shift = M.pre_shift; P.head_w = M.head_w; P.head_b = M.head_b;
+            } else {
+                P.w = Pin.w; P.bias = Pin.bias; P.pre_scale = Pin.pre_scale; P.pre_shift = Pin.pre_shift; P.head_w = Pin.head_w; P.head_b = Pin.head_b;
+            }
+        }
+        if constexpr (IS_ARENA) {                                // the mover's model evaluates this game for the whole move
+            const int sl = min(gtile, sa.ev.B - 1);
+            const int mover = __builtin_amdgcn_readfirstlane((int)sa.ev.states[sl].player);
+            const int m = __builtin_amdgcn_readfirstlane(sa.seat_of_slot ? (int)((sa.seat_of_slot[sl] >> (4 * mover)) & 15u) : sa.seat.v[mover & 7]);
+            if (m > 0 && m < Pin.nmodels) {
                 const TowerParams::Model &M = Pin.alt[m - 1];
                 P.w = M.w; P.bias = M.bias; P.pre_scale = M.pre_scale; P.pre_shift = M.pre_shift; P.head_w = M.head_w; P.head_b = M.head_b;
             } else {
@@ -911,7 +930,8 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             asm volatile("" : "+v"(slot));                       // (opaque: keeps the slot's tree addresses from being hoisted out of
                                                                  //  the simulation loop and spilled across the tower)
             slot = __builtin_amdgcn_readfirstlane(slot);
-            if (slot < sa.ev.B) {
+            if (wave >= BOARDS) {                                // (one-board tiles: waves 1.. only take part in the tower)
+            } else if (slot < sa.ev.B) {
                 select_slot<G>(sa.ev, slot, lane, nullptr, [&](const typename G::S &st, int ln) {
                     if (ln < HW) {                               // leaf observation -> the image rows of board `wave`, channels 8.. zero
                         char *row = img + GEO::qrow(wave * HW + ln) * RS;
@@ -1257,7 +1277,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 asm volatile("" : "+v"(slot));
                 slot = __builtin_amdgcn_readfirstlane(slot);
                 const float *pv = reinterpret_cast<const float *>(img + SCRATCH_PV) + wave * 16;
-                if (slot < sa.ev.B) backup_slot<G>(sa.ev, slot, lane, pv, pv + P.A, nullptr, nullptr);
+                if (wave < BOARDS && slot < sa.ev.B) backup_slot<G>(sa.ev, slot, lane, pv, pv + P.A, nullptr, nullptr);
             }
             AZG_WGSTAMP(7);
             __syncthreads();

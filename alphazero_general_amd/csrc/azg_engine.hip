@@ -984,6 +984,31 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     return r;
 }
 
+extern "C" int azg_search_arena_f16(azg_engine *e, void *stream, int nmodels, const void *const *w, const float *const *bias, const float *const *pre_scale,
+                                    const float *const *pre_shift, int nblocks, const void *const *head_w, const float *const *head_b,
+                                    const int32_t *p2i_host, const uint32_t *seat_of_slot, int sims) {
+    if (!e || !w || !bias || !head_w || !head_b || nblocks < 0 || sims < 0 || (!p2i_host && !seat_of_slot)) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument");
+    if (e->cfg.game != AZG_GAME_CONNECT4 || !e->v.arena)
+        return fail(AZG_E_UNSUPPORTED, "the persistent arena launch is built for connect4 arena engines with 128-channel towers (use azg_select / network / azg_backup)");
+    if (nmodels < 1 || nmodels > 4 || nmodels < e->gi.num_players) return fail(AZG_E_UNSUPPORTED, "one model per player, at most 4");
+    for (int m = 0; m < nmodels; m++)
+        if (!w[m] || !bias[m] || !head_w[m] || !head_b[m] || (nblocks > 0 && (!pre_scale || !pre_shift || !pre_scale[m] || !pre_shift[m]))) return fail(AZG_E_INVALID_ARG, "null model parameter");
+    const int A = e->gi.action_size, NV = e->gi.num_players + 1;
+    TowerParams P{nullptr, w[0], bias[0], nblocks ? pre_scale[0] : nullptr, nblocks ? pre_shift[0] : nullptr, nullptr, e->v.B, nblocks,
+                  head_w[0], head_b[0], nullptr, nullptr, A, NV, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nmodels, {}};
+    for (int m = 1; m < nmodels; m++)
+        P.alt[m - 1] = TowerParams::Model{w[m], bias[m], nblocks ? pre_scale[m] : nullptr, nblocks ? pre_shift[m] : nullptr, head_w[m], head_b[m]};
+    SearchArena<C4> sa{e->v, sims, SeatMap{}, seat_of_slot};
+    if (p2i_host) for (int i = 0; i < e->gi.num_players && i < 8; i++) {
+        if (p2i_host[i] < 0 || p2i_host[i] >= nmodels) return fail(AZG_E_INVALID_ARG, "player_to_index entry out of range");
+        sa.seat.v[i] = p2i_host[i];
+    }
+    EvPair ep; const bool prof = sims > 0 && netprof_begin((hipStream_t)stream, ep);
+    const int r = launch_tower<C4::H, C4::W, 1, 128, 1, SearchArena<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
+    netprof_end((hipStream_t)stream, 2, prof, ep);
+    return r;
+}
+
 // the persistent wide-head search launch, sparse heads (EXACT = false: hd) or full-width heads (EXACT = true: hf)
 template <bool EXACT>
 static int search_wide(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift, int nblocks, int channels,

@@ -450,6 +450,25 @@ class HipResNet:
             arr([n.head_w_packed for n in nets]), arr([n.head_b16 for n in nets]), int(n0.A), int(n0.NV), vp(policy_all), vp(value_all),
             vp(rows_per_model)))
 
+    @staticmethod
+    def search_arena(nets, engine, sims, player_to_index=None, slot_seats=None):
+        """a whole arena move in ONE persistent launch (azg_search_arena_f16): every game of `engine` (an arena engine) is searched
+        `sims` simulations on its mover's tree with its mover's model -- nets[player_to_index[mover]], or the slot's own seating
+        (slot_seats: int32 device tensor, 4 bits per player).  Needs the fused tower + heads kernel on every model."""
+        import ctypes as C
+        n0 = nets[0]
+        for n in nets:
+            if not n.fused_head or n.game != 0 or n.CH != 128:
+                raise NotImplementedError('the persistent arena launch needs connect4 models with the fused tower + heads kernel (128 channels)')
+            assert (len(n.blocks), n.A, n.NV) == (len(n0.blocks), n0.A, n0.NV)
+        arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p2i = None if player_to_index is None else (C.c_int32 * len(player_to_index))(*[int(x) for x in player_to_index])
+        seats = None if slot_seats is None else C.c_void_p(slot_seats.data_ptr())
+        n0._check(n0.L.azg_search_arena_f16(engine.h, st, len(nets), arr([n.tower_w for n in nets]), arr([n.tower_b for n in nets]),
+                                            arr([n.tower_ps for n in nets]), arr([n.tower_pt for n in nets]), len(n0.blocks),
+                                            arr([n.head_w_packed for n in nets]), arr([n.head_b16 for n in nets]), p2i, seats, int(sims)))
+
     def to_nhwc8(self, batch):
         """[B, C, H, W] (any float dtype) -> [B, H*W, 8] fp16."""
         B, C = batch.shape[0], batch.shape[1]

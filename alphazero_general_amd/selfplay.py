@@ -315,7 +315,7 @@ class ArenaRunner:
     (wins, draws, winrates) contract of Arena.play_games (:376) via get_game_results semantics (utils.py:34-54)."""
 
     def __init__(self, game_cls, nnets, args, *, num_slots, seed=0, slot_base=0, device=None, use_graph=True, result_capacity=None,
-                 seats='agent', nodes_per_tree=0):
+                 seats='agent', nodes_per_tree=0, fused_search=None):
         self.game_cls, self.nnets, self.args = game_cls, list(nnets), args
         self.game = azg_game_id(game_cls)
         self.B = int(num_slots)
@@ -361,6 +361,12 @@ class ArenaRunner:
         self.value = torch.zeros((self.B, e.NV), dtype=torch.float32, device=e.device)
         # fused tower + heads on every model: the per-model batch split never leaves the device
         self.device_split = bool(hip) and all(n._hip.fused_head for n in self.nnets)
+        # a whole move as ONE persistent launch (azg_search_arena_f16: one game per workgroup, the mover's tree, the mover's model) where the
+        # models have it -- connect4 x 128 channels --, else one multi-model tower launch + one tree launch per simulation
+        can = self.device_split and self.game == 0 and all(n._hip.CH == 128 for n in self.nnets)
+        if fused_search and not can:
+            raise NotImplementedError('no persistent arena launch for these models / this game')
+        self.fused_search = can if fused_search is None else bool(fused_search)
         self._graph = None
         if self.device_split and use_graph:
             self.capture()
@@ -400,6 +406,10 @@ class ArenaRunner:
         advance, so the rows are laid out once; then select, and per simulation ONE tower launch for all models plus one
         tree launch (backup k + select k + 1); advance."""
         e = self.engine
+        if self.fused_search:
+            HipResNet.search_arena([n._hip for n in self.nnets], e, sims, None if self.slot_seats is not None else self.player_to_index, self.slot_seats)
+            e.advance(record_history=False)
+            return
         row_of_slot, rpm = self._rows()
         e.select(self.obs, row_of_slot)
         nets = [n._hip for n in self.nnets]
@@ -415,6 +425,8 @@ class ArenaRunner:
         """Capture one whole round (all simulations of a move + advance) as a hipGraph (device-side split only)."""
         assert self.device_split
         self._step_device_split()                                    # warm: lazy allocations happen outside the capture
+        if self.fused_search:
+            HipResNet.search_arena([n._hip for n in self.nnets], self.engine, 0, None if self.slot_seats is not None else self.player_to_index, self.slot_seats)
         self.engine.reset()                                          # (the warm step is not part of any game)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

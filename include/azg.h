@@ -366,6 +366,16 @@ uint64_t azg_tape_u64(uint64_t seed, uint64_t stream, uint64_t ctr);
 double   azg_tape_uniform(uint64_t seed, uint64_t stream, uint64_t ctr);
 void     azg_tape_shuffle_pos(uint64_t seed, uint64_t stream, uint64_t ctr, int k, int32_t *pos);
 
+/* The batched Arena's move as ONE persistent launch (Arena.pyx:208-328 + SelfPlayAgent.pyx arena mode :62-73,117-132): connect4 arena
+ * engines, fused-heads 128-channel towers.  One game per workgroup: `sims` x [find_leaf on the MOVER's tree, the MOVER's model on MFMA,
+ * process_results]; model of a game = p2i_host[mover] (player_to_index, SelfPlayAgent.pyx:44-47; host int32[P], read at launch) or, when
+ * seat_of_slot_dev != NULL, the slot's own seating (4 bits per player, as azg_arena_rows_seats).  Model parameters as
+ * azg_resnet_policy_value_multi_f16 takes them.  Results identical to `sims` x [azg_select / azg_backup_select with the row map of
+ * azg_arena_rows, azg_resnet_policy_value_multi_f16] + a final azg_backup.  sims == 0: one-time setup only. */
+int  azg_search_arena_f16(azg_engine *e, void *stream, int nmodels, const void *const *w_packed_dev, const float *const *bias_dev,
+                          const float *const *pre_scale_dev, const float *const *pre_shift_dev, int nblocks, const void *const *head_w_packed_dev,
+                          const float *const *head_b_dev, const int32_t *p2i_host, const uint32_t *seat_of_slot_dev, int sims);
+
 /* "Identical seeds", literally (second tier): Node.add_children shuffles with np.random.shuffle on numpy's global MT19937
  * stream (MCTS.pyx:76-79).  The engine's own shuffles come from the counter-based tape; this call makes the engine REPLAY recorded
  * permutations instead: ranks_host int16 [num_slots][len], where the rank (position in the shuffled list) of child i -- children in
