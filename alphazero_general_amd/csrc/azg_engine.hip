@@ -1043,6 +1043,7 @@ static int search_wide(azg_engine *e, void *stream, const void *w, const float *
         else if (bt == 3) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);    // solo tree phase: one wavefront per game
 #ifdef AZG_TUNING
         else if (bt == 8) r = launch_tower<BR::H, BR::W, 8, 64, 4, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);   // one workgroup of eight wavefronts per CU
+        else if (bt == 14) r = launch_tower<BR::H, BR::W, 4, 64, 2, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);  // (what the spills cost: the 4-board tile with the whole register file)
 #endif
         else r = launch_tower<BR::H, BR::W, 4, 64, 2, SW>(s, P, sa, init);
     } else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) {

@@ -435,8 +435,8 @@ class ArenaRunner:
         self._graph = g
 
     def play_round(self, eager=False):
-        if self.device_split and self._graph is not None:
-            if eager:
+        if self.device_split and (self._graph is not None or self.fused_search):
+            if eager or self._graph is None:
                 self._round_device_split(int(self.args.get('numMCTSSims', 100)))
             else:
                 self._graph.replay()

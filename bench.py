@@ -270,10 +270,10 @@ def build(workload, a, rank, local_rank, dev, rounds, slots=0, search_heads=None
             c.nets.append(NNetWrapper(Game, netargs, device=dev, dtype=torch.float16))
         c.net = c.nets[0]
         c.runner = ArenaRunner(Game, c.nets, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
-                               use_graph=not a.no_graph, result_capacity=c.B * rounds // 5 + 2 * c.B)
+                               use_graph=not a.no_graph, fused_search=False if a.no_fused_search else None, result_capacity=c.B * rounds // 5 + 2 * c.B)
         c.engines = [c.runner.engine]
         c.counters = c.runner.engine.counters
-        c.fused_search = False
+        c.fused_search = bool(c.runner.fused_search)
         c.search_heads = None
     else:
         torch.manual_seed(0)                                         # same random-init weights on every rank
@@ -405,7 +405,7 @@ def rooflines(c, netprof, prof):
             r['executed_frac'] = round(ex / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
         return r
 
-    skind = ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else \
+    skind = ('Arena', 'C4', 'azg_search_arena_f16') if arena else ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else \
         ('Wide', W['game'], 'azg_search_wide_exact_f16' if c.search_heads == 'exact' else 'azg_search_wide_f16')
     roof_search = mfma_roof('search', 'k_tower2<...,Search%s<%s>> (%s: %d x [find_leaf, ResNet + heads, backup] on every game, one persistent launch '
                             'per move)' % (skind + (sims,)), 'Search' + skind[0] + '<', Bl * sims)

@@ -83,9 +83,9 @@ def test_arena_256x100_graph_equals_host_split():
     from alphazero_general_amd.selfplay import ArenaRunner
     nets = [_net(0), _net(1)]
     runs = []
-    for mode in ('graph', 'host'):
-        r = ArenaRunner(Game, nets, _args(), num_slots=256, seed=3, use_graph=(mode == 'graph'))
-        assert r.device_split and (r._graph is not None) == (mode == 'graph')
+    for mode in ('graph', 'phase', 'host'):       # graph: the persistent launch (azg_search_arena_f16); phase: tower + tree launch per simulation
+        r = ArenaRunner(Game, nets, _args(), num_slots=256, seed=3, use_graph=(mode != 'host'), fused_search=(mode == 'graph'))
+        assert r.device_split and (r._graph is not None) == (mode != 'host') and r.fused_search == (mode == 'graph')
         if mode == 'host':
             r.device_split = False
         acts = []
@@ -93,11 +93,12 @@ def test_arena_256x100_graph_equals_host_split():
             r.play_round()
             acts.append(r.engine.last_actions().cpu().numpy().copy())
         runs.append((np.array(acts), r.engine.counters(), r.results(), [x.copy() for x in r.engine.results()]))
-    (a0, c0, res0, raw0), (a1, c1, res1, raw1) = runs
-    assert (a0 == a1).all() and c0 == c1 and res0 == res1
+    (a0, c0, res0, raw0) = runs[0]
     assert c0['sims'] == 256 * 100 * 16 and c0['games_played'] > 0                   # games have ended and restarted
-    for x, y in zip(raw0, raw1):
-        assert (x == y).all()
+    for (a1, c1, res1, raw1) in runs[1:]:
+        assert (a0 == a1).all() and c0 == c1 and res0 == res1
+        for x, y in zip(raw0, raw1):
+            assert (x == y).all()
 
 
 def test_arena_64_slots_vs_oracle_with_real_nets():

@@ -31,9 +31,9 @@ def test_arena_runner_device_split_graph_equals_host_split():
     from alphazero_general_amd.selfplay import ArenaRunner
     nets = [_net(0), _net(1)]
     runs = []
-    for mode in ('graph', 'eager', 'host'):
-        r = ArenaRunner(Game, nets, _args(), num_slots=96, seed=5, use_graph=(mode == 'graph'))
-        assert r.device_split and (r._graph is not None) == (mode == 'graph')
+    for mode in ('graph', 'eager', 'phase_graph', 'phase_eager', 'host'):    # (graph / eager: the persistent launch, one per move)
+        r = ArenaRunner(Game, nets, _args(), num_slots=96, seed=5, use_graph=mode.endswith('graph'), fused_search=not mode.startswith('phase') and mode != 'host')
+        assert r.device_split and (r._graph is not None) == mode.endswith('graph') and r.fused_search == (mode in ('graph', 'eager'))
         if mode == 'host':
             r.device_split = False
         acts = []
