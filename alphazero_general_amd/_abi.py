@@ -99,6 +99,7 @@ SYMBOLS = {
     'azg_resnet_tower_features_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
     'azg_policy_value_heads_fact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'azg_search_arena_f16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    'azg_obs_to_nhwc8_f16': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'azg_set_shuffle_tape': (_i, [_vp, _vp, _vp, _i]),
     'azg_search_wide_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_search_wide_exact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i]),

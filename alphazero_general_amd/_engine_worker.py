@@ -25,6 +25,25 @@ def engine_worker(conn, cfg):
         obs = eng.new_obs(_t.float32)
         pol = _t.zeros((B, cfg['A']), dtype=_t.float32, device=dev)
         val = _t.zeros((B, cfg['NV']), dtype=_t.float32, device=dev)
+        # the shared-memory buffers page-locked in place (hipHostRegister): the observation batch goes device -> shm and the policy /
+        # value rows shm -> device by DMA, without a pageable staging copy each (the hops of every simulation in compat mode)
+        obs_t, pol_t, val_t = _t.from_numpy(obs_h), _t.from_numpy(pol_h), _t.from_numpy(val_h)
+        pinned = True
+        for t_ in (obs_t, pol_t, val_t):
+            try:
+                pinned = pinned and int(_t.cuda.cudart().cudaHostRegister(t_.data_ptr(), t_.numel() * 4, 0)) == 0
+            except Exception:                                    # noqa: BLE001
+                pinned = False
+
+        def obs_out():
+            if pinned:
+                obs_t.copy_(obs.reshape(B, -1), non_blocking=True)
+                _t.cuda.current_stream().synchronize()
+            else:
+                obs_h[:] = obs.reshape(B, -1).cpu().numpy()
+
+        def pv_in():
+            pol.copy_(pol_t, non_blocking=pinned); val.copy_(val_t, non_blocking=pinned)
         n_ex = 0
         row_of_slot = None
         conn.send(('ready', None))
@@ -35,7 +54,7 @@ def engine_worker(conn, cfg):
                 if cfg['arena']:
                     row_of_slot, rpm = eng.arena_rows(cfg['player_to_index'])
                 eng.select(obs, row_of_slot)
-                obs_h[:] = obs.reshape(B, -1).cpu().numpy()
+                obs_out()
                 if cfg['arena']:
                     rows = (row_of_slot.cpu().numpy().copy(), rpm.cpu().numpy().copy())
                 conn.send(('ok', rows))
@@ -43,14 +62,16 @@ def engine_worker(conn, cfg):
                 eng.select(None)
                 conn.send(('ok', None))
             elif cmd == 'backup':
-                pol.copy_(_t.from_numpy(pol_h)); val.copy_(_t.from_numpy(val_h))
+                pv_in()
+                if pinned:
+                    _t.cuda.current_stream().synchronize()      # (the rows have left the shared buffers before the agent is answered)
                 eng.backup(pol, val, row_of_slot if cfg['arena'] else None)
                 conn.send(('ok', None))
             elif cmd == 'backup_select':                         # processBatch of this simulation + generateBatch of the next: one launch
-                pol.copy_(_t.from_numpy(pol_h)); val.copy_(_t.from_numpy(val_h))
+                pv_in()
                 # (arena: the movers -- hence the row <-> game map -- do not change until the move is played)
                 eng.backup_select(pol, val, obs, row_of_slot if cfg['arena'] else None)
-                obs_h[:] = obs.reshape(B, -1).cpu().numpy()
+                obs_out()
                 conn.send(('ok', (row_of_slot.cpu().numpy().copy(), rpm.cpu().numpy().copy()) if cfg['arena'] else None))
             elif cmd == 'advance_begin':
                 fin = eng.advance_begin(record_history=arg)

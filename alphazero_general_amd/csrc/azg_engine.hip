@@ -909,6 +909,23 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
     return fail(AZG_E_UNSUPPORTED, "no MFMA tower for this game / channel count (supported: connect4 x {32,64,128}, brandubh x {64,128}, trimok x 32 channels)");
 }
 
+// [boards, C, H*W] f32 planes (what GameState.observation / the reference's batch tensors hold) -> the tower's input rows [boards * H*W][8] fp16
+__global__ __launch_bounds__(256) void k_obs_to_nhwc8(const float *src, half8 *dst, int n, int C, int HW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / HW, pos = i - b * HW;
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < C; c++) v[c] = (_Float16)src[((size_t)b * C + c) * HW + pos];
+    dst[i] = v;
+}
+extern "C" int azg_obs_to_nhwc8_f16(void *stream, const float *obs, int boards, int channels, int hw, void *x) {
+    if (!obs || !x || boards <= 0 || channels <= 0 || channels > 8 || hw <= 0) return fail(AZG_E_INVALID_ARG, "null or out-of-range argument (channels <= 8)");
+    const int n = boards * hw;
+    hipLaunchKernelGGL(k_obs_to_nhwc8, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, (half8 *)x, n, channels, hw);
+    HIPCHK(hipGetLastError());
+    return AZG_OK;
+}
+
 extern "C" int azg_resnet_tower_f16(void *stream, int game, const void *x, const void *w, const float *bias, const float *pre_scale,
                                     const float *pre_shift, void *y, int boards, int nblocks, int channels) {
     if (!x || !w || !bias || !y || boards <= 0 || nblocks < 0) return fail(AZG_E_INVALID_ARG, "null argument");

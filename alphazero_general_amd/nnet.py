@@ -472,6 +472,12 @@ class HipResNet:
     def to_nhwc8(self, batch):
         """[B, C, H, W] (any float dtype) -> [B, H*W, 8] fp16."""
         B, C = batch.shape[0], batch.shape[1]
+        if batch.dtype == torch.float32 and batch.is_cuda and batch.is_contiguous() and B > 0:      # one launch (azg_obs_to_nhwc8_f16)
+            import ctypes as Ct
+            x = torch.empty((B, self.HW, 8), dtype=torch.float16, device=self.device)
+            self._check(self.L.azg_obs_to_nhwc8_f16(Ct.c_void_p(torch.cuda.current_stream().cuda_stream), Ct.c_void_p(batch.data_ptr()), int(B), int(C),
+                                                    int(self.HW), Ct.c_void_p(x.data_ptr())))
+            return x
         x = torch.zeros((B, self.HW, 8), dtype=torch.float16, device=self.device)
         x[:, :, :C] = batch.to(self.device).reshape(B, C, self.HW).permute(0, 2, 1)
         return x
@@ -489,6 +495,49 @@ class CapturedNet:
 
     def replay(self):
         self.graph.replay()
+
+
+_PINNED = {}                                                   # data_ptr -> [nbytes, registered?, weakref to the tensor object, registrations]
+
+
+def _unpin(key):
+    ent = _PINNED.pop(key, None)
+    if ent is not None and ent[1] == 'registered':
+        try:
+            torch.cuda.cudart().cudaHostUnregister(key)
+        except Exception:                                      # noqa: BLE001 (interpreter shutdown)
+            pass
+
+
+def pin_shared(t):
+    """Page-lock a caller-owned SHARED-MEMORY CPU tensor in place (hipHostRegister) for as long as the tensor object lives: Coach /
+    Arena hand the same shared input tensors to nnet.process for a whole iteration (Coach.py:294-314 -- their own pin_memory() calls
+    discard the result, SURVEY.md Q17, so the tensors arrive pageable), and a pageable host -> device copy is staged synchronously.
+    Registered memory is DMA'd directly.  Only tensors that say is_shared() are touched; the registration is dropped when the tensor
+    object is collected (a weakref callback, before its memory is unmapped); a caller that hands a NEW tensor object over the same
+    memory every call is left on the pageable path after a few registrations; a failure is remembered.  True if the tensor is pinned."""
+    import weakref
+    if t.device.type != 'cpu' or not torch.cuda.is_available():
+        return False
+    key, n = t.untyped_storage().data_ptr(), t.untyped_storage().nbytes()
+    ent = _PINNED.get(key)
+    if ent is not None and ent[0] >= n:
+        return ent[1] != 'no'
+    ok = 'no'
+    try:
+        if t.is_pinned():
+            ok = 'pinned'
+        elif t.is_shared() and n >= 4096 and _PIN_COUNT.get(key, 0) < 4:
+            if int(torch.cuda.cudart().cudaHostRegister(key, n, 0)) == 0:
+                ok = 'registered'
+                _PIN_COUNT[key] = _PIN_COUNT.get(key, 0) + 1
+    except Exception:                                          # noqa: BLE001 (a runtime without host registration: the pageable path stays)
+        ok = 'no'
+    _PINNED[key] = [n, ok, weakref.ref(t, lambda _r, key=key: _unpin(key))]
+    return ok != 'no'
+
+
+_PIN_COUNT = {}
 
 
 class NNetWrapper:
@@ -539,6 +588,8 @@ class NNetWrapper:
         if self._infer is None:
             self.refresh()
         if self._hip is not None:
+            if batch.device.type == 'cpu' and pin_shared(batch):     # (compat mode: the caller's shared batch tensor, DMA'd instead of staged)
+                batch = batch.to(self.device, non_blocking=True)
             return self._hip.forward_nhwc8(self._hip.to_nhwc8(batch))
         x = batch.to(self.device, self.dtype)
         if self.device.type == 'cuda':

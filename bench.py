@@ -497,7 +497,7 @@ def phase_budget(c, roofline):
     return w
 
 
-def compat_run(W, net, seconds=12.0, workers=2):
+def compat_run(W, net, seconds=12.0, workers=2, games_per_worker=None):
     """What an UNMODIFIED Coach gets (compat mode, Coach.py:291-361): `workers` SelfPlayAgent processes with the reference's
     constructor and queue / event / shared-tensor protocol, each driving a device engine through its worker interpreter, the
     parent serving their batches with the GPU network exactly like Coach.processSelfPlayBatches (:337-342: ready_queue.get ->
@@ -508,7 +508,7 @@ def compat_run(W, net, seconds=12.0, workers=2):
     import torch.multiprocessing as mp
     from alphazero_general_amd.SelfPlayAgent import SelfPlayAgent
     Game = importlib.import_module('alphazero_general_amd.envs.' + W['game']).Game
-    B = W['B'] // workers
+    B = int(games_per_worker or W['B'] // workers)
     args = selfplay_args(W)
     args.update(_num_players=Game.num_players() + 1, _azg_seed=0)
     C, H, Wd = Game.observation_size()
@@ -525,7 +525,8 @@ def compat_run(W, net, seconds=12.0, workers=2):
         agents[i].daemon = True
         agents[i].start()
     served, nsamples, t_first, t_end = 0, 0, None, None
-    deadline = time.time() + 240
+    t_wait = t_net = t_copy = 0.0                                    # the parent's own time per batch: idle, evaluation (H2D + net + D2H), hand-back
+    deadline = time.time() + float(os.environ.get("AZG_COMPAT_DEADLINE", "240"))
 
     def drain():
         n = 0
@@ -538,17 +539,24 @@ def compat_run(W, net, seconds=12.0, workers=2):
         return n
     try:
         while completed.value != workers and time.time() < deadline:
-            nsamples += drain()
+            if served % 32 == 0:                                     # (Coach.processSelfPlayBatches does not touch the sample queue in this loop at all)
+                nsamples += drain()
+            t0 = time.perf_counter()
             try:
                 i = ready_queue.get(timeout=0.5)
             except queue.Empty:
                 continue
+            t1 = time.perf_counter()
             p, v = net.process(inputs[i])
+            p, v = p.cpu(), v.cpu()                                  # (the D2H the copy_ below would do, timed with the evaluation)
+            t2 = time.perf_counter()
             pols[i].copy_(p); vals[i].copy_(v); ready[i].set()
+            t3 = time.perf_counter()
             if t_first is None:
                 t_first = time.time()                                # (the workers' start-up is not self-play)
             else:
                 served += 1
+                t_wait += t1 - t0; t_net += t2 - t1; t_copy += t3 - t2
             t_end = time.time()
             if t_end - t_first >= seconds:
                 break
@@ -575,6 +583,10 @@ def compat_run(W, net, seconds=12.0, workers=2):
     return {'value': round(served * B / dt, 1), 'unit': 'simulations/s (leaf evaluations served; ~ expansions/s: only revisits of terminal nodes differ)',
             'workers': workers, 'games_per_worker': B, 'sims_per_move': W['sims'], 'batches_served': served, 'seconds': round(dt, 2),
             'ms_per_batch': round(dt * 1e3 / served, 3), 'games_finished': int(games_played.value), 'samples_received': nsamples,
+            # where the parent's time per batch goes (it serves the agents one batch at a time, Coach.py:337-342): waiting for a ready agent,
+            # nnet.process incl. H2D of the batch and D2H of policy / value, copying into the shared tensors + batch_ready.set()
+            'parent_us_per_batch': {'wait_for_agent': round(t_wait * 1e6 / served, 1), 'evaluate_h2d_net_d2h': round(t_net * 1e6 / served, 1),
+                                    'hand_back': round(t_copy * 1e6 / served, 1)},
             'path': 'alphazero_general_amd.SelfPlayAgent (reference constructor / queue protocol) x %d processes, parent serves batches like '
                     'Coach.processSelfPlayBatches with the GPU net: per simulation two process hops + H2D + D2H of the batch' % workers}
 
@@ -699,7 +711,12 @@ def main():
             torch.manual_seed(0)
             cnet = NNetWrapper(__import__('alphazero_general_amd.envs.connect4', fromlist=['Game']).Game, nn_mod.CONNECT4_NET_ARGS, device=dev, dtype=torch.float16)
             cnet.refresh()
-            others['compat'] = compat_run(WORKLOADS['connect4'], cnet)
+            # config 2's own shape (its 2048 games on two agents) and four agents x 2048 games: the parent serves ONE batch at a time
+            # (Coach.py:337-342), so what it needs is enough agents to always find one ready and batches large enough to amortise its
+            # fixed cost per batch (tools/compat_sweep.py: profiles/r05_compat_sweep.txt)
+            runs = [compat_run(WORKLOADS['connect4'], cnet, seconds=6.0, workers=w_, games_per_worker=g_) for w_, g_ in ((2, 1024), (4, 2048))]
+            best = max(runs, key=lambda r_: r_.get('value', 0))
+            others['compat'] = dict(best, runs=[{k_: r_.get(k_) for k_ in ('workers', 'games_per_worker', 'value', 'ms_per_batch', 'parent_us_per_batch', 'error')} for r_ in runs])
             del cnet
         except Exception as ex:                                      # noqa: BLE001
             others['compat'] = {'error': '%s: %s' % (type(ex).__name__, ex)}

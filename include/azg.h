@@ -376,6 +376,11 @@ int  azg_search_arena_f16(azg_engine *e, void *stream, int nmodels, const void *
                           const float *const *pre_scale_dev, const float *const *pre_shift_dev, int nblocks, const void *const *head_w_packed_dev,
                           const float *const *head_b_dev, const int32_t *p2i_host, const uint32_t *seat_of_slot_dev, int sims);
 
+/* Observation planes as callers of the reference hold them -- f32 [boards][C][H*W] (GameState.observation, the batch tensors of
+ * Coach.py:294-300) -- into the tower's input rows [boards * H*W][8] fp16 (channels padded to 8), one launch.  obs_dev may be device
+ * memory or page-locked host memory the device can read (a registered shared batch tensor: the H2D and the conversion are then one pass). */
+int  azg_obs_to_nhwc8_f16(void *stream, const float *obs_dev, int boards, int channels, int hw, void *x_dev);
+
 /* "Identical seeds", literally (second tier): Node.add_children shuffles with np.random.shuffle on numpy's global MT19937
  * stream (MCTS.pyx:76-79).  The engine's own shuffles come from the counter-based tape; this call makes the engine REPLAY recorded
  * permutations instead: ranks_host int16 [num_slots][len], where the rank (position in the shuffled list) of child i -- children in
