@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AZG_LIB_PATH') or os.path.join(HERE, 'lib', 'libazg_hip.so')   # (override: measurement builds)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 GAME_CONNECT4, GAME_BRANDUBH, GAME_TRIMOK = 0, 1, 2
 E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_TREE_FULL, E_EXAMPLES_FULL, E_UNSUPPORTED, E_INTERNAL, E_FLOATING_POINT = -1, -2, -3, -4, -5, -6, -7, -8
@@ -46,6 +46,7 @@ _vp, _i, _u64, _f, _d = C.c_void_p, C.c_int, C.c_uint64, C.c_float, C.c_double
 _i32p, _f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
 SYMBOLS = {
     'azg_abi_version': (_i, []),
+    'azg_source_sha': (C.c_char_p, []),
     'azg_last_error': (C.c_char_p, []),
     'azg_game_info_get': (_i, [_i, C.POINTER(GameInfo)]),
     'azg_device_count': (_i, []),

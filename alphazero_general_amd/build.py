@@ -23,6 +23,17 @@ def hipcc():
     return 'hipcc'
 
 
+def source_sha():
+    """content hash of the kernel sources (csrc/*.h, the device code) -- compiled into the library (azg_source_sha) so that a run can say
+    which sources the loaded binary was built from; bench.csrc_sha computes the same over the working tree"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h'))):
+        h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -34,7 +45,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ['-o', OUT, SRC]
+    cmd = [hipcc()] + FLAGS + ['-DAZG_SRC_SHA="%s"' % source_sha(), '-o', OUT, SRC]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

@@ -50,6 +50,10 @@ static const azg_game_info k_info[] = {
 static const int k_num_games = 3;
 
 extern "C" int azg_abi_version(void) { return AZG_ABI_VERSION; }
+#ifndef AZG_SRC_SHA
+#define AZG_SRC_SHA "unstamped"
+#endif
+extern "C" const char *azg_source_sha(void) { return AZG_SRC_SHA; }
 extern "C" const char *azg_last_error(void) { return g_err.c_str(); }
 extern "C" int azg_game_info_get(int game, azg_game_info *out) {
     if (game < 0 || game >= k_num_games || !out) return fail(AZG_E_INVALID_ARG, "unknown game id");

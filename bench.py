@@ -121,13 +121,22 @@ def profile_key(c):
     return c.name if c.B == WORKLOADS[c.name]['B'] else '%s_%d' % (c.name, c.B)
 
 
+def lib_source_sha():
+    """the kernel sources the LOADED library was built from (azg_source_sha, stamped by build.py)"""
+    from alphazero_general_amd import _abi
+    try:
+        return _abi.lib().azg_source_sha().decode()
+    except Exception:                                                # noqa: BLE001
+        return None
+
+
 def measured_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from the committed PMC summary (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes;
     MI355X_MICROARCH.md 'HBM': FETCH_SIZE counts half the bytes of wide loads on gfx950).  None when no profile is committed."""
     pmc = load_json(PMC_FILE)
     if not pmc:
         return None, None, None
-    same = pmc.get('csrc_sha') == csrc_sha()                          # were the counters taken on the kernels this run times?
+    same = pmc.get('csrc_sha') == csrc_sha() == lib_source_sha()      # were the counters taken on the kernels this run's binary holds?
     for name, rec in pmc.get('workloads', {}).get(workload, {}).items():
         if kernel_substr in name:
             return (int(rec['traffic_bytes']), 'profiles/%s @%s (%d dispatches%s)' % (os.path.basename(PMC_FILE), pmc.get('git', '?'), rec.get('dispatches', 0),
@@ -656,6 +665,7 @@ def main():
                    'games_per_gpu': c.B, 'sims_per_move': c.sims, 'hipgraph_rounds': not a.no_graph, 'stream_pipelines': a.pipelines,
                    'fused_search_launch': c.fused_search, 'search_heads': c.search_heads, 'mfma_tower': c.net._hip is not None, 'ranks': world,
                    'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                   'lib_source_sha': lib_source_sha(), 'tree_source_sha': csrc_sha(),
                    'rank_devices': rank_devices},
         'games_per_sec': round(t['games'] / dt, 2), 'simulations_per_sec': round(t['sims'] / dt, 1),
         'games_finished': t['games'], 'samples_gathered': t['samples'],

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AZG_ABI_VERSION 4
+#define AZG_ABI_VERSION 5
 
 typedef enum azg_status {
     AZG_OK = 0,
@@ -111,6 +111,9 @@ typedef struct azg_counters {
 
 /* ---- library ------------------------------------------------------------------------------------------- */
 int          azg_abi_version(void);
+/* content hash of the kernel sources (the headers under csrc/) this binary was built from, stamped by alphazero_general_amd/build.py ("unstamped" for a
+ * build made another way): bench.py prints it and quotes profile counters next to a run only when they were taken on the same sources */
+const char  *azg_source_sha(void);
 const char  *azg_last_error(void);
 int          azg_game_info_get(int game, azg_game_info *out);              /* Game.py static methods       */
 int          azg_device_count(void);
