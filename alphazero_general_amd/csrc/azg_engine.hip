@@ -1064,9 +1064,15 @@ static int search_wide(azg_engine *e, void *stream, const void *w, const float *
         else if (bt == 3) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);    // solo tree phase: one wavefront per game
 #ifdef AZG_TUNING
         else if (bt == 8) r = launch_tower<BR::H, BR::W, 8, 64, 4, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);   // one workgroup of eight wavefronts per CU
+        else if (bt == 12) r = launch_tower<BR::H, BR::W, 2, 64, 2, SearchWide<BR, 1, EXACT>, 2>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);  // 2 games, 8 wavefronts (k-split), one workgroup per CU
         else if (bt == 14) r = launch_tower<BR::H, BR::W, 4, 64, 2, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);  // (what the spills cost: the 4-board tile with the whole register file)
 #endif
-        else r = launch_tower<BR::H, BR::W, 4, 64, 2, SW>(s, P, sa, init);
+        else {
+            r = launch_tower<BR::H, BR::W, 4, 64, 2, SW>(s, P, sa, init);
+            // (two 4-game workgroups fill a CU's LDS to the last KB with a 4-block tower's parameters beside them: a deeper tower takes the
+            //  3-game tile, whose LDS holds the parameters of up to ~25 blocks)
+            if (r == AZG_E_INVALID_ARG && !forced) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);
+        }
     } else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) {
         // (measured, M expansions/s at 256 / 512 / 1024 games: one game per workgroup 20.7 / 37.4 / 39.4, two 16.3 / 31.3 / 48.0, four -- solo --
         //  - / 23.3 / 44.4: profiles/r05_wide_tile_sweep.txt)
