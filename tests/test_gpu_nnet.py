@@ -324,3 +324,40 @@ def test_one_board_tile_refuses_a_tower_that_does_not_fit_lds():
                                 C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(y.data_ptr()), B, nb, ch)
     torch.cuda.synchronize()
     assert rc == -1, (rc, L.azg_last_error())                  # AZG_E_INVALID_ARG
+
+
+def test_shared_batch_tensors_are_page_locked_for_their_lifetime():
+    """NNetWrapper.process page-locks a caller-owned SHARED CPU batch tensor in place (nnet.pin_shared: what Coach's input tensors are,
+    Coach.py:294-300) so that the H2D copy is a DMA instead of a staged pageable copy; the registration follows the tensor object -- it
+    is dropped when the tensor is collected -- and the evaluation equals the one of a private copy bit for bit.  Plain CPU tensors are
+    never registered."""
+    import gc
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.envs.connect4 import Game
+    torch.manual_seed(3)
+    net = N.NNetWrapper(Game, N.CONNECT4_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    g = torch.Generator().manual_seed(5)
+    base = (torch.rand((256, 4, 6, 7), generator=g) > 0.5).float()
+    shared = base.clone().share_memory_()
+    key = shared.untyped_storage().data_ptr()
+    p0, v0 = net.process(base)                                   # private pageable tensor: the staged path
+    assert base.untyped_storage().data_ptr() not in N._PINNED
+    for _ in range(3):                                           # the same shared tensor, call after call (one registration)
+        p1, v1 = net.process(shared)
+        assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    assert N._PINNED[key][1] == 'registered' and shared.is_pinned() and N._PIN_COUNT[key] == 1
+    shared[0, 0, 0, 0] = 1 - shared[0, 0, 0, 0]                  # the caller rewrites the batch in place between calls (SelfPlayAgent.pyx:116-123)
+    p2, _ = net.process(shared)
+    q2, _ = net.process(shared.clone())
+    assert torch.equal(p2, q2)
+    del shared, p1, v1, p2
+    gc.collect()
+    assert key not in N._PINNED                                  # unregistered before the memory went away
+    for _ in range(3):                                           # new shared tensors keep working (fresh registrations, no leak of old ones)
+        t = base.clone().share_memory_()
+        p3, _ = net.process(t)
+        assert torch.equal(p3, p0)
+        del t
+    gc.collect()
+    assert all(v[1] != 'registered' for v in N._PINNED.values())
