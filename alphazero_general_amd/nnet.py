@@ -519,6 +519,8 @@ def pin_shared(t):
     import weakref
     if t.device.type != 'cpu' or not torch.cuda.is_available():
         return False
+    if not t.is_shared():                                      # (a private tensor is never registered, nor remembered)
+        return t.is_pinned()
     key, n = t.untyped_storage().data_ptr(), t.untyped_storage().nbytes()
     ent = _PINNED.get(key)
     if ent is not None and ent[0] >= n:
