@@ -327,3 +327,52 @@ def test_persistent_launches_at_finished_and_almost_finished_roots(game):
             assert ti['n'] == m.root_n == sims and ti['nodes_used'] == eb.tree_info(r)['nodes_used'] and ti['max_depth'] == 0, r
     ea.close(); eb.close()
 
+
+
+@pytest.mark.parametrize('B', [600, 1100, 1600, 2100])
+def test_wide_tiles_from_wide_finished_and_almost_finished_roots(B):
+    """Every tile shape of the persistent wide-head launches (1, 2, 3 and 4 brandubh games per workgroup by engine size; the last two walk
+    a game's tree with ONE wavefront on the compact LDS scratch) from the roots that take the rare paths: 65-70 legal moves (two lane
+    chunks in the move list, the shuffle, best_child, the priors' numpy-order sum; five 16-child subtiles in the sparse heads), games that
+    are over (find_leaf returns the root, the win state is backed up, MCTS.pyx:213,234-235) and one or two plies before the end.  Both
+    hand-overs (exact: all logits inside the launch; sparse) against their launch-per-phase twins: counts, values, pi, tape counters,
+    counters identical."""
+    import torch
+    from alphazero_general_amd.engine import DeviceEngine
+    Game, net = _setup('brandubh', 9)
+    hip = net._hip
+    gid, sims = Game.AZG_GAME_ID, 10
+    rng = np.random.RandomState(5)
+    pos = list(ol.br_wide_positions(16, 11))
+    assert min(int(g.valid_moves().sum()) for g in pos) > 64
+    while len(pos) < 64:
+        g = ol.OGame(gid); hist = [g.clone()]
+        while not g.win_state().any():
+            g.play(int(rng.choice(np.flatnonzero(g.valid_moves())))); hist.append(g.clone())
+        pos += [hist[-1], hist[-2], hist[max(0, len(hist) - 3)], hist[len(hist) // 2]]
+    st = [(g.cells(), g.player, g.turns, g.s.aux[0]) for g in pos]
+    st = [st[(i * 7) % len(st)] for i in range(B)]                # (mixed within every tile)
+    kw = dict(cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=3, sims_hint=sims)
+    for exact in (True, False):
+        ea, eb = DeviceEngine(gid, B, **kw), DeviceEngine(gid, B, **kw)
+        ea.set_states(st); eb.set_states(st)
+        hip.search(ea, sims, exact=exact)
+        ob = torch.zeros((B, 49, 8), dtype=torch.float16, device=ea.device)
+        eb.select(ob)
+        for s in range(sims):
+            if exact:
+                eb.backup_select_logits(hip.forward_logits_nhwc8(ob, key=1), ob, select=s + 1 < sims)
+            else:
+                eb.backup_select_features(hip.forward_features_nhwc8(ob, key=1), hip.head_rows, hip.head2_b, ob, select=s + 1 < sims)
+        assert torch.equal(ea.root_counts(), eb.root_counts()), exact
+        assert torch.equal(ea.root_value(True), eb.root_value(True)) and torch.equal(ea.root_value(False), eb.root_value(False))
+        pa, pb = ea.root_probs(1.0), eb.root_probs(1.0)
+        assert torch.equal(torch.isnan(pa), torch.isnan(pb)) and torch.equal(torch.nan_to_num(pa), torch.nan_to_num(pb))
+        assert (ea.tape_counters() == eb.tape_counters()).all()
+        for r in range(0, B, 97):
+            ca, cb = ea.root_children(r), eb.root_children(r)
+            for f in ('a', 'n', 'q', 'p', 'v'):
+                assert (ca[f] == cb[f]).all(), (exact, f, r)
+        c = ea.counters()
+        assert c == eb.counters() and c['sims'] == B * sims
+        ea.close(); eb.close()
