@@ -209,9 +209,12 @@ def test_wide_exact_search_launch_vs_oracle_at_bench_size(game, B, sims, moves):
     eng.close()
 
 
-def test_arena_graph_vs_oracle_at_256x100():
-    """BASELINE config 4 (per-GPU shard) as bench.py times it: 256 arena games x 100 simulations, two differently seeded 128ch x 8
-    nets, arenaTemp 0.25, the native runner's whole-move hipGraph (device-side row split, both models in one launch) against the
+@pytest.mark.parametrize('B,moves,fused', [(256, 24, True), (512, 9, True), (256, 9, False)])
+def test_arena_graph_vs_oracle_at_256x100(B, moves, fused):
+    """BASELINE config 4 as bench.py times it -- 256 arena games x 100 simulations (the 2-GPU shard) and all 512 on one GPU, two
+    differently seeded 128ch x 8 nets, arenaTemp 0.25: the native runner's whole-move hipGraph -- the persistent launch
+    azg_search_arena_f16 (one game per workgroup, the mover's tree and model), and the launch-per-phase form (fused=False: device-side row
+    split, both models in one tower launch + one tree launch per simulation) -- against the
     oracle's arena agent (SelfPlayAgent.pyx:44-47,117-132,142-151 with the reference's row mis-routing off) fed, every simulation, by
     the same two networks evaluating ITS leaf rows per model: actions every move, then tallies, results, counters -- until games have
     finished and restarted."""
@@ -224,12 +227,12 @@ def test_arena_graph_vs_oracle_at_256x100():
     for sd in (0, 1):
         torch.manual_seed(sd)
         n = NNetWrapper(Game, CONNECT4_NET_ARGS, device='cuda:0', dtype=torch.float16); n.refresh(); nets.append(n)
-    B, sims, moves, seed = 256, 100, 24, 0
+    sims, seed = 100, 0
     args = dotdict(numMCTSSims=sims, numFastSims=20, probFastSim=0.0, gamesPerIteration=1 << 30, cpuct=4.0, fpu_reduction=0.4,
                    root_noise_frac=0.1, root_policy_temp=1.1, min_discount=1.0, add_root_noise=True, add_root_temp=True,
                    symmetricSamples=True, mctsResetThreshold=0, startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
-    r = ArenaRunner(Game, nets, args, num_slots=B, seed=seed, result_capacity=8 * B)
-    assert r.device_split and r._graph is not None
+    r = ArenaRunner(Game, nets, args, num_slots=B, seed=seed, result_capacity=8 * B, fused_search=fused)
+    assert r.device_split and r._graph is not None and r.fused_search == fused
     ag = ol.OAgent(0, B, sims=sims, games_per_iteration=1 << 30, seed=seed, cpuct=4.0, fpu_reduction=0.4, is_arena=True, ref_misroute=False)
     assert ag.player_to_index() == r.player_to_index
     for mv in range(moves):
@@ -247,7 +250,8 @@ def test_arena_graph_vs_oracle_at_256x100():
         r.play_round()                                            # the timed form: one graph replay per move
         assert (r.engine.last_actions().cpu().numpy() == ag.last_actions()).all(), mv
     c = r.engine.counters()
-    assert c['games_played'] == ag.games_played > 0 and c['sims'] == B * sims * moves == ag.sims_done and c['expansions'] == ag.expansions
+    assert c['games_played'] == ag.games_played and c['sims'] == B * sims * moves == ag.sims_done and c['expansions'] == ag.expansions
+    assert moves < 20 or c['games_played'] > 0
     ws, turns, slot = r.engine.results()
     ows, oturns, oslot = ag.results()
-    assert len(ws) > 0 and (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all()
+    assert len(ws) == len(ows) and (ws == ows).all() and (turns == oturns).all() and (slot == oslot).all()
