@@ -1058,7 +1058,21 @@ static int search_wide(azg_engine *e, void *stream, const void *w, const float *
         // two workgroups of four wavefronts per CU in every shape: 512 workgroups are one round of the chip
         using SW = SearchWide<BR, 2, EXACT>;
         const SW sa{e->v, sims, hd, hf};
-        const int bt = forced ? forced : e->v.B <= 512 ? 1 : e->v.B <= 1024 ? 2 : e->v.B <= 1536 ? 3 : 4;
+        // the tile that finishes the engine's games soonest: n = ceil(B / games per tile) workgroups run in rounds of 512 (two per CU); a
+        // workgroup's chain per simulation, in k cycles, with a neighbour on its CU / alone on it (measured: profiles/r05_wide_tile_sweep.txt)
+        static const int co_exact[4] = {83, 118, 123, 161}, alone_exact[4] = {70, 100, 100, 124};
+        static const int co_sparse[4] = {54, 92, 109, 146}, alone_sparse[4] = {45, 80, 90, 125};
+        int bt = 1;
+        if (forced) bt = forced;
+        else {
+            long best = -1;
+            for (int t = 1; t <= 4; t++) {
+                const int n = (e->v.B + t - 1) / t, full = n / 512, rem = n % 512;
+                const int co = (EXACT ? co_exact : co_sparse)[t - 1], al = (EXACT ? alone_exact : alone_sparse)[t - 1];
+                const long cost = (long)full * co + (rem == 0 ? 0 : rem <= 256 ? al : co);
+                if (best < 0 || cost < best) { best = cost; bt = t; }
+            }
+        }
         if (bt == 1) r = launch_tower<BR::H, BR::W, 1, 64, 1, SW, 2>(s, P, sa, init);      // four wavefronts per game (walk, priors, masks, rules), k-split tower
         else if (bt == 2) r = launch_tower<BR::H, BR::W, 2, 64, 2, SW>(s, P, sa, init);    // walker + helper per game
         else if (bt == 3) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);    // solo tree phase: one wavefront per game

@@ -335,10 +335,10 @@ def test_mcts_class_keeps_searching_at_one_root():
 
 @pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200), ('brandubh', 1, 2),
                                            ('trimok', 3, 2), ('trimok', 1, 5),
-                                           # above 512 games: the tile of several boards per workgroup, one wavefront per game's tree (a last
-                                           # tile with one and with two games, then BASELINE config 3's 2-GPU shard)
-                                           ('brandubh', 700, 23), ('brandubh', 515, 9), ('brandubh', 1300, 11), ('brandubh', 1537, 7),
-                                           ('brandubh', 2048, 200), ('trimok', 513, 9), ('trimok', 1024, 50)])
+                                           # above 512 games: tiles of several boards per workgroup (3 at 700 / 515 / 1300 -- a last tile with one and with
+                                           # two games --, 2 at 1024, 4 at 1537 and at BASELINE config 3's 2-GPU shard)
+                                           ('brandubh', 700, 23), ('brandubh', 515, 9), ('brandubh', 1024, 9), ('brandubh', 1300, 11),
+                                           ('brandubh', 1537, 7), ('brandubh', 2048, 200), ('trimok', 513, 9), ('trimok', 1024, 50)])
 def test_wide_search_launch_equals_phase_launches(game, B, sims):
     """azg_search_wide_f16 (networks with factorised heads: tree walk by two wavefronts per game, tower, head convolutions and the
     sparse heads all inside one persistent launch) against the launch-per-phase path -- azg_select / azg_backup_select_features,
@@ -380,8 +380,8 @@ def test_wide_search_launch_equals_phase_launches(game, B, sims):
 
 
 @pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200), ('brandubh', 1, 2), ('trimok', 3, 2),
-                                           ('brandubh', 700, 23), ('brandubh', 1300, 11), ('brandubh', 1537, 7), ('brandubh', 2048, 200),
-                                           ('trimok', 513, 9), ('trimok', 1024, 50)])
+                                           ('brandubh', 700, 23), ('brandubh', 1023, 9), ('brandubh', 1300, 11), ('brandubh', 1537, 7),
+                                           ('brandubh', 2048, 200), ('trimok', 513, 9), ('trimok', 1024, 50)])
 def test_wide_exact_search_launch_equals_logits_phase_launches(game, B, sims):
     """azg_search_wide_exact_f16 -- the persistent launch that computes ALL A + P+1 logits of its boards itself (heads_full_lds: the
     fragments and summation order of k_heads_fact) and takes the softmax over all A, masks, renormalises -- against the launch-per-phase

@@ -329,7 +329,7 @@ def test_persistent_launches_at_finished_and_almost_finished_roots(game):
 
 
 
-@pytest.mark.parametrize('B', [600, 1100, 1600, 2100])
+@pytest.mark.parametrize('B', [300, 600, 1024, 1600, 2100])    # 1, 3, 2, 4, 3 games per workgroup
 def test_wide_tiles_from_wide_finished_and_almost_finished_roots(B):
     """Every tile shape of the persistent wide-head launches (1, 2, 3 and 4 brandubh games per workgroup by engine size; the last two walk
     a game's tree with ONE wavefront on the compact LDS scratch) from the roots that take the rare paths: 65-70 legal moves (two lane
