@@ -491,8 +491,22 @@ template <class G, int HW, int BOARDS, bool COMPACT = false> struct WideLds : Wi
 // vmcnt(0): 36 k cycles per evaluation instead of the 15 k the 0.94 MB take through the CU's L1 path).
 //   wps: the policy chain's fragments SUBTILE-major, [OSP][k-step][64 lanes] x 16 B (k_heads_fact's wp is k-step-major: a wave here
 //   streams one subtile's 25 KB contiguously); wv [k-step][64]; bias f32 [A + P + 1].
+// the fragments and the bias of a wavefront's FIRST subtile: they do not depend on the evaluation, so the launch requests them before
+// the head convolutions and the barrier behind them (one L2 round trip of the stream hidden per simulation)
+template <class G, int HW> struct HeadsFirst { half8 b[WideScratch<G, HW>::FK / 32]; float bias; };
+template <class G, int HW, int NW>
+__device__ __forceinline__ void heads_full_prefetch(const HeadsFull &hf, int wave, int lane, HeadsFirst<G, HW> &pf) {
+    constexpr int A = G::A, NV = G::P + 1, KS = WideScratch<G, HW>::FK / 32, KQ = (KS + HEADF_Q - 1) / HEADF_Q, OSP = (A + 15) / 16;
+    const int i16 = lane & 15, s0 = min(wave, OSP);
+    const half8 *w0 = s0 == OSP ? hf.wv + lane : hf.wps + (size_t)s0 * (KS * 64) + lane;
+    pf.bias = hf.bias[min(s0 == OSP ? A + i16 : s0 * 16 + i16, A + NV - 1)];
+#pragma unroll
+    for (int j = 0; j < KQ; j++)
+#pragma unroll
+        for (int q = 0; q < HEADF_Q; q++) { const int ks = q * KQ + j; if (ks < KS && ks < (q + 1) * KQ) pf.b[ks] = w0[(size_t)ks * 64]; }
+}
 template <class G, int HW, int BOARDS, int NW, bool COMPACT>
-__device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row, const HeadsFull &hf, int wave, int lane) {
+__device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row, const HeadsFull &hf, int wave, int lane, HeadsFirst<G, HW> &pf) {
     using WS = WideScratch<G, HW, COMPACT>;
     constexpr int A = G::A, NV = G::P + 1, FK = WS::FK, KS = FK / 32, KQ = (KS + HEADF_Q - 1) / HEADF_Q, OSP = (A + 15) / 16;
     constexpr int NIT = (OSP + 1 + NW - 1) / NW;                             // subtiles per wavefront (the last one may be a repeat)
@@ -503,17 +517,8 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row,
     const int vhalf = live ? FK * 2 : 0;
     auto frags = [&](int s_) { return s_ == OSP ? hf.wv + lane : hf.wps + (size_t)s_ * (KS * 64) + lane; };
     // consumption order of the k-steps: the four chains interleaved
-    half8 b[KS];
-    float bias_cur, bias_nxt = 0.f;
-    {
-        const int s0 = min(wave, OSP);
-        const half8 *w0 = frags(s0);
-        bias_cur = hf.bias[min(s0 == OSP ? A + i16 : s0 * 16 + i16, A + NV - 1)];
-#pragma unroll
-        for (int j = 0; j < KQ; j++)
-#pragma unroll
-            for (int q = 0; q < HEADF_Q; q++) { const int ks = q * KQ + j; if (ks < KS && ks < (q + 1) * KQ) b[ks] = w0[(size_t)ks * 64]; }
-    }
+    half8 (&b)[KS] = pf.b;                                                   // (heads_full_prefetch)
+    float bias_cur = pf.bias, bias_nxt = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int s_ = wave + it * NW;                                       // (scalar)
@@ -558,6 +563,8 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row,
 // process_results and find_leaf itself -- policy logits, softmax, priors, value, path, walk with the rules, shuffle ranks --, the
 // one-wave functions of k_select / k_backup in the order of k_backup_select2; waves past BOARDS only take part in the tower
 template <int C, int PSPLIT, int KSPLIT, int BOARDS> constexpr bool wide_solo() { return (C / 32) * PSPLIT * KSPLIT < 2 * BOARDS; }
+template <class SEARCH, class = void> struct WideGameOf { using type = C4; };
+template <class SEARCH> struct WideGameOf<SEARCH, std::void_t<typename SEARCH::Game>> { using type = typename SEARCH::Game; };
 template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else { if constexpr (SEARCH::WIDE) return SEARCH::MIN_BLOCKS; else return 2; } }
 
 // KSPLIT = 2 (64-channel towers of one board): the two 32-channel k-steps of every tap go to two wave groups -- wave = (cout group
@@ -1129,6 +1136,11 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             // compute them for their own pixel subtiles straight out of the image (the final stream)
             [[maybe_unused]] _Float16 *feat_lds = nullptr;       // wide search mode: the features stay in LDS
             if constexpr (IS_WIDE) feat_lds = reinterpret_cast<_Float16 *>(smem + TILE + WideScratch<typename SEARCH::Game, HW, SOLO>::FEAT);
+            [[maybe_unused]] HeadsFirst<typename std::conditional<IS_WIDE, typename WideGameOf<SEARCH>::type, C4>::type, HW> hfirst;
+            // (one-game tiles only: the 100 registers the fragments wait in cost the multi-game tiles more in spills than the round trip:
+            //  brandubh 512 games 7.24 -> 7.03 ms per move, 2048 games 15.19 -> 15.61 with it, same box)
+            constexpr bool HEADS_EARLY = EXACT && BOARDS == 1;
+            if constexpr (HEADS_EARLY) heads_full_prefetch<typename SEARCH::Game, HW, NT / 64>(sa.hf, wave, lane, hfirst);
             if (cg == 0) {
                 int opaque = 0;
                 asm volatile("" : "+s"(opaque));                 // (keeps these loop invariants from being hoisted across the layers)
@@ -1179,7 +1191,13 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 // (second stage: the next tree phase turns the features into the logits it needs -- sparse heads, azg_kernels.h)
                 __syncthreads();                                 // the features of every board are in LDS
                 AZG_WPHASE(3);
-                if constexpr (EXACT) heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave, lane);
+                if constexpr (HEADS_EARLY) {
+                    heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave, lane, hfirst);
+                } else if constexpr (EXACT) {
+                    HeadsFirst<typename SEARCH::Game, HW> hl;
+                    heads_full_prefetch<typename SEARCH::Game, HW, NT / 64>(sa.hf, wave, lane, hl);
+                    heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave, lane, hl);
+                }
                 AZG_WPHASE(4);
 #ifdef AZG_TOWER_TIMING
                 if (P.dbg && tid == 0 && blockIdx.x < 512 && sim >= 8)      // tree (incl. the sparse heads), tower, head conv (cycles, summed over simulations)
