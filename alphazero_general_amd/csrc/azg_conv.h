@@ -488,7 +488,8 @@ template <class G, int HW, int BOARDS, bool COMPACT = false> struct WideLds : Wi
 // accumulators); the fragments AND the bias of the wave's NEXT subtile are requested as the current ones are consumed, in the order
 // they will be used, and the subtile loop is fully unrolled -- vmcnt retires in order, so every MFMA then waits for exactly its own
 // fragment instead of draining the stream (a loop back-edge or a bias load at the point of use both made the compiler wait for
-// vmcnt(0): 36 k cycles per evaluation instead of the 15 k the 0.94 MB take through the CU's L1 path).
+// vmcnt(0): 36 k cycles per evaluation; 28 k now -- 0.94 MB at ~33 B/clk, what one workgroup gets through the CU's L1 miss path with
+// 100 KB in flight; a second subtile in flight does not fit the registers: profiles/r05_wide_tile_sweep.txt).
 //   wps: the policy chain's fragments SUBTILE-major, [OSP][k-step][64 lanes] x 16 B (k_heads_fact's wp is k-step-major: a wave here
 //   streams one subtile's 25 KB contiguously); wv [k-step][64]; bias f32 [A + P + 1].
 // the fragments and the bias of a wavefront's FIRST subtile: they do not depend on the evaluation, so the launch requests them before
@@ -579,8 +580,8 @@ template <int H, int W, int C> constexpr bool tower_khalf_order() { return H == 
 // [nblocks][C] and shift [nblocks][C]: sized by the launch (dynamic LDS), (12 * nblocks + 8) * C bytes.
 template <int C, int BOARDS> constexpr int tower_layer_param_bytes(int nblocks) { return ((2 * nblocks + 1) * C * 4 + 2 * nblocks * C * 2 + C * 4 + 15) / 16 * 16; }   // (+ one row of slack: the bias prefetch of the last layer)
 // (+ the 1x1 head convolutions of the factorised heads: C / 32 k-steps x 2 fragments of 64 lanes x 16 bytes, then their 32 biases)
-// (tiles of several games of the persistent wide launch, SOLO: the layers' parameters only -- their global fetches were exposed at the top of
-//  every layer and behind every residual layer's main loop, and what LDS the games leave holds them but not the head fragments too)
+// (tiles of several games of the persistent wide launch, SOLO: the layers' parameters only -- what LDS the games leave holds them but not
+//  the head fragments too; measured neutral while a neighbour workgroup covers the fetches, kept for the workgroup that is alone on its CU)
 template <int C, int BOARDS, bool SOLO = false> constexpr int tower_param_bytes(int nblocks) {
     return BOARDS == 1 ? tower_layer_param_bytes<C, BOARDS>(nblocks) + (C / 32) * 2 * 1024 + 128 : SOLO ? tower_layer_param_bytes<C, BOARDS>(nblocks) : 0;
 }
@@ -648,7 +649,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     const unsigned edelta = (unsigned)(GEO::BIAS - g * 16 + ecol * 2);      // epilogue cell of a pixel = fragment base + edelta
     // (the four-wave search launch: two waves per SIMD cover each other's weight latency, and its registers are the scarce resource --
     //  a ring of 3 k-steps instead of 9: 82 -> 48 spilled registers, launch 5.47 -> 5.38 ms)
-    constexpr int WR = (IS_WIDE && KSPLIT == 2) ? 3 : WeightRing<NSUB, C / 32>::N;
+    // (the same for the 2-game tiles, whose small pixel groups would otherwise take the deep ring of the one-wave-per-SIMD shapes: 154 -> 56
+    //  spilled registers, brandubh 1024 games 11.2 -> 9.95 ms per move; the 3- and 4-game tiles keep their ring of 2: a third slot costs the
+    //  sparse 4-game launch 33 %)
+    constexpr int WR = (IS_WIDE && (KSPLIT == 2 || (BOARDS == 2 && tower_min_blocks<SEARCH>() == 2))) ? 3 : WeightRing<NSUB, C / 32>::N;
     static_assert((9 * (C / 32)) % WR == 0, "a layer must advance the weight ring by whole turns");
     const unsigned slot_role = __builtin_amdgcn_s_getreg(63492) & 1;       // HW_ID.wave_id parity: the two waves of a SIMD differ
     half8 a[WR][2];

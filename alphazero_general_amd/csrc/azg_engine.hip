@@ -1060,8 +1060,8 @@ static int search_wide(azg_engine *e, void *stream, const void *w, const float *
         const SW sa{e->v, sims, hd, hf};
         // the tile that finishes the engine's games soonest: n = ceil(B / games per tile) workgroups run in rounds of 512 (two per CU); a
         // workgroup's chain per simulation, in k cycles, with a neighbour on its CU / alone on it (measured: profiles/r05_wide_tile_sweep.txt)
-        static const int co_exact[4] = {83, 118, 123, 161}, alone_exact[4] = {70, 100, 100, 124};
-        static const int co_sparse[4] = {54, 92, 109, 146}, alone_sparse[4] = {45, 80, 90, 125};
+        static const int co_exact[4] = {83, 105, 123, 161}, alone_exact[4] = {70, 90, 100, 124};
+        static const int co_sparse[4] = {54, 83, 109, 146}, alone_sparse[4] = {45, 72, 90, 125};
         int bt = 1;
         if (forced) bt = forced;
         else {
