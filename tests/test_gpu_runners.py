@@ -299,8 +299,9 @@ def test_arena_runner_per_slot_seats():
     from alphazero_general_amd.selfplay import ArenaRunner
     nets = [_net(0), _net(1)]
     runs = []
-    for use_graph in (True, False):
-        r = ArenaRunner(Game, nets, _args(), num_slots=96, seed=8, use_graph=use_graph, seats='slot')
+    for use_graph, fused in ((True, True), (False, True), (True, False)):   # the persistent launch (graph / eager) and the launch-per-phase form
+        r = ArenaRunner(Game, nets, _args(), num_slots=96, seed=8, use_graph=use_graph, seats='slot', fused_search=fused)
+        assert r.fused_search == fused
         first = sum(1 for m in r.slot_player_to_index if m[0] == 0)
         assert 24 <= first <= 72                                      # a fair coin per slot
         for rnd in range(12):
@@ -313,7 +314,8 @@ def test_arena_runner_per_slot_seats():
                 exp[model == 0] = np.arange((model == 0).sum()); exp[model == 1] = (model == 0).sum() + np.arange((model == 1).sum())
                 assert (row_of_slot.cpu().numpy() == exp).all() and rpm.cpu().tolist() == [(model == 0).sum(), (model == 1).sum()]
         runs.append((r.engine.last_actions().cpu().numpy().copy(), r.engine.counters(), r.results()))
-    assert (runs[0][0] == runs[1][0]).all() and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    for other in runs[1:]:
+        assert (runs[0][0] == other[0]).all() and runs[0][1] == other[1] and runs[0][2] == other[2]
     wins, draws, _ = runs[0][2]
     assert sum(wins) + draws == runs[0][1]['games_played'] > 0
 
@@ -472,3 +474,39 @@ if __name__ == '__main__':
     script.write_text(code)
     r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b'REFUSAL_OK' in r.stdout, r.stdout.decode(errors='replace')[-2000:]
+
+
+def test_persistent_launches_refuse_what_they_are_not_built_for():
+    """azg_search_arena_f16 on a self-play engine or another game, azg_search_f16 / azg_search_wide_* on an arena engine, a seat map that
+    names a model that was not handed over: AZG_E_UNSUPPORTED / AZG_E_INVALID_ARG with a message, nothing launched."""
+    import torch
+    from alphazero_general_amd import _abi
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.engine import DeviceEngine
+    from alphazero_general_amd.nnet import HipResNet
+    from alphazero_general_amd.envs.brandubh import Game as BR
+    nets = [_net(0), _net(1)]
+    for n in nets:
+        n.refresh()
+    hips = [n._hip for n in nets]
+    plain = DeviceEngine(0, 8, sims_hint=10)
+    arena = DeviceEngine(0, 8, arena=True, sims_hint=10)
+    with pytest.raises(_abi.AzgError) as ei:
+        HipResNet.search_arena(hips, plain, 4, player_to_index=[0, 1])
+    assert ei.value.code == _abi.E_UNSUPPORTED
+    with pytest.raises(_abi.AzgError):
+        HipResNet.search_arena(hips, arena, 4, player_to_index=[0, 2])      # model 2 does not exist
+    with pytest.raises(_abi.AzgError) as ei:
+        hips[0].search(arena, 4)
+    assert ei.value.code == _abi.E_UNSUPPORTED
+    torch.manual_seed(1)
+    bnet = N.NNetWrapper(BR, N.BRANDUBH_NET_ARGS, device='cuda:0', dtype=torch.float16); bnet.refresh()
+    barena = DeviceEngine(1, 4, arena=True, sims_hint=10)
+    for exact in (True, False):
+        with pytest.raises(_abi.AzgError) as ei:
+            bnet._hip.search(barena, 4, exact=exact)
+        assert ei.value.code == _abi.E_UNSUPPORTED
+    HipResNet.search_arena(hips, arena, 3, player_to_index=[1, 0])          # (and the engines are still usable)
+    assert arena.counters()['sims'] == 8 * 3
+    for e in (plain, arena, barena):
+        e.close()
