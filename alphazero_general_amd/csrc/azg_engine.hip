@@ -1000,7 +1000,12 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, head_w, head_b, nullptr, nullptr, A, NV, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, {}};
     SearchArgs<C4> sa{e->v, sims};
     EvPair ep; const bool prof = sims > 0 && netprof_begin((hipStream_t)stream, ep);
-    const int r = launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
+    // games per workgroup like the stand-alone tower's tile (dispatch_tower): small engines -- the single-tree MCTS class, config 1's 32 games --
+    // take one game per workgroup (a lone 4-board tile runs at the tower's latency for four boards: 170 us per simulation against ~60)
+    int r;
+    if (e->v.B <= 640) r = launch_tower<C4::H, C4::W, 1, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
+    else if (e->v.B <= 1280) r = launch_tower<C4::H, C4::W, 2, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);
+    else r = launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);
     netprof_end((hipStream_t)stream, 2, prof, ep);
     return r;
 }
