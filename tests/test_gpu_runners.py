@@ -84,7 +84,8 @@ def test_selfplay_runner_launch_strategy_is_invisible(variant):
         assert sorted(zip(a[5].tolist(), a[4].tolist())) == sorted(zip(b[5].tolist(), b[4].tolist()))
 
 
-@pytest.mark.parametrize('B,sims,moves', [(203, 17, 30), (1, 2, 44), (2, 3, 44), (5, 2, 12), (7, 4, 6)])
+@pytest.mark.parametrize('B,sims,moves', [(203, 17, 30), (1, 2, 44), (2, 3, 44), (5, 2, 12), (7, 4, 6),
+                                              (641, 6, 9), (1281, 5, 9)])       # (two and four games per workgroup; a last tile with one game)
 def test_fused_search_kernel_equals_three_kernel_path(B, sims, moves):
     """azg_search_f16 (one persistent launch: tree walk, MFMA tower, backup for `sims` simulations) against the same number
     of [azg_select, azg_resnet_policy_value_f16, azg_backup] rounds on a twin engine: identical trees, moves, samples.
