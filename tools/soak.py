@@ -19,8 +19,12 @@ def args_for(sims, cpuct, fpu):
                    mctsResetThreshold=None, startTemp=1.0, arenaTemp=0.25, temp_scaling_fn=default_temp_scaling)
 
 
-for game, netargs, B, sims, cpuct, fpu, rounds in (('connect4', N.CONNECT4_NET_ARGS, 2048, 100, 4.0, 0.4, 1500), ('brandubh', N.BRANDUBH_NET_ARGS, 512, 200, 1.25, 0.2, 1200),
-                                                   ('trimok', N.DEFAULT_NET_ARGS, 256, 50, 1.25, 0.2, 4000)):
+# (round 5: every tile shape of the persistent launches -- 1 / 2 / 3 / 4 games per workgroup, exact heads by default -- and the small connect4 engines)
+for game, netargs, B, sims, cpuct, fpu, rounds in (('connect4', N.CONNECT4_NET_ARGS, 2048, 100, 4.0, 0.4, 1500), ('connect4', N.CONNECT4_NET_ARGS, 1024, 100, 4.0, 0.4, 800),
+                                                   ('connect4', N.CONNECT4_NET_ARGS, 256, 100, 4.0, 0.4, 1500),
+                                                   ('brandubh', N.BRANDUBH_NET_ARGS, 512, 200, 1.25, 0.2, 1200), ('brandubh', N.BRANDUBH_NET_ARGS, 768, 200, 1.25, 0.2, 800),
+                                                   ('brandubh', N.BRANDUBH_NET_ARGS, 1024, 200, 1.25, 0.2, 800), ('brandubh', N.BRANDUBH_NET_ARGS, 2048, 200, 1.25, 0.2, 800),
+                                                   ('trimok', N.DEFAULT_NET_ARGS, 256, 50, 1.25, 0.2, 4000), ('trimok', N.DEFAULT_NET_ARGS, 1024, 50, 1.25, 0.2, 3000)):
     rounds = max(60, int(rounds * scale))
     Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
     torch.manual_seed(0)
@@ -41,7 +45,7 @@ for game, netargs, B, sims, cpuct, fpu, rounds in (('connect4', N.CONNECT4_NET_A
                 ln.engine.clear_outputs()
     c = r.counters()
     assert c['sims'] == B * sims * rounds, (c['sims'], B * sims * rounds)
-    print('%s: %d rounds, %d games, %d simulations, %d expansions, peak nodes %d of %d, %.1f s' % (game, rounds, total_games, c['sims'], c['expansions'], peak, r.engine.nodes_per_tree, time.time() - t0), flush=True)
+    print('%s x %d (%s): %d rounds, %d games, %d simulations, %d expansions, peak nodes %d of %d, %.1f s' % (game, B, 'exact heads' if r.search_exact else 'sparse', rounds, total_games, c['sims'], c['expansions'], peak, r.engine.nodes_per_tree, time.time() - t0), flush=True)
     del r, net
     torch.cuda.empty_cache()
 
@@ -59,4 +63,4 @@ for i in range(rounds):
         c = r.engine.counters(); games += c['games_played']; r.engine.clear_outputs()
 c = r.engine.counters()
 assert c['sims'] == 256 * 100 * rounds
-print('arena: %d rounds, %d games, %d simulations, %.1f s' % (rounds, games, c['sims'], time.time() - t0), flush=True)
+print('arena x 256 (persistent launch: %s): %d rounds, %d games, %d simulations, %.1f s' % (r.fused_search, rounds, games, c['sims'], time.time() - t0), flush=True)
