@@ -503,6 +503,8 @@ _PINNED = {}                                                   # data_ptr -> [nb
 def _unpin(key):
     ent = _PINNED.pop(key, None)
     if ent is not None and ent[1] == 'registered':
+        if ent[3] >= 8:                                        # (a registration that served many calls was worth it: an address the allocator
+            _PIN_COUNT.pop(key, None)                          #  hands out again -- Coach's tensors of the next iteration -- starts afresh)
         try:
             torch.cuda.cudart().cudaHostUnregister(key)
         except Exception:                                      # noqa: BLE001 (interpreter shutdown)
@@ -515,7 +517,7 @@ def pin_shared(t):
     discard the result, SURVEY.md Q17, so the tensors arrive pageable), and a pageable host -> device copy is staged synchronously.
     Registered memory is DMA'd directly.  Only tensors that say is_shared() are touched; the registration is dropped when the tensor
     object is collected (a weakref callback, before its memory is unmapped); a caller that hands a NEW tensor object over the same
-    memory every call is left on the pageable path after a few registrations; a failure is remembered.  True if the tensor is pinned."""
+    memory every call is left on the pageable path after a few short-lived registrations; a failure is remembered.  True if the tensor is pinned."""
     import weakref
     if t.device.type != 'cpu' or not torch.cuda.is_available():
         return False
@@ -524,6 +526,7 @@ def pin_shared(t):
     key, n = t.untyped_storage().data_ptr(), t.untyped_storage().nbytes()
     ent = _PINNED.get(key)
     if ent is not None and ent[0] >= n:
+        ent[3] += 1
         return ent[1] != 'no'
     ok = 'no'
     try:
@@ -535,7 +538,7 @@ def pin_shared(t):
                 _PIN_COUNT[key] = _PIN_COUNT.get(key, 0) + 1
     except Exception:                                          # noqa: BLE001 (a runtime without host registration: the pageable path stays)
         ok = 'no'
-    _PINNED[key] = [n, ok, weakref.ref(t, lambda _r, key=key: _unpin(key))]
+    _PINNED[key] = [n, ok, weakref.ref(t, lambda _r, key=key: _unpin(key)), 1]
     return ok != 'no'
 
 

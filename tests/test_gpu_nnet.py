@@ -339,6 +339,7 @@ def test_shared_batch_tensors_are_page_locked_for_their_lifetime():
     net = N.NNetWrapper(Game, N.CONNECT4_NET_ARGS, device='cuda:0', dtype=torch.float16)
     g = torch.Generator().manual_seed(5)
     base = (torch.rand((256, 4, 6, 7), generator=g) > 0.5).float()
+    before = set(N._PINNED)                                      # (registrations other tests' still-living tensors hold)
     shared = base.clone().share_memory_()
     key = shared.untyped_storage().data_ptr()
     p0, v0 = net.process(base)                                   # private pageable tensor: the staged path
@@ -346,7 +347,7 @@ def test_shared_batch_tensors_are_page_locked_for_their_lifetime():
     for _ in range(3):                                           # the same shared tensor, call after call (one registration)
         p1, v1 = net.process(shared)
         assert torch.equal(p0, p1) and torch.equal(v0, v1)
-    assert N._PINNED[key][1] == 'registered' and shared.is_pinned() and N._PIN_COUNT[key] == 1
+    assert N._PINNED[key][1] == 'registered' and shared.is_pinned() and N._PINNED[key][3] == 3     # one registration served the three calls
     shared[0, 0, 0, 0] = 1 - shared[0, 0, 0, 0]                  # the caller rewrites the batch in place between calls (SelfPlayAgent.pyx:116-123)
     p2, _ = net.process(shared)
     q2, _ = net.process(shared.clone())
@@ -360,4 +361,18 @@ def test_shared_batch_tensors_are_page_locked_for_their_lifetime():
         assert torch.equal(p3, p0)
         del t
     gc.collect()
-    assert all(v[1] != 'registered' for v in N._PINNED.values())
+    assert all(v[1] != 'registered' for k_, v in N._PINNED.items() if k_ not in before)
+    # a caller that wraps the same memory in a NEW tensor object for every call (each registration serves one call) is left on the pageable
+    # path after a few of them; a long-lived tensor at an address the allocator hands out again is registered afresh
+    keep = base.clone().share_memory_()
+    k2 = keep.untyped_storage().data_ptr()
+    N._PIN_COUNT.pop(k2, None)
+    for i in range(8):
+        view = keep[:]                                            # same storage, new tensor object
+        p4, _ = net.process(view)
+        assert torch.equal(p4, p0)
+        del view
+        gc.collect()
+    assert N._PIN_COUNT.get(k2, 0) == 4 and N._PINNED.get(k2, [0, 'no'])[1] == 'no'
+    del keep
+    gc.collect()
