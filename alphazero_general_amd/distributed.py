@@ -86,6 +86,54 @@ def all_reduce_tallies(values, group=None):
     return t.cpu()
 
 
+def broadcast_object(obj, src=0, group=None):
+    """a small picklable object from rank `src` to every rank (the command of iteration.serve)"""
+    if not dist.is_initialized():
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
+def broadcast_state_dict(sd, meta=None, src=0, group=None, device=None):
+    """The weights of the net an iteration plays with, from rank `src` to every replica: ONE broadcast of a flat float32 buffer
+    (RCCL over xGMI: connect4 128ch x 8 is 9.6 MB) -- the only traffic of an iteration besides the example all-gather.  `sd`: the
+    state_dict on `src` (None elsewhere); `meta` = state_dict_meta(sd), which the other ranks need to cut the buffer up again
+    (sent with the command, iteration.lead).  Integer entries (BatchNorm's num_batches_tracked) travel in `meta`."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if meta is None:
+        meta = state_dict_meta(sd)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {k: v for k, v in sd.items()}
+    dev = device if device is not None else ('cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
+    n = sum(m[2] for m in meta['float'])
+    if rank == src:
+        flat = torch.cat([sd[k].detach().reshape(-1).to(dev, torch.float32) for k, _, _, _ in meta['float']]) if n else torch.zeros(0, device=dev)
+    else:
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+    if n:
+        dist.broadcast(flat, src=src, group=group)
+    out, off = {}, 0
+    for k, shape, numel, dt in meta['float']:
+        out[k] = flat[off:off + numel].reshape(shape).to(getattr(torch, dt))
+        off += numel
+    for k, shape, vals, dt in meta['int']:
+        out[k] = torch.tensor(vals, dtype=getattr(torch, dt)).reshape(shape)
+    return {k: out[k] for k in meta['order']}
+
+
+def state_dict_meta(sd):
+    """{'order': keys, 'float': [(key, shape, numel, dtype)], 'int': [(key, shape, values, dtype)]} -- plain Python, picklable"""
+    fl, it = [], []
+    for k, v in sd.items():
+        dt = str(v.dtype).replace('torch.', '')
+        if v.is_floating_point():
+            fl.append((k, tuple(v.shape), int(v.numel()), dt))
+        else:
+            it.append((k, tuple(v.shape), v.detach().reshape(-1).cpu().tolist(), dt))
+    return {'order': list(sd.keys()), 'float': fl, 'int': it}
+
+
 def describe_ranks(local_rank, group=None):
     """One record per rank, rank order -- which physical GPU every rank computes on (PCI bus id, name, CU count, memory), the
     host and process, and the collective library's version -- so that an N-GPU line explains its own placement; and the check
@@ -95,7 +143,10 @@ def describe_ranks(local_rank, group=None):
     rec = {'rank': dist.get_rank(group) if dist.is_initialized() else 0, 'local_rank': int(local_rank), 'host': socket.gethostname(), 'pid': os.getpid()}
     if torch.cuda.is_available():
         p = torch.cuda.get_device_properties(local_rank)
-        bus = '%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), getattr(p, 'pci_bus_id', -1) & 0xFF, getattr(p, 'pci_device_id', 0) & 0xFF)
+        # (a torch build whose device properties carry no pci_* / uuid fields gives no identifier: the shared-GPU check below is then
+        #  skipped for that rank instead of refusing a correct one-process-per-GPU job)
+        bus = ('%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id & 0xFF, getattr(p, 'pci_device_id', 0) & 0xFF)
+               if hasattr(p, 'pci_bus_id') else None)
         rec.update(device=p.name, pci_bus_id=bus, uuid=str(getattr(p, 'uuid', '')), compute_units=p.multi_processor_count,
                    memory_gb=round(p.total_memory / 2 ** 30, 1), visible_devices=os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES')))
     try:
@@ -109,7 +160,9 @@ def describe_ranks(local_rank, group=None):
     seen = {}
     for r in recs:
         key = (r['host'], r.get('pci_bus_id'), r.get('uuid'))
-        if 'pci_bus_id' in r and key in seen and not os.environ.get('AZG_SINGLE_DEVICE'):
+        if not (r.get('pci_bus_id') or r.get('uuid')):              # no identifier for this rank's device: nothing to compare
+            continue
+        if key in seen and not os.environ.get('AZG_SINGLE_DEVICE'):
             raise RuntimeError('ranks %d and %d share one GPU (%s on %s): one process per GPU -- check LOCAL_RANK / HIP_VISIBLE_DEVICES'
                                % (seen[key], r['rank'], r['pci_bus_id'], r['host']))
         seen[key] = r['rank']

@@ -652,6 +652,31 @@ class NNetWrapper:
     def replay(self):
         self._graph[0].replay()
 
+    def adopt(self, source, args=None):
+        """Take over the weights of a LIVE network without a checkpoint file: `source` is a state_dict, a torch module, or a wrapper
+        that holds one as `.nnet` -- the reference's own NNetWrapper (NNetWrapper.py:118-126; its ResNet's state_dict keys are this
+        ResNet's, the same compatibility load_checkpoint relies on).  `args` (default: source.args when it has them) names the
+        architecture; when its keys differ from this wrapper's the network is rebuilt first, as load_checkpoint(use_saved_args=True)
+        does.  The folded inference copies are dropped, so the next process() / search evaluates the adopted weights.  Returns self."""
+        if args is None:
+            args = getattr(source, 'args', None)
+        sd = source
+        if not isinstance(sd, dict):
+            mod = getattr(source, 'nnet', source)
+            mod = getattr(mod, 'module', mod)                        # (torch.nn.DataParallel)
+            sd = mod.state_dict()
+        if args is not None:
+            arch = {k: args[k] for k in DEFAULT_NET_ARGS if k in args}
+            if any(self.args.get(k) != v for k, v in arch.items()):
+                self.args.update(arch)
+                obs = tuple(self.game_cls.observation_size())
+                self.nnet = ResNet(obs, self.game_cls.action_size(), self.game_cls.num_players() + self.game_cls.has_draw(),
+                                   self.args).to(self.device)
+                self.nnet.eval()
+        self.nnet.load_state_dict({k: v.detach() for k, v in sd.items()})      # (copies onto this wrapper's device; strict: a key mismatch raises)
+        self._infer = self._hip = self._graph = None
+        return self
+
     def save_checkpoint(self, folder='checkpoint', filename='checkpoint.pth.tar', make_dirs=True):
         """NNetWrapper.save_checkpoint (NNetWrapper.py:239-250): {'state_dict', 'args'} under folder/filename (no optimizer /
         scheduler state: this wrapper only evaluates); the reference's load_checkpoint reads it."""

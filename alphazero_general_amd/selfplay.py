@@ -67,7 +67,9 @@ class SelfPlayRunner:
         gi = _abi.game_info(self.game)
         if example_capacity is None:
             per_game = (gi.max_turns + 1) * (gi.num_symmetries if args.get('symmetricSamples', True) else 1)
-            example_capacity = (int(args.get('gamesPerIteration', self.B)) + self.B) * per_game
+            games = int(args.get('gamesPerIteration', self.B))
+            # (no cap -- the benchmark's and the tests' "play K rounds": room for four generations of games; pass example_capacity to size it)
+            example_capacity = ((games if games < (1 << 30) else 3 * self.B) + self.B) * per_game
         if result_capacity is None:                                  # one record per finished game; a game is at least a few moves
             result_capacity = example_capacity // max(gi.num_symmetries if args.get('symmetricSamples', True) else 1, 1) // 4 + 4 * self.B + 1024
         self.seed, self.slot_base = int(seed), int(slot_base)
@@ -90,6 +92,7 @@ class SelfPlayRunner:
                 mcts_reset_threshold=args.get('mctsResetThreshold', 0) or 0,
                 games_per_iteration=quota, start_temp=args.get('startTemp', 1.0),
                 arena_temp=args.get('arenaTemp', 0.25), temp_fn=args.get('temp_scaling_fn', default_temp_scaling),
+                temp_table_override=args.get('_azg_temp_table'),     # (iteration.serve: the schedule of a callable that does not pickle)
                 seed=seed, slot_base=self.slot_base + li * Bl, device=device,
                 example_capacity=example_capacity // self.pipelines + 1, result_capacity=int(result_capacity) // self.pipelines + 1,
                 sims_hint=sims, nodes_per_tree=nodes_per_tree)
@@ -160,8 +163,8 @@ class SelfPlayRunner:
         e.select(ln.obs)
         logits_path = not self.warmup and ln.net.run_logits is not None    # wide heads: softmax inside the tree launch
         feat_path = not self.warmup and getattr(ln.net, 'run_features', None) is not None   # factorised: the heads too
-        if feat_path and logits_path and self.search_exact:       # (the default hand-over is the exact one in every launch form)
-            feat_path = False
+        if self.heads is None and feat_path and logits_path and self.search_exact:   # (the default hand-over is the exact one in every
+            feat_path = False                                                        #  launch form; a pinned heads= form is taken as given)
         if self.heads is not None and not self.warmup:
             if (self.heads == 'features' and not feat_path) or (self.heads == 'logits' and not logits_path):
                 raise NotImplementedError('this network has no %s hand-over to the tree launch' % self.heads)
@@ -277,30 +280,27 @@ class SelfPlayRunner:
 
     def save_iteration_samples(self, folder, iteration, first_per_lane=None):
         """Write the iteration's samples the way Coach.saveIterationSamples does (Coach.py:363-386): three CPU float32 tensors
-        `iteration-NNNN-{data,policy,value}.pkl` (torch.save, highest pickle protocol) that the unchanged Coach.train loads
+        `iteration-NNNN-{data,policy,value}.pkl` (torch.save; iteration.write_iteration_files) that the unchanged Coach.train loads
         (:444-456).  Returns the number of samples."""
-        import os
-        import pickle
-        data, policy, value = [t.cpu() for t in self.samples(first_per_lane)]
-        os.makedirs(folder, exist_ok=True)
-        stem = os.path.join(folder, 'iteration-%04d' % int(iteration))              # utils.get_iter_file :15-16
-        torch.save(data, stem + '-data.pkl', pickle_protocol=pickle.HIGHEST_PROTOCOL)
-        torch.save(policy, stem + '-policy.pkl', pickle_protocol=pickle.HIGHEST_PROTOCOL)
-        torch.save(value, stem + '-value.pkl', pickle_protocol=pickle.HIGHEST_PROTOCOL)
+        from .iteration import write_iteration_files
+        data, policy, value = self.samples(first_per_lane)
+        write_iteration_files(folder, iteration, data, policy, value)
         return int(data.shape[0])
 
-    def game_results(self):
+    def game_results(self, first_per_lane=None):
         """(wins per player, draws, average game length) -- utils.get_game_results (:34-54), what Coach.processGameResults
         logs (Coach.py:388-398) -- over every finished game."""
-        ws, turns, _ = self.results()
+        ws, turns, _ = self.results(first_per_lane)
         P = self.game_cls.num_players()
         wins = [int(ws[:, p].sum()) for p in range(P)] if len(ws) else [0] * P
         draws = int(ws[:, P].sum()) if len(ws) else 0
         return wins, draws, (float(turns.sum()) / len(turns) if len(turns) else 0)
 
-    def results(self):
+    def results(self, first_per_lane=None):
+        """(winstate u8[n, P+1], turns i32[n], slot i32[n]) of every finished game in result_queue order, lanes in slot order;
+        first_per_lane: skip the records a lane held before (the marks of iteration.SelfPlayIteration.begin)."""
         import numpy as np
-        rs = [ln.engine.results() for ln in self.lanes]
+        rs = [ln.engine.results(0 if first_per_lane is None else first_per_lane[i]) for i, ln in enumerate(self.lanes)]
         Bl = self.B // self.pipelines
         return (np.concatenate([r[0] for r in rs]), np.concatenate([r[1] for r in rs]),
                 np.concatenate([r[2] + i * Bl for i, r in enumerate(rs)]))
@@ -453,9 +453,10 @@ class ArenaRunner:
             if c['games_played'] >= games:
                 return c
 
-    def results(self):
-        """(wins per MODEL, draws, winrates) like Arena.play_games: winstate index -> model via player_to_index."""
-        ws, turns, slot = self.engine.results()
+    def results(self, first=0):
+        """(wins per MODEL, draws, winrates) like Arena.play_games: winstate index -> model via player_to_index.  first: skip the
+        result records the engine held before (iteration.ArenaIteration.begin)."""
+        ws, turns, slot = self.engine.results(first)
         P = self.game_cls.num_players()
         wins, draws = [0] * P, 0
         for w, sl in zip(ws, slot):

@@ -34,7 +34,7 @@ import torch  # noqa: E402
 from alphazero_general_amd import distributed as D  # noqa: E402
 from alphazero_general_amd import nnet as nn_mod  # noqa: E402
 from alphazero_general_amd.nnet import HipResNet, NNetWrapper  # noqa: E402
-from alphazero_general_amd.selfplay import ArenaRunner, SelfPlayRunner  # noqa: E402
+from alphazero_general_amd.iteration import ArenaIteration, SelfPlayIteration  # noqa: E402  (the library's iteration objects: per-rank runner + exchange step)
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
@@ -278,8 +278,9 @@ def build(workload, a, rank, local_rank, dev, rounds, slots=0, search_heads=None
             torch.manual_seed(sd)
             c.nets.append(NNetWrapper(Game, netargs, device=dev, dtype=torch.float16))
         c.net = c.nets[0]
-        c.runner = ArenaRunner(Game, c.nets, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
-                               use_graph=not a.no_graph, fused_search=False if a.no_fused_search else None, result_capacity=c.B * rounds // 5 + 2 * c.B)
+        c.iter = ArenaIteration(Game, c.nets, args, 1 << 30, num_slots=c.B, seed=0, seats='agent', device=local_rank,
+                                use_graph=not a.no_graph, fused_search=False if a.no_fused_search else None, result_capacity=c.B * rounds // 5 + 2 * c.B)
+        c.runner = c.iter.runner
         c.engines = [c.runner.engine]
         c.counters = c.runner.engine.counters
         c.fused_search = bool(c.runner.fused_search)
@@ -289,10 +290,11 @@ def build(workload, a, rank, local_rank, dev, rounds, slots=0, search_heads=None
         c.net = NNetWrapper(Game, netargs, device=dev, dtype=torch.float16)
         c.nets = [c.net]
         per_game = (Game.max_turns() + 1) * nsym
-        c.runner = SelfPlayRunner(Game, c.net, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
-                                  use_graph=not a.no_graph, pipelines=c.pipelines,
-                                  fused_search=False if (a.no_fused_search or c.pipelines > 1) else None, search_heads=search_heads or a.search_heads,
-                                  example_capacity=int(c.B * rounds / 5.0 + 2 * c.B) * per_game)
+        c.iter = SelfPlayIteration(Game, c.net, args, num_slots=c.B, seed=0, device=local_rank,
+                                   use_graph=not a.no_graph, pipelines=c.pipelines,
+                                   fused_search=False if (a.no_fused_search or c.pipelines > 1) else None, search_heads=search_heads or a.search_heads,
+                                   example_capacity=int(c.B * rounds / 5.0 + 2 * c.B) * per_game)
+        c.runner = c.iter.runner
         c.engines = [ln.engine for ln in c.runner.lanes]
         c.counters = c.runner.counters
         c.fused_search = bool(c.runner.fused_search)
@@ -303,37 +305,30 @@ def build(workload, a, rank, local_rank, dev, rounds, slots=0, search_heads=None
 
 def timed_region(c, steps, warmup, world, rank):
     """W warm-up rounds, then EXACTLY `steps` rounds -- every one the product's launch form (a replayed hipGraph unless --no-graph)
-    -- and the iteration's exchange step, bracketed by barrier + synchronize; nothing else runs inside."""
+    -- and the iteration's exchange step, bracketed by barrier + synchronize; nothing else runs inside.  The rounds and the exchange
+    are the library's own (alphazero_general_amd.iteration: what run_iteration / run_arena and the Coach adapter execute)."""
     c.rounds_before = getattr(c, 'rounds_played', 0)                 # (rounds this runner has played before this region)
     for _ in range(warmup):
-        c.runner.play_round()
+        c.iter.play_round()
     c.rounds_played = c.rounds_before + warmup + steps
-    c0 = c.counters()
-    ex0 = [e.counters()['num_examples'] for e in c.engines] if not c.arena else None
+    c.iter.begin()                                                   # the iteration's marks: what exchange() hands over is what follows
     if world > 1 and not c.arena:                                    # (the collectives' one-time set-up stays out of the timed region)
-        o_, p_, z_ = c.runner.samples(ex0)
+        o_, p_, z_ = c.iter.local_samples()
         D.all_gather_examples(o_[:1], p_[:1], z_[:1])
     D.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        c.runner.play_round()
+        c.iter.play_round()
     torch.cuda.synchronize()
     t_search = time.perf_counter() - t0                                      # this rank's own rounds (before it waits for anybody)
-    c1 = c.counters()
-    nsamples = 0
-    if not c.arena:                                                  # the exchange step of an iteration: all-gather the example shards
-        obs, pi, z = c.runner.samples(ex0)
-        gobs, gpi, gz = D.all_gather_examples(obs, pi, z)
-        nsamples = gobs.shape[0]
-    tall = D.all_reduce_tallies([c1['expansions'] - c0['expansions'], c1['sims'] - c0['sims'],
-                                 c1['games_played'] - c0['games_played'], nsamples if rank == 0 else 0])
+    ex = c.iter.exchange()                                           # all-gather of the example shards + tallies (arena: tallies only)
     torch.cuda.synchronize()
     t_exchange = time.perf_counter() - t0 - t_search
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0)
     r = dict(dt=dt, steps=steps, rank_ms_per_step_max=D.max_over_ranks(t_search) * 1e3 / steps,
              rank_ms_per_step_min=-D.max_over_ranks(-t_search) * 1e3 / steps, exchange_ms=D.max_over_ranks(t_exchange) * 1e3)
-    r['expansions'], r['sims'], r['games'], r['samples'] = [int(x) for x in tall]
+    r['expansions'], r['sims'], r['games'], r['samples'] = ex['expansions'], ex['sims'], ex['games'], ex.get('num_samples', 0)
     # steady state: all games start from the empty board at round 0, so the first finishes come in a burst; every slot plays one
     # move per round, so a game's finishing round is the running sum of its slot's game lengths (result records, read after the
     # region) -- games that finished in the SECOND half of the timed rounds, over that half's share of the time
@@ -459,9 +454,10 @@ def sparse_heads_run(c, a, rank, local_rank, dev, world, steps=8, warmup=2):
     nsym = len(c.Game().symmetries(np.zeros(c.Game.action_size(), np.float32)))
     x = Ctx()
     x.name, x.W, x.B, x.sims, x.Game, x.net, x.nets, x.arena, x.pipelines = c.name + '_sparse', c.W, c.B, c.sims, c.Game, c.net, c.nets, False, 1
-    x.runner = SelfPlayRunner(c.Game, c.net, args, num_slots=c.B, seed=0, slot_base=D.slot_base(rank, c.B), device=local_rank,
-                              use_graph=not a.no_graph, search_heads='sparse',
-                              example_capacity=int(c.B * (steps + warmup) / 5.0 + 2 * c.B) * (c.Game.max_turns() + 1) * nsym)
+    x.iter = SelfPlayIteration(c.Game, c.net, args, num_slots=c.B, seed=0, device=local_rank,
+                               use_graph=not a.no_graph, search_heads='sparse',
+                               example_capacity=int(c.B * (steps + warmup) / 5.0 + 2 * c.B) * (c.Game.max_turns() + 1) * nsym)
+    x.runner = x.iter.runner
     x.engines = [ln.engine for ln in x.runner.lanes]
     x.counters = x.runner.counters
     x.fused_search = bool(x.runner.fused_search)
@@ -609,7 +605,7 @@ def workload_label(c):
 def release(c):
     for e in c.engines:
         e.close()
-    c.runner = c.engines = c.net = c.nets = None
+    c.runner = c.iter = c.engines = c.net = c.nets = None
     import gc
     gc.collect(); torch.cuda.empty_cache()
 
@@ -725,8 +721,10 @@ def main():
             # (Coach.py:337-342), so what it needs is enough agents to always find one ready and batches large enough to amortise its
             # fixed cost per batch (tools/compat_sweep.py: profiles/r05_compat_sweep.txt)
             runs = [compat_run(WORKLOADS['connect4'], cnet, seconds=6.0, workers=w_, games_per_worker=g_) for w_, g_ in ((2, 1024), (4, 2048))]
-            best = max(runs, key=lambda r_: r_.get('value', 0))
-            others['compat'] = dict(best, runs=[{k_: r_.get(k_) for k_ in ('workers', 'games_per_worker', 'value', 'ms_per_batch', 'parent_us_per_batch', 'error')} for r_ in runs])
+            # 'compat' is config 2's OWN shape (2048 games on two agents), like for like with the headline; the larger sweep point sits
+            # under its own key
+            others['compat'] = dict(runs[0], runs=[{k_: r_.get(k_) for k_ in ('workers', 'games_per_worker', 'value', 'ms_per_batch', 'parent_us_per_batch', 'error')} for r_ in runs])
+            others['compat_best_shape'] = {k_: max(runs, key=lambda r_: r_.get('value', 0)).get(k_) for k_ in ('workers', 'games_per_worker', 'value', 'unit', 'ms_per_batch')}
             del cnet
         except Exception as ex:                                      # noqa: BLE001
             others['compat'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
