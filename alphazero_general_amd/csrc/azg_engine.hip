@@ -1101,9 +1101,19 @@ static int search_wide(azg_engine *e, void *stream, const void *w, const float *
         else if (bt == 4) r = launch_tower<TM::H, TM::W, 4, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);
 #endif
         else r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);   // walker + helper per game
+    } else if (e->cfg.game == AZG_GAME_CONNECT4 && channels == 32) {
+        // the reference's DEFAULT net (Coach.py:108-116: 32 channels x 4 blocks, 16 + 16 head channels -- BASELINE config 1's network and what an
+        // unconfigured Coach trains) on connect4: factorised heads, so the wide search mode; tiles like the 3-player env's 32-channel tower
+        const int bt = forced ? forced : e->v.B <= 512 ? 1 : 2;
+        if (bt == 1) r = launch_tower<C4::H, C4::W, 1, 32, 2, SearchWide<C4, 1, EXACT>>(s, P, SearchWide<C4, 1, EXACT>{e->v, sims, hd, hf}, init);
+        else r = launch_tower<C4::H, C4::W, 2, 32, 4, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init);   // walker + helper per game
+    } else if (e->cfg.game == AZG_GAME_CONNECT4 && channels == 64) {
+        const int bt = forced ? forced : e->v.B <= 512 ? 1 : 2;
+        if (bt == 1) r = launch_tower<C4::H, C4::W, 1, 64, 2, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init);   // four wavefronts per game
+        else r = launch_tower<C4::H, C4::W, 2, 64, 2, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init);           // walker + helper per game
     } else {
         g_kev = nullptr;
-        return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64 channels and the 3-player env x 32 channels (use azg_select / network / azg_backup)");
+        return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64, the 3-player env x 32 and connect4 x {32, 64} channels (use azg_select / network / azg_backup)");
     }
     netprof_end(s, 2, prof, ep);
     return r;

@@ -404,8 +404,9 @@ class HipResNet:
     @property
     def can_search(self):
         """a persistent search launch exists for this network: connect4 x 128 channels with fused heads (azg_search_f16), or
-        factorised heads on brandubh x 64 / the 3-player env x 32 channels (azg_search_wide_f16)."""
-        return (self.fused_head and self.game == 0 and self.CH == 128) or (self.fact_head and (self.game, self.CH) in ((1, 64), (2, 32)))
+        factorised heads on brandubh x 64 / the 3-player env x 32 / connect4 x {32, 64} channels -- the reference's default net
+        (Coach.py:108-116) on connect4 is the 32-channel one -- (azg_search_wide_exact_f16 / azg_search_wide_f16)."""
+        return (self.fused_head and self.game == 0 and self.CH == 128) or (self.fact_head and (self.game, self.CH) in ((1, 64), (2, 32), (0, 32), (0, 64)))
 
     def search(self, engine, sims, exact=False):
         """`sims` whole simulations (select -> this network -> backup) on every slot of `engine` in one persistent launch: the

@@ -47,15 +47,12 @@ CLOCK_GHZ_NOMINAL = 2.4                                                         
 
 
 def csrc_sha():
-    """content hash of the kernel sources (alphazero_general_amd/csrc/*.h): the committed PMC summary and phase budget are stamped with
+    """content hash of everything the library is built from -- csrc/*.h, csrc/*.hip, include/azg.h, the compile flags
+    (alphazero_general_amd.build.source_sha) -- over the WORKING TREE: the committed PMC summary and phase budget are stamped with
     the hash of the sources they were measured on (tools/collect_profiles.py); a counter taken on other kernels is not quoted next
     to this run's launch time (there is no .git on the GPU box, so the stamp is a content hash, not a commit)."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'alphazero_general_amd', 'csrc', '*.h'))):       # (the device code; azg_engine.hip is the host side)
-        h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read())
-    return h.hexdigest()[:16]
+    from alphazero_general_amd.build import source_sha
+    return source_sha()
 
 # name: game module, net args, games / GPU, sims / move, cpuct, fpu reduction, typical (children, depth) of the tree bytes model
 WORKLOADS = {
@@ -347,7 +344,7 @@ def timed_region(c, steps, warmup, world, rank):
     return r
 
 
-def profile_rounds(c, persistent_rounds=3):
+def profile_rounds(c, persistent_rounds=10):
     """OUTSIDE the timed region: rounds launched eagerly with the library's profile hooks on (single kernels go through
     hipExtLaunchKernelGGL, whose events carry the dispatch's own begin / end timestamps).  With a persistent search launch:
     `persistent_rounds` rounds of it, then ONE round of the launch-per-phase form of the same move loop, which shows the tree
@@ -362,8 +359,11 @@ def profile_rounds(c, persistent_rounds=3):
             c.runner.fused_search = False
         c.engines[0].profile(True); HipResNet.profile(True)
         c.runner.play_round(eager=True)
-        for kk, vv in HipResNet.profile_read().items():             # (GPU ms and launch counts per family: tower, wide heads, search)
+        rd = HipResNet.profile_read()
+        for kk, vv in rd.items():                                    # (GPU ms and launch counts per family: tower, wide heads, search)
             netprof[kk] = netprof.get(kk, 0) + vv
+        if kind == 'search' and rd.get('search_n'):                  # one persistent launch per round: its own duration, launch by launch
+            netprof.setdefault('search_each_us', []).append(rd['search_ms'] * 1e3 / rd['search_n'])
         HipResNet.profile(False)
         if kind == 'phase':
             prof = c.engines[0].profile_read()
@@ -395,10 +395,13 @@ def rooflines(c, netprof, prof):
         if not n:
             return None
         us = netprof[fam + '_ms'] * 1e3 / n
+        each = sorted(netprof.get(fam + '_each_us', []))
         tf = flops_leaf * units / (us * 1e-6) / 1e12
         traffic, src, busy = measured_traffic(profile_key(c), kmatch)
         r = {'kernel': kname, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
              'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'avg_launch_us': round(us, 2), 'launches_timed': n,
+             # (the timed launches one by one: avg_launch_us <= ms_per_step of the graph-replayed rounds can be checked against the spread)
+             'launch_us_min_median_max': [round(each[0], 2), round(each[len(each) // 2], 2), round(each[-1], 2)] if each else None,
              'algorithmic_flops_per_launch': flops_leaf * units, 'mfma_issued_over_algorithmic': issued_frac(),
              'traffic': traffic, 'traffic_source': src}
         if busy:
@@ -625,7 +628,7 @@ def main():
                     help='2 launches per simulation (tower, backup+select) instead of one persistent launch per move (azg_search_f16)')
     ap.add_argument('--no-other-workloads', action='store_true',
                     help='skip the short runs of BASELINE configs 3-5 that the default (connect4, 1 GPU) line carries as other_workloads')
-    ap.add_argument('--profile-rounds', type=int, default=3, help='eager rounds of the persistent launch timed after the timed region')
+    ap.add_argument('--profile-rounds', type=int, default=10, help='eager rounds of the persistent launch timed after the timed region')
     ap.add_argument('--compat', action='store_true', help='also time compat mode (unmodified-Coach protocol: SelfPlayAgent processes served by the parent)')
     ap.add_argument('--search-heads', default=None, choices=['exact', 'sparse'],
                     help='wide-head workloads, persistent launch: all A + P+1 logits inside the launch (bit-exact) or the valid actions only')

@@ -135,3 +135,34 @@ def test_tower_lds_layout_invariants(game, bt, ch, H, W):
             assert all(pclass(int(p)) == c for p in pm[s * 16:(s + 1) * 16] if p >= 0), (s, c)
         assert doubled == 0 or (bt, H, W) != (4, 6, 7)                       # the headline tile stays conflict-free
     assert L.azg_tower_layout(game, 3, ch, None, None, info) == _abi.E_UNSUPPORTED
+
+
+def test_source_stamp_covers_everything_the_binary_is_made_from(tmp_path, monkeypatch):
+    """build.source_sha -- compiled into the library as azg_source_sha and compared with the committed counters' stamp by bench.py --
+    changes when ANY input of the binary does: a kernel header, the host translation unit (azg_engine.hip: tile choice, launch bounds,
+    LDS sizing, the cost model), the public header, or a compile flag; and the library in the tree carries the stamp of the tree."""
+    import shutil
+    from alphazero_general_amd import build as b
+    base = b.source_sha()
+    assert len(base) == 16 and base == b.source_sha()
+    assert len({b.source_sha(v) for v in ('product', 'debug', 'tuning', 'timing-tree', 'timing-tower')}) == 5      # flags are part of the stamp
+    names = {os.path.basename(d) for d in b.DEPS}
+    assert {'azg_engine.hip', 'azg_kernels.h', 'azg_conv.h', 'azg_games.h', 'azg_device.h', 'azg.h'} <= names
+    for name in ('azg_engine.hip', 'azg_kernels.h', 'azg.h'):
+        deps = []
+        for d in b.DEPS:
+            if os.path.basename(d) == name:
+                c = str(tmp_path / name)
+                shutil.copy(d, c)
+                with open(c, 'a') as f:
+                    f.write('\n// touched\n')
+                d = c
+            deps.append(d)
+        monkeypatch.setattr(b, 'DEPS', deps)
+        assert b.source_sha() != base, name
+        monkeypatch.undo()
+    assert b.source_sha() == base
+    if os.path.exists(b.OUT) and not b.needs_build():                         # the in-tree library is the tree's build
+        L = C.CDLL(b.OUT)
+        L.azg_source_sha.restype = C.c_char_p
+        assert L.azg_source_sha().decode() == base

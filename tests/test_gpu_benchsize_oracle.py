@@ -44,8 +44,11 @@ def _threads():
 def _net(game, seed):
     import torch
     from alphazero_general_amd import nnet as N
-    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
-    args = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[game]
+    name, _, width = game.partition(':')                              # 'connect4:32': connect4 with the reference's default net (Coach.py:108-116)
+    Game = importlib.import_module('alphazero_general_amd.envs.' + name).Game
+    args = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[name]
+    if width:
+        args = N.dotdict(dict(N.DEFAULT_NET_ARGS, num_channels=int(width)))
     torch.manual_seed(seed)
     net = N.NNetWrapper(Game, args, device='cuda:0', dtype=torch.float16)
     net.refresh()
@@ -163,10 +166,13 @@ def test_wide_search_launch_vs_oracle_at_bench_size(game, B, sims, moves):
 
 
 @pytest.mark.parametrize('game,B,sims,moves', [('brandubh', 512, 200, 5), ('brandubh', 1024, 200, 2), ('brandubh', 2048, 200, 3),
-                                                 ('trimok', 256, 50, 8), ('trimok', 1024, 50, 5)])
+                                                 ('trimok', 256, 50, 8), ('trimok', 1024, 50, 5),
+                                                 # BASELINE config 1's shape and network (connect4, 32 games x 25 sims, the reference's default
+                                                 # net) through whole games, its 64-channel sibling, and the default net at config 2's size
+                                                 ('connect4:32', 32, 25, 44), ('connect4:64', 96, 25, 12), ('connect4:32', 2048, 100, 4)])
 def test_wide_exact_search_launch_vs_oracle_at_bench_size(game, B, sims, moves):
     """BASELINE configs 3 and 5 as bench.py times them by default, at their 8- / 4-GPU shard size and at the 2- and 1-GPU shard sizes
-    (one, two and four games per workgroup): azg_search_wide_exact_f16 -- all A + P+1 logits inside the launch, softmax over all A, mask,
+    (one, two and four games per workgroup) -- and config 1's network on connect4 (round 6: the default net's persistent launch): azg_search_wide_exact_f16 -- all A + P+1 logits inside the launch, softmax over all A, mask,
     renormalise -- against the oracle pool fed NNetWrapper.process of ITS OWN leaves (NNetWrapper.py:225-232 -> MCTS.pyx:239-245, what
     the reference computes).  No slot may diverge: visit counts of every root and pi every move, sampled actions, tape counters,
     samples (as multisets), results, counters -- identical."""

@@ -26,6 +26,20 @@ def _net(seed):
     return n
 
 
+def _wide_game_net(game):
+    """'brandubh' / 'trimok' / 'connect4:32' / 'connect4:64' -> (Game class, net args of a factorised-heads network); connect4 x 32 is the
+    reference's DEFAULT net (Coach.py:108-116), BASELINE config 1's network"""
+    import importlib
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.utils import dotdict
+    name, _, width = game.partition(':')
+    Game = importlib.import_module('alphazero_general_amd.envs.' + name).Game
+    na = dotdict(dict(N.BRANDUBH_NET_ARGS if name == 'brandubh' else N.DEFAULT_NET_ARGS))
+    if width:
+        na['num_channels'] = int(width)
+    return Game, na
+
+
 def _args(**kw):
     from alphazero_general_amd.utils import dotdict, default_temp_scaling
     a = dotdict(numMCTSSims=100, numFastSims=20, probFastSim=0.0, gamesPerIteration=1 << 30, cpuct=4.0, fpu_reduction=0.4,
@@ -338,7 +352,9 @@ def test_mcts_class_keeps_searching_at_one_root():
                                            # above 512 games: tiles of several boards per workgroup (3 at 700 / 515 / 1300 -- a last tile with one and with
                                            # two games --, 2 at 1024, 4 at 1537 and at BASELINE config 3's 2-GPU shard)
                                            ('brandubh', 700, 23), ('brandubh', 515, 9), ('brandubh', 1024, 9), ('brandubh', 1300, 11),
-                                           ('brandubh', 1537, 7), ('brandubh', 2048, 200), ('trimok', 513, 9), ('trimok', 1024, 50)])
+                                           ('brandubh', 1537, 7), ('brandubh', 2048, 200), ('trimok', 513, 9), ('trimok', 1024, 50),
+                                           # connect4 with the reference's default net (32 channels) and its 64-channel sibling: one and two games per workgroup
+                                           ('connect4:32', 32, 25), ('connect4:32', 515, 9), ('connect4:32', 1, 3), ('connect4:64', 131, 17), ('connect4:64', 600, 9)])
 def test_wide_search_launch_equals_phase_launches(game, B, sims):
     """azg_search_wide_f16 (networks with factorised heads: tree walk by two wavefronts per game, tower, head convolutions and the
     sparse heads all inside one persistent launch) against the launch-per-phase path -- azg_select / azg_backup_select_features,
@@ -349,9 +365,9 @@ def test_wide_search_launch_equals_phase_launches(game, B, sims):
     import torch
     from alphazero_general_amd import nnet as N
     from alphazero_general_amd.engine import DeviceEngine
-    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    Game, na = _wide_game_net(game)
     torch.manual_seed(21)
-    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    net = N.NNetWrapper(Game, na, device='cuda:0', dtype=torch.float16)
     net.refresh()
     hip = net._hip
     assert hip.fact_head and hip.can_search
@@ -381,7 +397,9 @@ def test_wide_search_launch_equals_phase_launches(game, B, sims):
 
 @pytest.mark.parametrize('game,B,sims', [('brandubh', 203, 23), ('trimok', 131, 17), ('brandubh', 512, 200), ('brandubh', 1, 2), ('trimok', 3, 2),
                                            ('brandubh', 700, 23), ('brandubh', 1023, 9), ('brandubh', 1300, 11), ('brandubh', 1537, 7),
-                                           ('brandubh', 2048, 200), ('trimok', 513, 9), ('trimok', 1024, 50)])
+                                           ('brandubh', 2048, 200), ('trimok', 513, 9), ('trimok', 1024, 50),
+                                           ('connect4:32', 32, 25), ('connect4:32', 515, 9), ('connect4:32', 1, 3), ('connect4:32', 2048, 100),
+                                           ('connect4:64', 131, 17), ('connect4:64', 600, 9)])
 def test_wide_exact_search_launch_equals_logits_phase_launches(game, B, sims):
     """azg_search_wide_exact_f16 -- the persistent launch that computes ALL A + P+1 logits of its boards itself (heads_full_lds: the
     fragments and summation order of k_heads_fact) and takes the softmax over all A, masks, renormalises -- against the launch-per-phase
@@ -393,9 +411,9 @@ def test_wide_exact_search_launch_equals_logits_phase_launches(game, B, sims):
     import torch
     from alphazero_general_amd import nnet as N
     from alphazero_general_amd.engine import DeviceEngine
-    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
+    Game, na = _wide_game_net(game)
     torch.manual_seed(22)
-    net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    net = N.NNetWrapper(Game, na, device='cuda:0', dtype=torch.float16)
     net.refresh()
     hip = net._hip
     assert hip.fact_head and hip.can_search

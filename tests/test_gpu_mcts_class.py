@@ -62,7 +62,7 @@ def test_mcts_pickle_round_trip_continues_bit_for_bit():
     assert (m3.counts(g) == m.counts(g)).all()
 
 
-@pytest.mark.parametrize('game', ['connect4', 'brandubh', 'trimok'])
+@pytest.mark.parametrize('game', ['connect4', 'brandubh', 'trimok', 'connect4:32', 'connect4:64'])
 def test_mcts_search_on_the_persistent_launch(game):
     """MCTS.search(gs, nn, sims, noise, temp) with nn = this package's NNetWrapper: ONE launch per call, the same tree as the
     find_leaf / nn(obs) / process_results loop bit for bit -- connect4's fused heads and the wide-head networks' exact launch
@@ -71,8 +71,11 @@ def test_mcts_search_on_the_persistent_launch(game):
     import torch
     from alphazero_general_amd import nnet as N
     from alphazero_general_amd.MCTS import MCTS
-    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
-    na = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[game]
+    name, _, width = game.partition(':')                              # 'connect4:32': the reference's default net (Coach.py:108-116) on connect4
+    Game = importlib.import_module('alphazero_general_amd.envs.' + name).Game
+    na = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[name]
+    if width:
+        na = N.dotdict(dict(N.DEFAULT_NET_ARGS, num_channels=int(width)))
     torch.manual_seed(3)
     net = N.NNetWrapper(Game, na, device='cuda:0', dtype=torch.float16)
     args = _args(_num_players=Game.num_players() + 1, numMCTSSims=64)

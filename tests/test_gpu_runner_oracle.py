@@ -34,8 +34,11 @@ pytestmark = pytest.mark.gpu
 def _setup(game, seed_net):
     import torch
     from alphazero_general_amd import nnet as N
-    Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
-    net_args = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[game]
+    name, _, width = game.partition(':')                              # 'connect4:32' = connect4 with the reference's default net (config 1)
+    Game = importlib.import_module('alphazero_general_amd.envs.' + name).Game
+    net_args = {'connect4': N.CONNECT4_NET_ARGS, 'brandubh': N.BRANDUBH_NET_ARGS, 'trimok': N.DEFAULT_NET_ARGS}[name]
+    if width:
+        net_args = N.dotdict(dict(N.DEFAULT_NET_ARGS, num_channels=int(width)))
     torch.manual_seed(seed_net)
     net = N.NNetWrapper(Game, net_args, device='cuda:0', dtype=torch.float16)
     net.refresh()
@@ -99,6 +102,7 @@ def test_runner_phase_launches_vs_oracle_with_real_net(game, heads, B, sims):
     ('trimok', 'search', 64, 50, 60), ('trimok', 'features', 64, 24, 60),
     ('connect4', 'search', 64, 100, 50),
     ('brandubh', 'exact', 48, 200, 60), ('trimok', 'exact', 64, 50, 60),
+    ('connect4:32', 'exact', 32, 25, 50),                        # BASELINE config 1: the default net's persistent launch (round 6)
 ])
 def test_runner_timed_launches_vs_oracle_with_real_net(game, form, B, sims, rounds):
     """The launches bench.py times (--workload brandubh | trimok: azg_search_wide_f16 with sparse heads at 200 / 50 simulations per
