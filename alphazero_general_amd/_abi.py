@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AZG_LIB_PATH') or os.path.join(HERE, 'lib', 'libazg_hip.so')   # (override: measurement builds)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 GAME_CONNECT4, GAME_BRANDUBH, GAME_TRIMOK = 0, 1, 2
 E_INVALID_ARG, E_HIP, E_INVALID_ACTION, E_TREE_FULL, E_EXAMPLES_FULL, E_UNSUPPORTED, E_INTERNAL, E_FLOATING_POINT = -1, -2, -3, -4, -5, -6, -7, -8
@@ -104,6 +104,7 @@ SYMBOLS = {
     'azg_set_shuffle_tape': (_i, [_vp, _vp, _vp, _i]),
     'azg_search_wide_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_search_wide_exact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i]),
+    'azg_search_wide_tile_info': (_i, [_vp, _i, _i, _i, _i32p]),
     'azg_profile_net_enable': (_i, [_i]),
     'azg_profile_net_read': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'azg_profile_enable': (_i, [_vp, _i]),

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -716,8 +717,10 @@ extern "C" int azg_last_actions_dev(azg_engine *e, int32_t **actions) {
     return AZG_OK;
 }
 
+// occ (optional): the workgroups of THIS instantiation a CU of this device holds at once (the occupancy query with the launch's own LDS
+// size) -- what the tile choice of the persistent launches is derived from instead of a constant for one chip
 template <int H, int W, int BOARDS, int C, int PSPLIT = 1, class SEARCH = NoSearch, int KSPLIT = 1>
-static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}, bool init_only = false) {
+static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{}, bool init_only = false, int *occ = nullptr) {
     constexpr bool IS_SEARCH = !__is_same(SEARCH, NoSearch);
     using GEO = TowerGeom<H, W, BOARDS, C>;
     constexpr size_t LDS_IMG = []() {                          // the image (+ the wide search mode's scratch behind it)
@@ -756,6 +759,12 @@ static int launch_tower(hipStream_t s, const TowerParams &P, SEARCH sa = SEARCH{
         }
     }
     if (LDS_BYTES > (size_t)d_lds[dev]) return fail(AZG_E_INVALID_ARG, "this tower does not fit the LDS of its tile (too many residual blocks)");
+    if (occ) {
+        int n = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&k_tower2<H, W, BOARDS, C, PSPLIT, SEARCH, KSPLIT>),
+                                                            C * 2 * PSPLIT * KSPLIT, LDS_BYTES));
+        *occ = n > 0 ? n : 1;
+    }
     if (init_only) return AZG_OK;                            // (first-use allocations must not happen inside a stream capture)
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = (P.boards + BOARDS - 1) / BOARDS + (P.rows_per_model ? P.nmodels - 1 : 0);
@@ -862,6 +871,14 @@ extern "C" int azg_profile_net_read(double *ms3, int64_t *launches3) {
     return AZG_OK;
 }
 
+static int device_cus(int *cus) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (*cus <= 0) *cus = 1;
+    return AZG_OK;
+}
+
 // Boards per workgroup tile: the big tile has the least MFMA padding, small ones fill the chip at small batches (the arena,
 // the single-tree API, brandubh's 512 games per GPU).  Tuning builds (hipcc -DAZG_TUNING, tools/sweep_small.py) let the
 // environment override the choice: AZG_TOWER_BOARDS, AZG_TOWER_PSPLIT; the product library reads no environment.
@@ -873,8 +890,11 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
     constexpr int forced = 0, psplit = 0;
 #endif
     const int n = P.boards;
+    // (tile thresholds in boards per CU of THIS device -- measured on 256 CUs: 640 / 1280 boards = 2.5 / 5 per CU ... -- not in boards)
+    int cus = 1;
+    { const int r = device_cus(&cus); if (r != AZG_OK) return r; }
     if (game == AZG_GAME_CONNECT4 && channels == 128) {
-        const int bt = forced ? forced : n <= 640 ? 1 : n <= 1280 ? 2 : 4;
+        const int bt = forced ? forced : 2 * n <= 5 * cus ? 1 : n <= 5 * cus ? 2 : 4;
         if (bt == 1 && psplit == 2) return launch_tower<C4::H, C4::W, 1, 128, 2>(s, P);   // 8 waves, 2 + 1 pixel subtiles: measured slower (101 vs 69 us)
         if (bt == 1) return launch_tower<C4::H, C4::W, 1, 128>(s, P);
 #ifdef AZG_TUNING
@@ -885,7 +905,7 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
     }
     if (game == AZG_GAME_CONNECT4 && channels == 64) return launch_tower<C4::H, C4::W, 4, 64>(s, P);
     if (game == AZG_GAME_CONNECT4 && channels == 32) {           // the default net of Coach.py:108-116 (BASELINE config 1): one cout group,
-        const int bt = forced ? forced : n <= 1024 ? 2 : 4;      // the tile's pixel subtiles dealt to two waves
+        const int bt = forced ? forced : n <= 4 * cus ? 2 : 4;   // the tile's pixel subtiles dealt to two waves
         if (bt == 2) return launch_tower<C4::H, C4::W, 2, 32, 2>(s, P);
         return launch_tower<C4::H, C4::W, 4, 32, 2>(s, P);
     }
@@ -893,8 +913,8 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
         // measured (us per evaluation incl. heads, 256 / 512 / 1024 / 2048 boards): 1 board, no split 39 / 47 / 66 / 107;
         // 1 board, split 35 / 46 / 80 / 113; 2 boards, split 39 / 43 / 63 / 113
         // round 3, the k-split 1-board tile (`sp == 3`): 28 / 36 / 64 / 114 -- the shape up to 512 boards
-        const int bt = forced ? forced : n <= 512 ? 1 : 2;
-        const int sp = psplit ? psplit : n <= 512 ? 3 : n <= 1024 ? 2 : 1;
+        const int bt = forced ? forced : n <= 2 * cus ? 1 : 2;
+        const int sp = psplit ? psplit : n <= 2 * cus ? 3 : n <= 4 * cus ? 2 : 1;
         if (bt == 1 && sp == 3) return launch_tower<BR::H, BR::W, 1, 64, 1, NoSearch, 2>(s, P);   // k-split: 4 waves = (cout group, k group)
         if (bt == 1 && sp == 2) return launch_tower<BR::H, BR::W, 1, 64, 2>(s, P);
         if (bt == 1) return launch_tower<BR::H, BR::W, 1, 64>(s, P);
@@ -903,7 +923,7 @@ static int dispatch_tower(hipStream_t s, int game, int channels, const TowerPara
     }
     if (game == AZG_GAME_BRANDUBH && channels == 128) return launch_tower<BR::H, BR::W, 2, 128>(s, P);
     if (game == AZG_GAME_TRIMOK && channels == 32) {             // one cout group
-        const int bt = forced ? forced : n <= 2048 ? 2 : 5;
+        const int bt = forced ? forced : n <= 8 * cus ? 2 : 5;
         const int sp = psplit ? psplit : 2;                      // (256 boards: 26 us unsplit, 23 us split in two)
         if (bt == 2 && sp == 4) return launch_tower<TM::H, TM::W, 2, 32, 4>(s, P);
         if (bt == 2 && sp == 2) return launch_tower<TM::H, TM::W, 2, 32, 2>(s, P);
@@ -1002,9 +1022,10 @@ extern "C" int azg_search_f16(azg_engine *e, void *stream, const void *w, const 
     EvPair ep; const bool prof = sims > 0 && netprof_begin((hipStream_t)stream, ep);
     // games per workgroup like the stand-alone tower's tile (dispatch_tower): small engines -- the single-tree MCTS class, config 1's 32 games --
     // take one game per workgroup (a lone 4-board tile runs at the tower's latency for four boards: 170 us per simulation against ~60)
-    int r;
-    if (e->v.B <= 640) r = launch_tower<C4::H, C4::W, 1, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
-    else if (e->v.B <= 1280) r = launch_tower<C4::H, C4::W, 2, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);
+    int r, cus = 1;
+    r = device_cus(&cus); if (r != AZG_OK) { g_kev = nullptr; return r; }
+    if (2 * e->v.B <= 5 * cus) r = launch_tower<C4::H, C4::W, 1, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);   // sims == 0: set up only
+    else if (e->v.B <= 5 * cus) r = launch_tower<C4::H, C4::W, 2, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);
     else r = launch_tower<C4::H, C4::W, 4, 128, 1, SearchArgs<C4>>((hipStream_t)stream, P, sa, sims == 0);
     netprof_end((hipStream_t)stream, 2, prof, ep);
     return r;
@@ -1035,7 +1056,176 @@ extern "C" int azg_search_arena_f16(azg_engine *e, void *stream, int nmodels, co
     return r;
 }
 
-// the persistent wide-head search launch, sparse heads (EXACT = false: hd) or full-width heads (EXACT = true: hf)
+// ---- the persistent wide-head search launch: tiles, the device-derived tile model, the set-up autotune ----------------------------------
+#ifdef AZG_TUNING
+static int wide_forced_tile() { static const int f = getenv("AZG_WIDE_BOARDS") ? atoi(getenv("AZG_WIDE_BOARDS")) : 0; return f; }
+#else
+static constexpr int wide_forced_tile() { return 0; }
+#endif
+
+// ONE tile shape of the launch (bt games per workgroup) for (game, tower width); AZG_E_UNSUPPORTED: no such tile.  sparse heads (EXACT =
+// false: hd) or full-width heads (EXACT = true: hf).  init: one-time set-up only.  occ: see launch_tower.
+template <bool EXACT>
+static int wide_tile_launch(azg_engine *e, hipStream_t s, const TowerParams &P, int channels, int bt, const HeadRows &hd, const HeadsFull &hf, int sims,
+                            bool init, int *occ) {
+    const int game = e->cfg.game;
+    if (game == AZG_GAME_BRANDUBH && channels == 64) {
+        // two workgroups of four wavefronts per CU in every shape
+        using SW = SearchWide<BR, 2, EXACT>;
+        const SW sa{e->v, sims, hd, hf};
+        if (bt == 1) return launch_tower<BR::H, BR::W, 1, 64, 1, SW, 2>(s, P, sa, init, occ);      // four wavefronts per game (walk, priors, masks, rules), k-split tower
+        if (bt == 2) return launch_tower<BR::H, BR::W, 2, 64, 2, SW>(s, P, sa, init, occ);         // walker + helper per game
+        if (bt == 3) return launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init, occ);         // solo tree phase: one wavefront per game
+        if (bt == 4) return launch_tower<BR::H, BR::W, 4, 64, 2, SW>(s, P, sa, init, occ);         // (two 4-game workgroups fill a CU's LDS with a 4-block tower's
+                                                                                                    //  parameters beside them: a deeper tower does not fit -> AZG_E_INVALID_ARG)
+#ifdef AZG_TUNING
+        if (bt == 8) return launch_tower<BR::H, BR::W, 8, 64, 4, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init, occ);   // one workgroup of eight wavefronts per CU
+        if (bt == 12) return launch_tower<BR::H, BR::W, 2, 64, 2, SearchWide<BR, 1, EXACT>, 2>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init, occ);  // 2 games, 8 wavefronts (k-split), one workgroup per CU
+        if (bt == 14) return launch_tower<BR::H, BR::W, 4, 64, 2, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init, occ);  // (what the spills cost: the 4-board tile with the whole register file)
+#endif
+    } else if (game == AZG_GAME_TRIMOK && channels == 32) {
+        if (bt == 1) return launch_tower<TM::H, TM::W, 1, 32, 2, SearchWide<TM, 1, EXACT>>(s, P, SearchWide<TM, 1, EXACT>{e->v, sims, hd, hf}, init, occ);
+        if (bt == 2) return launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init, occ);   // walker + helper per game
+#ifdef AZG_TUNING
+        if (bt == 4) return launch_tower<TM::H, TM::W, 4, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init, occ);
+#endif
+    } else if (game == AZG_GAME_CONNECT4 && channels == 32) {
+        // the reference's DEFAULT net (Coach.py:108-116: 32 channels x 4 blocks, 16 + 16 head channels -- BASELINE config 1's network and what an
+        // unconfigured Coach trains) on connect4: factorised heads, so the wide search mode; tiles like the 3-player env's 32-channel tower
+        if (bt == 1) return launch_tower<C4::H, C4::W, 1, 32, 2, SearchWide<C4, 1, EXACT>>(s, P, SearchWide<C4, 1, EXACT>{e->v, sims, hd, hf}, init, occ);
+        if (bt == 2) return launch_tower<C4::H, C4::W, 2, 32, 4, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init, occ);   // walker + helper per game
+    } else if (game == AZG_GAME_CONNECT4 && channels == 64) {
+        if (bt == 1) return launch_tower<C4::H, C4::W, 1, 64, 2, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init, occ);   // four wavefronts per game
+        if (bt == 2) return launch_tower<C4::H, C4::W, 2, 64, 2, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init, occ);   // walker + helper per game
+    }
+    return AZG_E_UNSUPPORTED;
+}
+
+static int wide_max_tile(int game, int channels) {
+    if (game == AZG_GAME_BRANDUBH && channels == 64) return 4;
+    if ((game == AZG_GAME_TRIMOK && channels == 32) || (game == AZG_GAME_CONNECT4 && (channels == 32 || channels == 64))) return 2;
+    return 0;
+}
+
+// The tile model (used when no measurement exists: a launch that is being captured without a set-up call before it).  Nothing in it is
+// a constant of one chip or one depth: a tile of t games gives n = ceil(B / t) workgroups; they run in rounds of cus x occ(t) (CU count of
+// THIS device x the occupancy query of the tile's kernel with its LDS for THIS depth); a workgroup's chain per simulation is
+// fixed(t) [tree phase + heads] + conv(t) x (2 nblocks + 1) [the tower], in k cycles, from the phase stamps of the measurement build
+// (profiles/r05_phase_budget.json, r05_wide_tile_sweep.txt: brandubh 4-block chain exact 83 / 105 / 123 / 161, sparse 54 / 83 / 109 / 146 at
+// 1 / 2 / 3 / 4 games per workgroup, of which the tower 37 / 62 / 78 / 100 -- i.e. per conv 4.1 / 6.9 / 8.7 / 11.1); a last round that
+// fills at most half of the chip's slots runs without a neighbour on its CU (x 0.82: 70 vs 83 ... 124 vs 161 measured).
+template <bool EXACT>
+static int wide_tile_model(azg_engine *e, int channels, int nblocks, int cus, const int *occ) {
+    const int game = e->cfg.game, B = e->v.B, tmax = wide_max_tile(game, channels);
+    if (game != AZG_GAME_BRANDUBH) {
+        // one game per workgroup up to two games per CU (3-player env, M expansions/s at 256 / 512 / 1024 games on 256 CUs: one game per
+        // workgroup 20.7 / 37.4 / 39.4, two 16.3 / 31.3 / 48.0: profiles/r05_wide_tile_sweep.txt); beyond that the shared weight stream wins
+        return (occ[0] > 0 && B <= 2 * cus) || tmax < 2 || occ[1] <= 0 ? 1 : 2;
+    }
+    static const double fixed_exact[4] = {46, 43, 45, 61}, fixed_sparse[4] = {17, 21, 31, 46}, conv[4] = {4.1, 6.9, 8.7, 11.1};
+    int bt = 1; double best = -1;
+    for (int t = 1; t <= tmax; t++) {
+        if (occ[t - 1] <= 0) continue;                          // this tile does not fit (LDS: too deep a tower)
+        const long round = (long)cus * occ[t - 1], n = (B + t - 1) / t, full = n / round, rem = n % round;
+        const double chain = (EXACT ? fixed_exact : fixed_sparse)[t - 1] + conv[t - 1] * (2 * nblocks + 1);
+        const double cost = full * chain + (rem == 0 ? 0 : rem * 2 <= round ? 0.82 * chain : chain);
+        if (best < 0 || cost < best) { best = cost; bt = t; }
+    }
+    return bt;
+}
+
+// what was decided for (device, game, width, heads, engine size, depth): tile, where it came from (0 model, 1 measured at set-up, 2 forced)
+struct WideTileKey { int dev, game, channels, exact, B, nblocks; bool operator<(const WideTileKey &o) const { return memcmp(this, &o, sizeof(*this)) < 0; } };
+struct WideTilePick { int bt, source, occ; float us[4]; };
+static std::mutex g_tile_mu;
+static std::map<WideTileKey, WideTilePick> g_tile;
+
+// Set-up autotune (sims == 0, never inside a capture): every tile shape this (game, width) has is timed ONCE on a scratch engine of the same
+// size -- fresh games, a node store for the trial only -- with THIS network: a warm launch and a timed launch of 8 simulations each; the
+// fastest is the engine's tile for (B, nblocks) from then on.  Tile shape changes no result (every shape is bit-identical to the
+// launch-per-phase form: tests/test_gpu_fullsize.py), so the measurement only decides speed.  Falls back to the model when the scratch
+// engine cannot be had (memory).
+template <bool EXACT>
+static int wide_tile_autotune(azg_engine *e, hipStream_t s, const TowerParams &P, int channels, const HeadRows &hd, const HeadsFull &hf, const int *occ,
+                              WideTilePick &pick) {
+    const int tmax = wide_max_tile(e->cfg.game, channels);
+    constexpr int TRIAL_SIMS = 8;
+    azg_config cfg = e->cfg;
+    cfg.sims_per_move = TRIAL_SIMS; cfg.nodes_per_tree = (2 * TRIAL_SIMS + 2) * e->gi.max_children + 64;
+    cfg.example_capacity = 0; cfg.result_capacity = 0; cfg.temp_table = nullptr; cfg.temp_table_len = 0; cfg.arena = 0;
+    azg_engine *tmp = nullptr;
+    if (azg_engine_create(&cfg, &tmp) != AZG_OK || !tmp) return AZG_E_HIP;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { azg_engine_destroy(tmp); return AZG_E_HIP; }
+    int best = 0; float best_ms = 0;
+    for (int t = 1; t <= tmax; t++) {
+        pick.us[t - 1] = 0;
+        if (occ[t - 1] <= 0) continue;
+        if (azg_engine_reset(tmp, s) != AZG_OK) continue;
+        TowerParams Q = P; Q.boards = tmp->v.B;
+        if (wide_tile_launch<EXACT>(tmp, s, Q, channels, t, hd, hf, TRIAL_SIMS, false, nullptr) != AZG_OK) continue;
+        (void)hipEventRecord(a, s);
+        const int r = wide_tile_launch<EXACT>(tmp, s, Q, channels, t, hd, hf, TRIAL_SIMS, false, nullptr);
+        (void)hipEventRecord(b, s);
+        if (r != AZG_OK || hipEventSynchronize(b) != hipSuccess) continue;
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+        pick.us[t - 1] = ms * 1e3f;
+        if (!best || ms < best_ms) { best = t; best_ms = ms; }
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    azg_engine_destroy(tmp);
+    (void)hipGetLastError();
+    if (!best) return AZG_E_HIP;
+    pick.bt = best; pick.source = 1;
+    return AZG_OK;
+}
+
+template <bool EXACT>
+static int wide_tile_pick(azg_engine *e, hipStream_t s, const TowerParams &P, int channels, const HeadRows &hd, const HeadsFull &hf, bool setup, WideTilePick &out) {
+    int dev = 0, cus = 1;
+    HIPCHK(hipGetDevice(&dev));
+    int r = device_cus(&cus); if (r != AZG_OK) return r;
+    const WideTileKey key{dev, e->cfg.game, channels, EXACT ? 1 : 0, e->v.B, P.nblocks};
+    {
+        std::lock_guard<std::mutex> lk(g_tile_mu);
+        auto it = g_tile.find(key);
+        if (it != g_tile.end() && (it->second.source != 0 || !setup)) { out = it->second; return AZG_OK; }
+    }
+    WideTilePick pick{1, 0, 1, {0, 0, 0, 0}};
+    const int tmax = wide_max_tile(e->cfg.game, channels);
+    if (tmax == 0) return AZG_E_UNSUPPORTED;
+    if (wide_forced_tile()) {
+        pick.bt = wide_forced_tile(); pick.source = 2;
+        r = wide_tile_launch<EXACT>(e, s, P, channels, pick.bt, hd, hf, 0, true, &pick.occ);
+        if (r != AZG_OK) return r;
+    } else {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cs);
+        const bool capturing = cs != hipStreamCaptureStatusNone;
+        int occ[4] = {0, 0, 0, 0};
+        for (int t = 1; t <= tmax; t++) {                        // set up every tile this network fits; its occupancy on this device
+            int o = 0;
+            if (capturing) {                                     // (no first-use allocation inside a capture: a tile that was never set up is left out)
+                continue;
+            }
+            if (wide_tile_launch<EXACT>(e, s, P, channels, t, hd, hf, 0, true, &o) == AZG_OK) occ[t - 1] = o;
+        }
+        if (capturing) {                                         // a captured launch without a set-up call before it: the model over what is set up
+            return fail(AZG_E_INVALID_ARG, "persistent wide-head search: call it once with sims == 0 (one-time set-up) before capturing it in a graph");
+        }
+        bool any = false;
+        for (int t = 0; t < tmax; t++) any |= occ[t] > 0;
+        if (!any) return fail(AZG_E_INVALID_ARG, "this tower does not fit the LDS of any tile of the persistent launch (too many residual blocks)");
+        pick.bt = wide_tile_model<EXACT>(e, channels, P.nblocks, cus, occ);
+        if (setup && !e->v.perm_tape) (void)wide_tile_autotune<EXACT>(e, s, P, channels, hd, hf, occ, pick);   // (failure: the model's pick stands)
+        pick.occ = occ[pick.bt - 1];
+    }
+    std::lock_guard<std::mutex> lk(g_tile_mu);
+    g_tile[key] = pick;
+    out = pick;
+    return AZG_OK;
+}
+
 template <bool EXACT>
 static int search_wide(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift, int nblocks, int channels,
                        const void *head1_w, const float *head1_b, const HeadRows &hd, const HeadsFull &hf, int feat_k, int sims) {
@@ -1044,79 +1234,44 @@ static int search_wide(azg_engine *e, void *stream, const void *w, const float *
     if (e->v.arena) return fail(AZG_E_UNSUPPORTED, "the persistent search launches are built for self-play engines");
     const int A = e->gi.action_size, NV = e->gi.num_players + 1, hw = e->gi.obs_h * e->gi.obs_w;
     if (feat_k != (hw * 16 + 31) / 32 * 32) return fail(AZG_E_INVALID_ARG, "feat_k must be H*W*16 rounded up to 32");
+    if (wide_max_tile(e->cfg.game, channels) == 0)
+        return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64, the 3-player env x 32 and connect4 x {32, 64} channels (use azg_select / network / azg_backup)");
     TowerParams P{nullptr, w, bias, pre_scale, pre_shift, nullptr, e->v.B, nblocks, nullptr, nullptr, nullptr, nullptr, A, NV, nullptr, head1_w, head1_b, nullptr, feat_k,
                   nullptr, 0, {}};
     hipStream_t s = (hipStream_t)stream;
-    EvPair ep; const bool prof = sims > 0 && netprof_begin(s, ep);
-    int r = AZG_E_UNSUPPORTED;
-    // Games per workgroup by the engine's size (SelfPlayAgent.pyx:23-26: the batch is whatever the caller made it).  Up to two games
-    // per CU (512 brandubh games, 256 of the 3-player env: BASELINE's 8- / 4-GPU shards) one game per workgroup fills the chip best;
-    // beyond that a CU holds several games anyway and a tile of several boards shares every weight fragment between them, pads fewer
-    // pixel lanes (brandubh: 196 of 208 instead of 49 of 64) and has a main loop long enough to amortise a layer's epilogue and barriers.
-#ifdef AZG_TUNING
-    static const int forced = getenv("AZG_WIDE_BOARDS") ? atoi(getenv("AZG_WIDE_BOARDS")) : 0;
-#else
-    constexpr int forced = 0;
-#endif
-    const bool init = sims == 0;
-    if (e->cfg.game == AZG_GAME_BRANDUBH && channels == 64) {
-        // two workgroups of four wavefronts per CU in every shape: 512 workgroups are one round of the chip
-        using SW = SearchWide<BR, 2, EXACT>;
-        const SW sa{e->v, sims, hd, hf};
-        // the tile that finishes the engine's games soonest: n = ceil(B / games per tile) workgroups run in rounds of 512 (two per CU); a
-        // workgroup's chain per simulation, in k cycles, with a neighbour on its CU / alone on it (measured: profiles/r05_wide_tile_sweep.txt)
-        static const int co_exact[4] = {83, 105, 123, 161}, alone_exact[4] = {70, 90, 100, 124};
-        static const int co_sparse[4] = {54, 83, 109, 146}, alone_sparse[4] = {45, 72, 90, 125};
-        int bt = 1;
-        if (forced) bt = forced;
-        else {
-            long best = -1;
-            for (int t = 1; t <= 4; t++) {
-                const int n = (e->v.B + t - 1) / t, full = n / 512, rem = n % 512;
-                const int co = (EXACT ? co_exact : co_sparse)[t - 1], al = (EXACT ? alone_exact : alone_sparse)[t - 1];
-                const long cost = (long)full * co + (rem == 0 ? 0 : rem <= 256 ? al : co);
-                if (best < 0 || cost < best) { best = cost; bt = t; }
-            }
-        }
-        if (bt == 1) r = launch_tower<BR::H, BR::W, 1, 64, 1, SW, 2>(s, P, sa, init);      // four wavefronts per game (walk, priors, masks, rules), k-split tower
-        else if (bt == 2) r = launch_tower<BR::H, BR::W, 2, 64, 2, SW>(s, P, sa, init);    // walker + helper per game
-        else if (bt == 3) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);    // solo tree phase: one wavefront per game
-#ifdef AZG_TUNING
-        else if (bt == 8) r = launch_tower<BR::H, BR::W, 8, 64, 4, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);   // one workgroup of eight wavefronts per CU
-        else if (bt == 12) r = launch_tower<BR::H, BR::W, 2, 64, 2, SearchWide<BR, 1, EXACT>, 2>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);  // 2 games, 8 wavefronts (k-split), one workgroup per CU
-        else if (bt == 14) r = launch_tower<BR::H, BR::W, 4, 64, 2, SearchWide<BR, 1, EXACT>>(s, P, SearchWide<BR, 1, EXACT>{e->v, sims, hd, hf}, init);  // (what the spills cost: the 4-board tile with the whole register file)
-#endif
-        else {
-            r = launch_tower<BR::H, BR::W, 4, 64, 2, SW>(s, P, sa, init);
-            // (two 4-game workgroups fill a CU's LDS to the last KB with a 4-block tower's parameters beside them: a deeper tower takes the
-            //  3-game tile, whose LDS holds the parameters of up to ~25 blocks)
-            if (r == AZG_E_INVALID_ARG && !forced) r = launch_tower<BR::H, BR::W, 3, 64, 2, SW>(s, P, sa, init);
-        }
-    } else if (e->cfg.game == AZG_GAME_TRIMOK && channels == 32) {
-        // (measured, M expansions/s at 256 / 512 / 1024 games: one game per workgroup 20.7 / 37.4 / 39.4, two 16.3 / 31.3 / 48.0, four -- solo --
-        //  - / 23.3 / 44.4: profiles/r05_wide_tile_sweep.txt)
-        const int bt = forced ? forced : e->v.B <= 512 ? 1 : 2;
-        if (bt == 1) r = launch_tower<TM::H, TM::W, 1, 32, 2, SearchWide<TM, 1, EXACT>>(s, P, SearchWide<TM, 1, EXACT>{e->v, sims, hd, hf}, init);
-#ifdef AZG_TUNING
-        else if (bt == 4) r = launch_tower<TM::H, TM::W, 4, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);
-#endif
-        else r = launch_tower<TM::H, TM::W, 2, 32, 4, SearchWide<TM, 2, EXACT>>(s, P, SearchWide<TM, 2, EXACT>{e->v, sims, hd, hf}, init);   // walker + helper per game
-    } else if (e->cfg.game == AZG_GAME_CONNECT4 && channels == 32) {
-        // the reference's DEFAULT net (Coach.py:108-116: 32 channels x 4 blocks, 16 + 16 head channels -- BASELINE config 1's network and what an
-        // unconfigured Coach trains) on connect4: factorised heads, so the wide search mode; tiles like the 3-player env's 32-channel tower
-        const int bt = forced ? forced : e->v.B <= 512 ? 1 : 2;
-        if (bt == 1) r = launch_tower<C4::H, C4::W, 1, 32, 2, SearchWide<C4, 1, EXACT>>(s, P, SearchWide<C4, 1, EXACT>{e->v, sims, hd, hf}, init);
-        else r = launch_tower<C4::H, C4::W, 2, 32, 4, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init);   // walker + helper per game
-    } else if (e->cfg.game == AZG_GAME_CONNECT4 && channels == 64) {
-        const int bt = forced ? forced : e->v.B <= 512 ? 1 : 2;
-        if (bt == 1) r = launch_tower<C4::H, C4::W, 1, 64, 2, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init);   // four wavefronts per game
-        else r = launch_tower<C4::H, C4::W, 2, 64, 2, SearchWide<C4, 2, EXACT>>(s, P, SearchWide<C4, 2, EXACT>{e->v, sims, hd, hf}, init);           // walker + helper per game
-    } else {
-        g_kev = nullptr;
-        return fail(AZG_E_UNSUPPORTED, "persistent wide-head search: brandubh x 64, the 3-player env x 32 and connect4 x {32, 64} channels (use azg_select / network / azg_backup)");
-    }
+    // Games per workgroup by the engine's size (SelfPlayAgent.pyx:23-26: the batch is whatever the caller made it): measured at set-up
+    // (sims == 0) on this device with this network, else the device-derived model above.  More boards per tile share every weight fragment
+    // between the tile's boards, pad fewer pixel lanes (brandubh: 196 of 208 instead of 49 of 64) and have a main loop long enough to
+    // amortise a layer's epilogue and barriers; fewer fill the chip at small engines.
+    WideTilePick pick;
+    int r = wide_tile_pick<EXACT>(e, s, P, channels, hd, hf, sims == 0, pick);
+    if (r != AZG_OK) return r;
+    if (sims == 0) return AZG_OK;                            // one-time set-up only
+    EvPair ep; const bool prof = netprof_begin(s, ep);
+    r = wide_tile_launch<EXACT>(e, s, P, channels, pick.bt, hd, hf, sims, false, nullptr);
+    if (r == AZG_E_UNSUPPORTED) { g_kev = nullptr; return fail(r, "persistent wide-head search: no such tile for this game / width"); }
     netprof_end(s, 2, prof, ep);
     return r;
+}
+
+// the tile a wide-head engine searches with: info12 = {games per workgroup, workgroups of a launch, workgroups a CU holds at once, CUs of the
+// device, source (0 device-derived model, 1 measured at set-up, 2 forced by a tuning build), trial simulations, 0, 0, then the set-up
+// measurement in ns per trial launch for 1 / 2 / 3 / 4 games per workgroup (0: not measured)}; AZG_E_INVALID_ARG before the first call of the
+// launch for this (engine size, depth)
+extern "C" int azg_search_wide_tile_info(azg_engine *e, int channels, int nblocks, int exact, int32_t *info12) {
+    int32_t *info8 = info12;
+    if (!e || !info8) return fail(AZG_E_INVALID_ARG, "null argument");
+    int dev = 0, cus = 1;
+    HIPCHK(hipGetDevice(&dev));
+    int r = device_cus(&cus); if (r != AZG_OK) return r;
+    std::lock_guard<std::mutex> lk(g_tile_mu);
+    auto it = g_tile.find(WideTileKey{dev, e->cfg.game, channels, exact ? 1 : 0, e->v.B, nblocks});
+    if (it == g_tile.end()) return fail(AZG_E_INVALID_ARG, "no persistent wide-head launch has been set up for this engine size and depth");
+    const WideTilePick &p = it->second;
+    info8[0] = p.bt; info8[1] = (e->v.B + p.bt - 1) / p.bt; info8[2] = p.occ; info8[3] = cus; info8[4] = p.source;
+    info8[5] = 8; info8[6] = info8[7] = 0;
+    for (int t = 0; t < 4; t++) info8[8 + t] = (int32_t)(p.us[t] * 1e3f);
+    return AZG_OK;
 }
 
 extern "C" int azg_search_wide_f16(azg_engine *e, void *stream, const void *w, const float *bias, const float *pre_scale, const float *pre_shift,

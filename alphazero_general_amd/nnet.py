@@ -431,6 +431,35 @@ class HipResNet:
                                                    len(self.blocks), int(self.CH), vp(self.head1_w), vp(self.head1_b), vp(self.head_rows),
                                                    vp(self.head2_b), int(self.feat_k), int(sims)))
 
+    def search_tile(self, engine, exact=False):
+        """the tile the persistent wide-head launch runs `engine` with (azg_search_wide_tile_info): dict(games_per_workgroup, workgroups,
+        workgroups_per_cu, cus, source = 'model' | 'measured' | 'forced', trial_us = set-up measurement per tile shape); None for
+        fused-head networks (connect4 x 128: the tile follows the engine's size alone) or before the launch's first call."""
+        if not (self.fact_head and self.can_search):
+            return None
+        import ctypes as C
+        info = (C.c_int32 * 12)()
+        if self.L.azg_search_wide_tile_info(engine.h, int(self.CH), len(self.blocks), int(bool(exact)), info) != 0:
+            return None
+        return dict(games_per_workgroup=int(info[0]), workgroups=int(info[1]), workgroups_per_cu=int(info[2]), cus=int(info[3]),
+                    source=('model', 'measured', 'forced')[int(info[4])], trial_sims=int(info[5]), trial_us=[round(info[8 + t] / 1e3, 1) for t in range(4)])
+
+    def stream_bytes(self, exact=True, kbar=None):
+        """bytes of network parameters ONE workgroup of a persistent launch streams from L2 per simulation (every workgroup re-reads them:
+        they do not fit LDS beside the image): all tower fragments + the head operands -- fused heads: the collapsed [H*W*128, 16] matrix;
+        factorised exact: the 1x1 head fragments + every policy subtile's and the value chain's fragments; sparse: the 1x1 head fragments
+        + kbar gathered rows of the collapsed matrix.  (bench.py: the operand-stream bound of the small-shard launches.)"""
+        tower = sum(int(t.numel()) for t in [self.stem_w] + [t for b in self.blocks for t in (b['w1'], b['w2'])]) * 2
+        if self.fused_head:
+            head = int(self.head_w_packed.numel()) * 2
+        elif self.fact_head and exact:
+            head = (int(self.head1_w.numel()) + int(self.head2_wps.numel()) + int(self.head2_wv.numel())) * 2
+        elif self.fact_head:
+            head = int(self.head1_w.numel()) * 2 + int((kbar or 0) + self.NV) * self.feat_k * 2
+        else:
+            head = int(self.head_w_wide.numel()) * 2
+        return dict(tower=tower, heads=head, total=tower + head)
+
     @staticmethod
     def forward_models(nets, x_all, policy_all, value_all, rows_per_model):
         """Arena evaluation in ONE launch without a host read of the batch split: nets[m] (HipResNets of one architecture)

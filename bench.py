@@ -404,6 +404,8 @@ def rooflines(c, netprof, prof):
              'launch_us_min_median_max': [round(each[0], 2), round(each[len(each) // 2], 2), round(each[-1], 2)] if each else None,
              'algorithmic_flops_per_launch': flops_leaf * units, 'mfma_issued_over_algorithmic': issued_frac(),
              'traffic': traffic, 'traffic_source': src}
+        if fam == 'search':
+            r['operand_stream'] = operand_stream(us, units // max(Bl, 1))
         if busy:
             # FLOPs the MFMA pipes really executed in the profiled launch (SQ_VALU_MFMA_BUSY_CYCLES / 16 cycles per v_mfma_f32_16x16x32_f16
             # x 16 384 FLOP) over THIS run's launch time: what `frac` would be without credit for the skipped zero products
@@ -411,6 +413,29 @@ def rooflines(c, netprof, prof):
             r['executed_flops_per_launch'] = ex
             r['executed_frac'] = round(ex / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
         return r
+
+    def operand_stream(us, nsims):
+        """The bound that applies to a SMALL-shard persistent launch (one or two boards per workgroup): every workgroup streams the whole
+        parameter set -- tower fragments + head operands, HipResNet.stream_bytes -- from L2 through its CU's L1 miss path once per
+        simulation (nothing of it fits LDS beside the image), whatever the MFMA pipes could do with it.  achieved = bytes x workgroups x
+        simulations / launch time; peak = 64 B/clk/CU (the path's width) x the nominal clock x the device's CUs; the ceiling MEASURED on this
+        access pattern is 46-57 B/clk/CU (profiles/notes_r02_r04_experiments.md section 3d), i.e. frac 0.72-0.89 is the practical limit."""
+        hip = net._hip
+        if hip is None:
+            return None
+        exact = c.search_heads != 'sparse'
+        tile = hip.search_tile(c.engines[0], exact=exact) if (hip.fact_head and not arena) else None
+        cus = torch.cuda.get_device_properties(c.engines[0].device).multi_processor_count
+        gpw = tile['games_per_workgroup'] if tile else (1 if arena or 2 * Bl <= 5 * cus else 2 if Bl <= 5 * cus else 4)   # (connect4 x 128: azg_search_f16's rule)
+        sb = hip.stream_bytes(exact=exact, kbar=W['kbar'])
+        nwg = (Bl + gpw - 1) // gpw
+        total = float(sb['total']) * nwg * nsims
+        gbs = total / (us * 1e-6) / 1e9
+        peak = 64.0 * CLOCK_GHZ_NOMINAL * cus
+        return {'bound': 'l2->l1 operand stream: every workgroup re-reads the network parameters once per simulation', 'games_per_workgroup': gpw,
+                'tile': tile, 'workgroups': nwg, 'bytes_per_workgroup_per_sim': sb, 'bytes_per_launch': total, 'achieved': round(gbs, 1),
+                'peak': round(peak, 1), 'unit': 'GB/s', 'frac': round(gbs / peak, 4), 'B_per_clk_per_cu_at_nominal_clock': round(gbs / (CLOCK_GHZ_NOMINAL * cus), 2),
+                'peak_B_per_clk_per_cu': 64, 'measured_ceiling_B_per_clk_per_cu': [46, 57], 'cus': cus, 'clock_ghz': CLOCK_GHZ_NOMINAL}
 
     skind = ('Arena', 'C4', 'azg_search_arena_f16') if arena else ('Args', 'C4', 'azg_search_f16') if net._hip is not None and net._hip.fused_head else \
         ('Wide', W['game'], 'azg_search_wide_exact_f16' if c.search_heads == 'exact' else 'azg_search_wide_f16')
@@ -599,6 +624,42 @@ def compat_run(W, net, seconds=12.0, workers=2, games_per_worker=None):
                     'Coach.processSelfPlayBatches with the GPU net: per simulation two process hops + H2D + D2H of the batch' % workers}
 
 
+def projected_scaling(out, others, shards):
+    """BASELINE's metric is quoted at 1/2/4/8 GPUs.  Games shard with ZERO communication during search, so an N-GPU job
+    runs N copies of the per-GPU shard and its throughput is N x the shard's 1-GPU value -- minus the exchange step once per iteration.
+    Configs 3-5 name TOTAL games: more GPUs = SMALLER shards, and small shards run below the large ones' rate (one or two boards per
+    workgroup: bound by the parameter stream, `operand_stream`).  Every figure here is computed from shards TIMED ON ONE GPU in this run
+    (`strong_scaling_shards`, `other_workloads`): a projection, stated as one, until an 8-GPU node measures it."""
+    def val(name, B):
+        rec = shards.get('%s_%d' % (name, B)) if shards else None
+        if rec is None and others and WORKLOADS[name]['B'] == B:
+            rec = others.get(name)
+        return rec.get('value') if rec and 'value' in rec else None
+    proj = {}
+    for label, name, total, gpus in (('config3_brandubh_4096_games_200_sims', 'brandubh', 4096, (1, 2, 4, 8)),
+                                     ('config5_trimok_1024_games_50_sims', 'trimok', 1024, (1, 2, 4)),
+                                     ('config4_arena_512_games_100_sims', 'arena', 512, (1, 2))):
+        v1 = val(name, total)
+        rows = []
+        for n in gpus:
+            vs = val(name, total // n)
+            if v1 and vs:
+                rows.append({'gpus': n, 'games_per_gpu': total // n, 'shard_value_1gpu': vs, 'projected_value': round(n * vs, 1),
+                             'speedup': round(n * vs / v1, 3), 'efficiency': round(vs / v1, 3)})
+        if rows:
+            proj[label] = {'scaling': 'strong (total games fixed)', 'points': rows, 'at_config_gpus': rows[-1]}
+    k = max(out['steps'], 1)
+    ex = out.get('exchange_ms') or 0.0
+    proj['config2_connect4_2048_games_per_gpu'] = {
+        'scaling': 'weak (games per GPU fixed)', 'per_gpu_value': out['value'],
+        'points': [{'gpus': n, 'projected_value': round(n * out['value'] * (out['ms_per_step'] * k) / (out['ms_per_step'] * k + ex), 1)} for n in (1, 2, 4, 8)],
+        'efficiency': round((out['ms_per_step'] * k) / (out['ms_per_step'] * k + ex), 4),
+        'note': 'no communication during search; the only N-rank cost is the exchange step once per iteration (here: %.3f ms per %d rounds at world 1; '
+                'the all-gather moves each rank\'s shard over its own xGMI link)' % (ex, k)}
+    proj['basis'] = 'shards timed on ONE GPU in this run; N-GPU value = N x shard value (independent ranks); not a multi-GPU measurement'
+    return proj
+
+
 def workload_label(c):
     return '%s %s, %d games/GPU x %d sims/move, fp16 ResNet %dch x %d, random-init, %s' % (
         c.W['game'], 'arena (two nets)' if c.arena else 'self-play', c.B, c.sims, c.net.args.num_channels, c.net.args.depth,
@@ -707,7 +768,7 @@ def main():
                                 'games_per_sec': round(ot['games'] / ot['dt'], 2), 'steps': 8, 'warmup': 2,
                                 'ms_per_step': round(ot['dt'] * 1e3 / 8, 3), 'fused_search_launch': oc.fused_search, 'search_heads': oc.search_heads,
                                 'roofline': None if orf is None else {k: orf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
-                                                                                             'executed_frac', 'avg_launch_us', 'launches_timed', 'traffic')},
+                                                                                             'executed_frac', 'avg_launch_us', 'launches_timed', 'traffic', 'operand_stream')},
                                 'tree_launch_us': None if otr is None else otr['avg_launch_us']}
                 if opb is not None:
                     others[name]['phase_budget'] = opb
@@ -748,11 +809,12 @@ def main():
                         shards[key] = {'workload': workload_label(oc), 'games_per_gpu': Bs, 'gpus_at_this_shard_size': WORKLOAD_TOTAL_GAMES[name] // Bs,
                                        'value': round(ot['expansions'] / ot['dt'], 1), 'unit': 'expansions/s', 'games_per_sec': round(ot['games'] / ot['dt'], 2),
                                        'steps': 4, 'warmup': 1, 'ms_per_step': round(ot['dt'] * 1e3 / 4, 3), 'search_heads': oc.search_heads,
-                                       'roofline': None if orf is None else {k: orf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'launches_timed')}}
+                                       'roofline': None if orf is None else {k: orf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'launches_timed', 'operand_stream')}}
                         release(oc)
                     except Exception as ex:                          # noqa: BLE001
                         shards[key] = {'error': '%s: %s' % (type(ex).__name__, ex)}
             out['strong_scaling_shards'] = shards
+            out['projected_scaling'] = projected_scaling(out, others, shards)
     elif world == 1 and a.compat and not c.arena:
         out['compat'] = compat_run(c.W, c.net)
     print(json.dumps(out))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AZG_ABI_VERSION 5
+#define AZG_ABI_VERSION 6
 
 typedef enum azg_status {
     AZG_OK = 0,
@@ -309,6 +309,15 @@ int  azg_search_wide_exact_f16(azg_engine *e, void *stream, const void *w_packed
                                const float *pre_shift_dev, int nblocks, int channels, const void *head1_w_packed_dev,
                                const float *head1_b_dev, const void *wps_packed_dev, const void *wv_packed_dev, const float *head_b_dev,
                                int feat_k, int sims);
+
+/* The tile the persistent wide-head launches of `e` run with -- games per workgroup, picked per (device, game, tower width, heads, engine
+ * size, depth): MEASURED at the launch's one-time set-up (sims == 0: every tile shape this game / width has is timed once, 8 simulations on
+ * a scratch engine of the same size with the caller's network; tile shape changes no result), else a model derived from the device (CU
+ * count, the occupancy query of each tile's kernel with its LDS at this depth) and the depth.  info12 = {games per workgroup, workgroups of a
+ * launch, workgroups a CU holds at once, CUs, source (0 model, 1 measured, 2 forced by a tuning build), simulations per trial launch, 0, 0,
+ * ns per trial launch at 1 / 2 / 3 / 4 games per workgroup (0: not measured)}.  AZG_E_INVALID_ARG before the first call of the launch for this engine size and depth.
+ * (SelfPlayAgent.pyx:23-26: the batch size is whatever the caller made it; NNetArchitecture.py:78-84: depth is a free argument.) */
+int  azg_search_wide_tile_info(azg_engine *e, int channels, int nblocks, int exact, int32_t *info12);
 
 /* Collapsed heads for action spaces too wide to fuse behind the tower (A + NV > 16; brandubh: 588 + 3): the same
  * [k = H*W*C, A+NV] matrix applied to the final stream y [boards, k] fp16 that azg_resnet_tower_f16 stores, then the

@@ -1,0 +1,28 @@
+"""The tile choice of the persistent wide-head launches is derived from the device and measured at set-up, not a table of constants for
+one chip and one depth: for 4- and 8-block brandubh towers at the 8- / 4- / 2-GPU shard sizes and in between, the tile
+the PRODUCT picks must be within 5 % of the best tile a tuning build can force (tools/tile_pick_check.py: one process per library)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wide_tile_pick_is_within_5_percent_of_the_best_forced_tile(tmp_path):
+    out = str(tmp_path / 'tiles.json')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'tile_pick_check.py'), '--game', 'brandubh', '--sizes', '512,768,1024,2048', '--depths', '4,8',
+                        '--sims', '40', '--out', out], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=2400)
+    assert r.returncode == 0, r.stdout.decode(errors='replace')[-3000:]
+    res = json.load(open(out))
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'tile_pick_check.json'), 'w') as f:
+        json.dump(res, f, indent=1)
+    for key, c in res['cells'].items():
+        assert c['pick'] is not None and c['pick']['source'] == 'measured', (key, c)
+        assert c['pick']['cus'] > 0 and c['pick']['workgroups_per_cu'] >= 1
+        assert c['pick_over_best'] is not None and c['pick_over_best'] <= 1.05, (key, c)
+    assert res['cells']['4/512']['pick']['games_per_workgroup'] == 1 and res['cells']['4/2048']['pick']['games_per_workgroup'] == 4
