@@ -105,6 +105,7 @@ SYMBOLS = {
     'azg_search_wide_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_search_wide_exact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_search_wide_tile_info': (_i, [_vp, _i, _i, _i, _i32p]),
+    'azg_debug_bounds_site': (_i, [_vp, _vp, _i32p, _i32p]),
     'azg_profile_net_enable': (_i, [_i]),
     'azg_profile_net_read': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'azg_profile_enable': (_i, [_vp, _i]),

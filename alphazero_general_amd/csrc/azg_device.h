@@ -97,7 +97,7 @@ struct View {
 #define AZG_TSTAMP(ev, slot, lane, i) do { } while (0)
 #endif
 
-enum { GC_GAMES = 0, GC_RESULTS = 1, GC_EXAMPLES = 2, GC_ERROR = 3, GC_MAXNODES = 4, GC_MAXLIVE = 5 };
+enum { GC_GAMES = 0, GC_RESULTS = 1, GC_EXAMPLES = 2, GC_ERROR = 3, GC_MAXNODES = 4, GC_MAXLIVE = 5, GC_BOUNDS_SITE = 6 };
 
 // ------------------------------------------------------------------------------------------------ random tape
 // Definition in DESIGN.md "Random tape"; independent re-implementation of the spec (the oracle has its own).

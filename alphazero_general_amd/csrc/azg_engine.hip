@@ -467,17 +467,50 @@ extern "C" int azg_engine_info(azg_engine *e, int32_t *out8) {
 
 extern "C" int azg_set_shuffle_tape(azg_engine *e, void *stream, const int16_t *ranks_host, int len) {
     if (!e || len < 0) return fail(AZG_E_INVALID_ARG, "null engine or negative length");
-    hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipStreamSynchronize(s));
+    const size_t n = (size_t)e->v.B * (size_t)(len > 0 ? len : 0);
+    // every rank is an offset into an expansion's block of k <= max_children nodes: refuse anything else here, on the host (the device
+    // checks rank < k per expansion as well and raises the sticky AZG_E_INVALID_ARG)
+    if (ranks_host) for (size_t i = 0; i < n; i++)
+        if (ranks_host[i] < 0 || ranks_host[i] >= e->gi.max_children) return fail(AZG_E_INVALID_ARG, "shuffle tape: a rank is outside [0, max_children)");
+    // the View -- and with it this pointer -- is passed BY VALUE to every launch, also to launches captured in a hipGraph: work of ANY stream
+    // may still read the old tape, so the whole device is drained before it is freed.  A graph captured while a tape was set keeps replaying
+    // with the pointer it captured: re-capture after changing the tape (selfplay's runners capture after the engine is configured)
+    HIPCHK(hipDeviceSynchronize());
     if (e->d_perm) { (void)hipFree(e->d_perm); e->d_perm = nullptr; }
     e->v.perm_tape = nullptr; e->v.perm_len = 0;
     if (!ranks_host || len == 0) return AZG_OK;
-    const size_t n = (size_t)e->v.B * (size_t)len;
     HIPCHK(hipMalloc((void **)&e->d_perm, n * sizeof(int16_t)));
     HIPCHK(hipMemcpy(e->d_perm, ranks_host, n * sizeof(int16_t), hipMemcpyHostToDevice));
     e->v.perm_tape = e->d_perm; e->v.perm_len = len;
     return AZG_OK;
 }
+
+// bounds-checked builds (-DAZG_DEBUG_BOUNDS): the first check that failed (0: none; site numbers: csrc/azg_kernels.h AZG_BOUNDS_OK).
+// *checked = 1 if this binary carries the checks at all.
+extern "C" int azg_debug_bounds_site(azg_engine *e, void *stream, int32_t *site, int32_t *checked) {
+    if (!e || !site || !checked) return fail(AZG_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(site, e->v.gcount + GC_BOUNDS_SITE, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+#ifdef AZG_DEBUG_BOUNDS
+    *checked = 1;
+#else
+    *checked = 0;
+#endif
+    return AZG_OK;
+}
+
+#ifdef AZG_DEBUG_BOUNDS
+// bounds-checked builds only (not part of include/azg.h): overwrite the root's first_child of a slot's tree -- the positive control of
+// tools/debug_soak.py (a child block outside the live allocation must be caught by the checks, not read)
+extern "C" int azg_debug_poke_root_fc(azg_engine *e, void *stream, int slot, int32_t fc) {
+    int r = check_range(e, slot, 1); if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->v.hdr + (size_t)slot * e->v.T) + 16, &fc, sizeof(fc), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AZG_OK;
+}
+#endif
 
 extern "C" int azg_set_root_flags(azg_engine *e, int flags) {
     if (!e || flags < 0) return fail(AZG_E_INVALID_ARG, "null engine or negative flags");

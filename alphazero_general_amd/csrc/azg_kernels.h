@@ -27,6 +27,18 @@ AZG_DEV void load_node(const Node *p, uint4 &lo, uint4 &hi) {
     lo = q[0]; hi = q[1];
 }
 AZG_DEV void raise_error(const View &ev, int code) { atomicCAS(&ev.gcount[GC_ERROR], 0, code); }
+// The bounds-checked build (hipcc -DAZG_DEBUG_BOUNDS: alphazero_general_amd/build.py --variant debug; the reference turned its own checks
+// off, MCTS.pyx:2-6): every node / child-block / path index the tree kernels form is checked against the store's capacity, the tree's
+// live allocation and the path length BEFORE it is used.  A violation raises the sticky AZG_E_INTERNAL, records the first site in
+// gcount[GC_BOUNDS_SITE] (azg_debug_bounds_site) and the access is skipped.  The product build compiles the checks away.
+#ifdef AZG_DEBUG_BOUNDS
+AZG_DEV bool bounds_fail(const View &ev, int site) { raise_error(ev, AZG_E_INTERNAL); atomicCAS(&ev.gcount[GC_BOUNDS_SITE], 0, site); return false; }
+#define AZG_BOUNDS_OK(ev, site, cond) ((cond) ? true : bounds_fail(ev, site))
+#else
+#define AZG_BOUNDS_OK(ev, site, cond) true
+#endif
+// a child block [fc, fc + k) of a tree whose live space holds `alloc` nodes
+#define AZG_BLOCK_OK(ev, site, fc, k, alloc) AZG_BOUNDS_OK(ev, site, (fc) >= 0 && (k) > 0 && (k) <= G::MAXK && (fc) + (k) <= (alloc) && (alloc) <= (ev).cap)
 
 // a tree header in registers: one 64-byte line, every lane loads it (same address: one request, broadcast)
 struct HdrR {
@@ -90,10 +102,16 @@ AZG_DEV int add_children(const View &ev, int slot, Node *nodes, int &alloc, int 
             pos[c] = pc;
         }
     }
+    if (ev.perm_tape) {                                                      // a replayed rank outside [0, k) would write outside the expansion's k nodes
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < NC; c++) bad |= c * 64 + lane < k && (pos[c] < 0 || pos[c] >= k);
+        if (__ballot(bad)) { if (lane == 0) raise_error(ev, AZG_E_INVALID_ARG); return -1; }
+    }
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int i = c * 64 + lane;
-        if (i < k) {
+        if (i < k && AZG_BOUNDS_OK(ev, 1, pos[c] >= 0 && pos[c] < k && k <= G::MAXK)) {
             uint4 *q = reinterpret_cast<uint4 *>(nodes + fc + pos[c]);
             q[0] = make_uint4(0, 0, 0, 0);
             q[1] = pack_hi(-1, my_a[c], 0, 0, 0);
@@ -259,6 +277,7 @@ AZG_DEV void select_tree(const View &ev, int slot, int tree, const HdrR &hr, typ
         lv_t0 = __builtin_amdgcn_s_memtime();
 #endif
         if (k == 0 || fc < 0) { if (lane == 0) raise_error(ev, AZG_E_TREE_FULL); break; }
+        if (!AZG_BLOCK_OK(ev, 2, fc, k, hr.alloc) || !AZG_BOUNDS_OK(ev, 3, (hr.base == 0 || hr.base == ev.cap) && depth < ev.maxd)) break;
         if (gate(cur)) ctr = ev.tape_ctr[slot];
         NodeR sel; int bi;
         if constexpr (NCH > 1) { bi = k > 64 ? best_child<G, NCH>(ev, nodes, fc, k, cn, lane, sel) : best_child<G, 1>(ev, nodes, fc, k, cn, lane, sel); }
@@ -442,6 +461,7 @@ AZG_DEV void backup_policy(const View &ev, int slot, const HdrR &hr, Node *nodes
     constexpr int NCH = (G::MAXK + 63) / 64;
     if (hr.leaf_e || hr.leaf_fc < 0) return;                                 // :234-235 terminal: no policy update
     const int k = hr.leaf_k, fc = hr.leaf_fc;
+    if (!AZG_BLOCK_OK(ev, 4, fc, k, hr.alloc)) return;
     const bool at_root = hr.leaf == LEAF_IS_ROOT;
     if constexpr (NCH > 1) {
         if (k > 64) leaf_policy<G, NCH>(ev, slot, nodes, fc, k, at_root, pi, m_lds, scr, lane);
@@ -456,6 +476,7 @@ AZG_DEV void backup_path(const View &ev, int slot, int tree, HdrR &hr, Node *nod
     TreeHdr *h = ev.hdr + tree;
     const PathEnt *path = ev.path + (size_t)tree * ev.maxd;
     const int depth = hr.depth;
+    if (!AZG_BOUNDS_OK(ev, 5, depth >= 0 && depth <= ev.maxd && depth <= G::MAX_TURNS + 2)) return;
     uint4 ent[(G::MAX_TURNS + 2 + 63) / 64];                                 // the path, one level per lane
 #pragma unroll
     for (int j0 = 0, c = 0; j0 < G::MAX_TURNS + 2; j0 += 64, c++)
@@ -483,6 +504,7 @@ AZG_DEV void backup_path(const View &ev, int slot, int tree, HdrR &hr, Node *nod
             for (int pp = 1; pp < P; pp++) if (mover == pp) vm = val[pp];
             const float v = vsize > P ? vm + draw_share : vm;                // _get_value :291-295
             const int n = (int)ent[c].y; const float q = __uint_as_float(ent[c].z);
+            if (!AZG_BOUNDS_OK(ev, 6, idx >= 0 && idx < hr.alloc && hr.alloc <= ev.cap && n >= 0)) continue;
             Node *x = nodes + idx;
             const float qn = (((q * (float)n) + (v * 1.0f)) / ((float)(n + 1)));      // :282 (discount == 1)
             *reinterpret_cast<uint2 *>(x) = make_uint2((unsigned)(n + 1), __float_as_uint(qn));
@@ -851,6 +873,7 @@ __global__ __launch_bounds__(64) void k_root_stats(View ev, int what, float temp
     HdrR hr; load_hdr(ev.hdr + tree, hr);
     const Node *nodes = tree_nodes(ev, tree, hr.base);
     const int fc = hr.root.fc, k = hr.root.nchild;
+    if (k > 0 && !AZG_BLOCK_OK(ev, 11, fc, k, hr.alloc)) return;
     if (what == 0) {
         for (int a = lane; a < A; a += 64) counts[(size_t)slot * A + a] = 0;
         wave_sync();
@@ -891,6 +914,7 @@ AZG_DEV bool update_root(const View &ev, int slot, int tree, const typename G::S
         wave_sync();
     }
     int found = -1;
+    if (!AZG_BLOCK_OK(ev, 7, fc, k, __builtin_amdgcn_readfirstlane(h->alloc))) return false;
     for (int i0 = 0; i0 < k; i0 += 64) {
         int i = i0 + lane;
         uint64_t bal = __ballot(i < k && (int)nodes[fc + i].a == action);
@@ -930,6 +954,7 @@ __global__ __launch_bounds__(64) void k_compact(View ev, int force, int first_tr
     int nalloc = 0;
     if (hr.root.fc >= 0 && hr.root.nchild > 0) {                             // the root's child block -> to[0 .. k)
         const int k = hr.root.nchild;
+        if (!AZG_BLOCK_OK(ev, 8, hr.root.fc, k, hr.alloc)) return;
         for (int i = lane; i < k; i += 64) { uint4 lo, hi; load_node(from + hr.root.fc + i, lo, hi); uint4 *q = reinterpret_cast<uint4 *>(to + i); q[0] = lo; q[1] = hi; }
         nalloc = k;
     }
@@ -946,6 +971,7 @@ __global__ __launch_bounds__(64) void k_compact(View ev, int force, int first_tr
         while (todo) {                                                       // copy the frontier's child blocks, one parent at a time
             const int b = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
             const int sfc = rl(ofc, b), sk = rl(kk, b), dfc = rl(nfc, b);
+            if (!AZG_BLOCK_OK(ev, 9, sfc, sk, hr.alloc) || !AZG_BOUNDS_OK(ev, 10, dfc >= 0 && dfc + sk <= ev.cap)) continue;
             for (int j = lane; j < sk; j += 64) { uint4 lo, hi; load_node(from + sfc + j, lo, hi); uint4 *q = reinterpret_cast<uint4 *>(to + dfc + j); q[0] = lo; q[1] = hi; }
         }
         nalloc += total;
@@ -977,6 +1003,7 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
     HdrR hr; load_hdr(ev.hdr + tree, hr);
     const Node *nodes = tree_nodes(ev, tree, hr.base);
     const int fc = hr.root.fc, k = hr.root.nchild;
+    if (k > 0 && !AZG_BLOCK_OK(ev, 11, fc, k, hr.alloc)) return;
     float temp;
     if (ev.arena) temp = ev.arena_temp;                                      // :158
     else { int t = st.turns < ev.temp_len ? st.turns : ev.temp_len - 1; temp = ev.temp_table[t]; }   // :156-157

@@ -358,6 +358,13 @@ class DeviceEngine:
         out.copy_(torch.as_tensor(src, device=self.device))
         return out
 
+    def bounds_site(self):
+        """(site, checked): the first index check of a bounds-checked build that failed (0: none) and whether the loaded library carries
+        the checks at all (build.py --variant debug)"""
+        site, chk = C.c_int32(0), C.c_int32(0)
+        _abi.check(self.L.azg_debug_bounds_site(self.h, _stream(), C.byref(site), C.byref(chk)))
+        return int(site.value), bool(chk.value)
+
     def profile(self, on=True):
         _abi.check(self.L.azg_profile_enable(self.h, int(on)))
         self.profiling = bool(on)

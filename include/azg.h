@@ -310,6 +310,11 @@ int  azg_search_wide_exact_f16(azg_engine *e, void *stream, const void *w_packed
                                const float *head1_b_dev, const void *wps_packed_dev, const void *wv_packed_dev, const float *head_b_dev,
                                int feat_k, int sims);
 
+/* Bounds-checked builds (alphazero_general_amd/build.py --variant debug, -DAZG_DEBUG_BOUNDS; the reference compiles its own checks out,
+ * MCTS.pyx:2-6): every node / child-block / path index of the tree kernels is checked before use; a violation raises the sticky
+ * AZG_E_INTERNAL and is skipped.  *site = the first check that failed (0: none), *checked = 1 if this binary carries the checks. */
+int  azg_debug_bounds_site(azg_engine *e, void *stream, int32_t *site, int32_t *checked);
+
 /* The tile the persistent wide-head launches of `e` run with -- games per workgroup, picked per (device, game, tower width, heads, engine
  * size, depth): MEASURED at the launch's one-time set-up (sims == 0: every tile shape this game / width has is timed once, 8 simulations on
  * a scratch engine of the same size with the caller's network; tile shape changes no result), else a model derived from the device (CU
