@@ -56,18 +56,22 @@ def decode_state(template, cells, player, turns, aux0=0):
 
 
 class Node:
-    """Read-only view of one tree node with the reference's attribute names (MCTS.pyx:49-57)."""
+    """Read-only view of one tree node with the reference's attribute names (MCTS.pyx:49-57): _children, a, q, n, v, p and -- as the
+    reference's Node -- e (uint8 vector of length args._num_players: the node's win state, zeros until the node is expanded, :64-66,223-226)
+    and player (the player to move there, 0 until expanded)."""
 
-    def __init__(self, mcts, idx, a=-1, n=0, q=0.0, p=0.0, v=0.0):
+    def __init__(self, mcts, idx, a=-1, n=0, q=0.0, p=0.0, v=0.0, player=0, e_bits=0):
         self._mcts, self._idx = mcts, idx
         self.a, self.n, self.q, self.p, self.v = a, n, q, p, v
+        self.player = int(player)
+        self.e = np.array([(int(e_bits) >> j) & 1 for j in range(int(getattr(mcts, '_num_players', 0) or 0))], np.uint8)
 
     @property
     def _children(self):
         e = self._mcts._engine
         if e is None:
             return []
-        return [Node(self._mcts, c['idx'], c['a'], c['n'], c['q'], c['p'], c['v'])
+        return [Node(self._mcts, c['idx'], c['a'], c['n'], c['q'], c['p'], c['v'], c['player'], c['e'])
                 for c in e.node_children(0, self._idx)]
 
     def __repr__(self):
@@ -350,6 +354,4 @@ class MCTS:
         if self._engine is None:
             return Node(self, -1)
         i = self._engine.tree_info(0)
-        nd = Node(self, -1, -1, i['n'], i['q'], 0.0, i['v'])
-        nd.player, nd.e = i['player'], np.array([(i['e'] >> j) & 1 for j in range(self._num_players)], np.uint8)
-        return nd
+        return Node(self, -1, -1, i['n'], i['q'], 0.0, i['v'], i['player'], i['e'])

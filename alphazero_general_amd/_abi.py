@@ -80,7 +80,7 @@ SYMBOLS = {
     'azg_slot_export': (C.c_int64, [_vp, _vp, _i, _vp, C.c_int64]),
     'azg_slot_import': (_i, [_vp, _vp, _i, _vp, C.c_int64]),
     'azg_root_children': (_i, [_vp, _vp, _i, _i, _i, _i32p, _i32p, _f32p, _f32p, _f32p]),
-    'azg_node_children': (_i, [_vp, _vp, _i, _i, _i, _i, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p]),
+    'azg_node_children': (_i, [_vp, _vp, _i, _i, _i, _i, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i32p, _i32p]),
     'azg_reset_max_depth': (_i, [_vp, _vp]),
     'azg_tree_info': (_i, [_vp, _vp, _i, _i, _i32p]),
     'azg_last_path': (_i, [_vp, _vp, _i, _i, _i, _i32p]),
@@ -102,6 +102,7 @@ SYMBOLS = {
     'azg_search_arena_f16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
     'azg_obs_to_nhwc8_f16': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'azg_set_shuffle_tape': (_i, [_vp, _vp, _vp, _i]),
+    'azg_set_random_tape': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_search_wide_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_search_wide_exact_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'azg_search_wide_tile_info': (_i, [_vp, _i, _i, _i, _i32p]),

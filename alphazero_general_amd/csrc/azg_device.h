@@ -86,6 +86,11 @@ struct View {
     // expansion that starts at tape counter c is perm_tape[slot][c + i] -- the replay of np.random.shuffle permutations RECORDED from
     // the reference running on its own MT19937 stream (np.random.seed(s)), MCTS.pyx:79
     const int16_t *perm_tape; int32_t perm_len;
+    // ... and, with them, the other two draws of a self-play game (azg_set_random_tape), indexed by the same per-slot tape counter:
+    // u_tape [B][perm_len] double -- the uniform np.random.choice drew for the move made at counter c (SelfPlayAgent.pyx:160);
+    // noise_off [B][perm_len] int32 -- offset into noise_pool (float32) of the np.random.dirichlet vector mixed into the root priors at
+    // counter c (MCTS.pyx:197-206), one value per child in list order
+    const double *u_tape; const int32_t *noise_off; const float *noise_pool; int32_t noise_len;
     unsigned long long *dbg;   // AZG_TREE_TIMING builds only: s_memtime stamps [B][16] of the last simulation of every slot
 };
 

@@ -34,7 +34,8 @@ struct azg_engine {
     View v;
     std::vector<void *> allocs;
     int32_t *d_p2i = nullptr, *d_ok = nullptr;
-    int16_t *d_perm = nullptr;                                 // azg_set_shuffle_tape
+    int16_t *d_perm = nullptr;                                 // azg_set_shuffle_tape / azg_set_random_tape
+    double *d_utape = nullptr; int32_t *d_noff = nullptr; float *d_npool = nullptr;
     bool profile = false;
     std::vector<EvPair> ev[3];
     double ms[3] = {0, 0, 0};
@@ -196,6 +197,9 @@ extern "C" int azg_engine_destroy(azg_engine *e) {
     for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_perm) (void)hipFree(e->d_perm);
+    if (e->d_utape) (void)hipFree(e->d_utape);
+    if (e->d_noff) (void)hipFree(e->d_noff);
+    if (e->d_npool) (void)hipFree(e->d_npool);
     delete e;
     return AZG_OK;
 }
@@ -465,24 +469,50 @@ extern "C" int azg_engine_info(azg_engine *e, int32_t *out8) {
     return AZG_OK;
 }
 
-extern "C" int azg_set_shuffle_tape(azg_engine *e, void *stream, const int16_t *ranks_host, int len) {
-    if (!e || len < 0) return fail(AZG_E_INVALID_ARG, "null engine or negative length");
+extern "C" int azg_set_random_tape(azg_engine *e, void *stream, const int16_t *ranks_host, const double *u_host, const int32_t *noise_off_host,
+                                   const float *noise_pool_host, int noise_len, int len) {
+    (void)stream;
+    if (!e || len < 0 || noise_len < 0) return fail(AZG_E_INVALID_ARG, "null engine or negative length");
+    if ((u_host || noise_off_host) && !ranks_host) return fail(AZG_E_INVALID_ARG, "choice / noise tapes come with a shuffle tape (one counter indexes all three)");
+    if ((noise_off_host != nullptr) != (noise_pool_host != nullptr)) return fail(AZG_E_INVALID_ARG, "noise offsets and noise pool come together");
     const size_t n = (size_t)e->v.B * (size_t)(len > 0 ? len : 0);
     // every rank is an offset into an expansion's block of k <= max_children nodes: refuse anything else here, on the host (the device
     // checks rank < k per expansion as well and raises the sticky AZG_E_INVALID_ARG)
     if (ranks_host) for (size_t i = 0; i < n; i++)
         if (ranks_host[i] < 0 || ranks_host[i] >= e->gi.max_children) return fail(AZG_E_INVALID_ARG, "shuffle tape: a rank is outside [0, max_children)");
-    // the View -- and with it this pointer -- is passed BY VALUE to every launch, also to launches captured in a hipGraph: work of ANY stream
-    // may still read the old tape, so the whole device is drained before it is freed.  A graph captured while a tape was set keeps replaying
-    // with the pointer it captured: re-capture after changing the tape (selfplay's runners capture after the engine is configured)
+    if (u_host) for (size_t i = 0; i < n; i++)
+        if (!(u_host[i] >= 0.0 && u_host[i] < 1.0)) return fail(AZG_E_INVALID_ARG, "choice tape: a uniform is outside [0, 1)");
+    if (noise_off_host) for (size_t i = 0; i < n; i++)
+        if (noise_off_host[i] < -1 || noise_off_host[i] >= noise_len) return fail(AZG_E_INVALID_ARG, "noise tape: an offset is outside the pool");
+    // the View -- and with it these pointers -- is passed BY VALUE to every launch, also to launches captured in a hipGraph: work of ANY
+    // stream may still read the old tapes, so the whole device is drained before they are freed.  A graph captured while a tape was set
+    // keeps replaying with the pointers it captured: re-capture after changing the tape
     HIPCHK(hipDeviceSynchronize());
     if (e->d_perm) { (void)hipFree(e->d_perm); e->d_perm = nullptr; }
-    e->v.perm_tape = nullptr; e->v.perm_len = 0;
+    if (e->d_utape) { (void)hipFree(e->d_utape); e->d_utape = nullptr; }
+    if (e->d_noff) { (void)hipFree(e->d_noff); e->d_noff = nullptr; }
+    if (e->d_npool) { (void)hipFree(e->d_npool); e->d_npool = nullptr; }
+    e->v.perm_tape = nullptr; e->v.perm_len = 0; e->v.u_tape = nullptr; e->v.noise_off = nullptr; e->v.noise_pool = nullptr; e->v.noise_len = 0;
     if (!ranks_host || len == 0) return AZG_OK;
     HIPCHK(hipMalloc((void **)&e->d_perm, n * sizeof(int16_t)));
     HIPCHK(hipMemcpy(e->d_perm, ranks_host, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    if (u_host) {
+        HIPCHK(hipMalloc((void **)&e->d_utape, n * sizeof(double)));
+        HIPCHK(hipMemcpy(e->d_utape, u_host, n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (noise_off_host) {
+        HIPCHK(hipMalloc((void **)&e->d_noff, n * sizeof(int32_t)));
+        HIPCHK(hipMemcpy(e->d_noff, noise_off_host, n * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&e->d_npool, (size_t)(noise_len > 0 ? noise_len : 1) * sizeof(float)));
+        HIPCHK(hipMemcpy(e->d_npool, noise_pool_host, (size_t)noise_len * sizeof(float), hipMemcpyHostToDevice));
+    }
     e->v.perm_tape = e->d_perm; e->v.perm_len = len;
+    e->v.u_tape = e->d_utape; e->v.noise_off = e->d_noff; e->v.noise_pool = e->d_npool; e->v.noise_len = noise_len;
     return AZG_OK;
+}
+
+extern "C" int azg_set_shuffle_tape(azg_engine *e, void *stream, const int16_t *ranks_host, int len) {
+    return azg_set_random_tape(e, stream, ranks_host, nullptr, nullptr, nullptr, 0, len);
 }
 
 // bounds-checked builds (-DAZG_DEBUG_BOUNDS): the first check that failed (0: none; site numbers: csrc/azg_kernels.h AZG_BOUNDS_OK).
@@ -637,7 +667,8 @@ extern "C" int azg_root_children(azg_engine *e, void *stream, int slot, int tree
     return k;
 }
 
-extern "C" int azg_node_children(azg_engine *e, void *stream, int slot, int tree, int node, int max_k, int32_t *idx, int32_t *a, int32_t *n, float *q, float *p, float *vv) {
+extern "C" int azg_node_children(azg_engine *e, void *stream, int slot, int tree, int node, int max_k, int32_t *idx, int32_t *a, int32_t *n, float *q, float *p, float *vv,
+                                 int32_t *player, int32_t *e_bits) {
     int r = check_range(e, slot, 1); if (r) return r;
     if (tree < 0 || tree >= e->v.T) return fail(AZG_E_INVALID_ARG, "tree index out of range");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
@@ -648,7 +679,11 @@ extern "C" int azg_node_children(azg_engine *e, void *stream, int slot, int tree
     if (k == 0) return 0;
     std::vector<Node> ch((size_t)k);
     HIPCHK(hipMemcpy(ch.data(), base + nd.first_child, sizeof(Node) * k, hipMemcpyDeviceToHost));
-    for (int i = 0; i < k; i++) { idx[i] = nd.first_child + i; a[i] = ch[i].a; n[i] = ch[i].n; q[i] = ch[i].q; p[i] = ch[i].p; vv[i] = ch[i].v; }
+    for (int i = 0; i < k; i++) {
+        idx[i] = nd.first_child + i; a[i] = ch[i].a; n[i] = ch[i].n; q[i] = ch[i].q; p[i] = ch[i].p; vv[i] = ch[i].v;
+        if (player) player[i] = ch[i].player;
+        if (e_bits) e_bits[i] = ch[i].e;
+    }
     return k;
 }
 

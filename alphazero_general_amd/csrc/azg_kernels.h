@@ -430,21 +430,31 @@ AZG_DEV void leaf_policy(const View &ev, int slot, Node *nodes, int fc, int k, b
     }
     if (at_root && ev.add_noise) {                                           // :197-206 Dirichlet noise (tape)
         const uint64_t ctr = ev.tape_ctr[slot];
-        const uint64_t key = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr);
-        const double alpha = 10.83 / (double)k;
-        double g[NC]; double acc = 0.0;
+        float nzv[NC];
+        if (ev.noise_off) {                                                  // a RECORDED np.random.dirichlet vector (azg_set_random_tape), float32 as :198-200 casts it
+            const int off = ctr < (uint64_t)ev.perm_len ? ev.noise_off[(size_t)slot * ev.perm_len + ctr] : -1;
+            if (off < 0 || off + k > ev.noise_len) { if (lane == 0) raise_error(ev, AZG_E_INVALID_ARG); return; }
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            int i = c * 64 + lane;
-            g[c] = 0.0;
-            if (i < k) { SubStream ss = { key, (uint64_t)i, 0 }; g[c] = ss_gamma(ss, alpha); }
+            for (int c = 0; c < NC; c++) { const int i = c * 64 + lane; nzv[c] = i < k ? ev.noise_pool[off + i] : 0.f; }
+        } else {
+            const uint64_t key = tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr);
+            const double alpha = 10.83 / (double)k;
+            double g[NC]; double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                int i = c * 64 + lane;
+                g[c] = 0.0;
+                if (i < k) { SubStream ss = { key, (uint64_t)i, 0 }; g[c] = ss_gamma(ss, alpha); }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) { int lim = min(64, k - c * 64); for (int j = 0; j < lim; j++) acc += rl(g[c], j); }
+            const double inv = 1.0 / acc;
+#pragma unroll
+            for (int c = 0; c < NC; c++) nzv[c] = (float)(g[c] * inv);
         }
 #pragma unroll
-        for (int c = 0; c < NC; c++) { int lim = min(64, k - c * 64); for (int j = 0; j < lim; j++) acc += rl(g[c], j); }
-        const double inv = 1.0 / acc;
-#pragma unroll
         for (int c = 0; c < NC; c++) {
-            float nz = (float)(g[c] * inv);
+            const float nz = nzv[c];
             cp[c] = (float)(((double)cp[c] * (1.0 - (double)ev.noise_frac)) + (double)(ev.noise_frac * nz));
         }
         if (lane == 0) ev.tape_ctr[slot] = ctr + 1;
@@ -1015,7 +1025,11 @@ __global__ __launch_bounds__(64) void k_play(View ev, int record_history) {
     }
     // np.random.choice(A, p=policy) via the tape (:160): cdf in double, first index whose cdf/total > u
     uint64_t ctr = ev.tape_ctr[slot];
-    const double u = u53(tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr));
+    double u;
+    if (ev.u_tape) {                                                         // the uniform np.random.choice DREW, recorded (azg_set_random_tape)
+        if (ctr >= (uint64_t)ev.perm_len) { if (lane == 0) { raise_error(ev, AZG_E_INVALID_ARG); ev.fin_flag[slot] = 0; } return; }
+        u = ev.u_tape[(size_t)slot * ev.perm_len + ctr];
+    } else u = u53(tape_u64(ev.seed, ev.slot_base + (uint64_t)slot, ctr));
     double total = 0.0;
     for (int a = 0; a < A; a++) { float x = pr[a]; if (x != 0.f) total += (double)x; }
     double acc = 0.0; int action = 0; bool le = true;                        // cdf_i <= u  (searchsorted side='right')

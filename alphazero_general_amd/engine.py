@@ -126,6 +126,20 @@ class DeviceEngine:
         assert r.ndim == 2 and r.shape[0] == self.B
         _abi.check(self.L.azg_set_shuffle_tape(self.h, _stream(), r.ctypes.data_as(C.c_void_p), int(r.shape[1])))
 
+    def set_random_tape(self, ranks, u=None, noise_off=None, noise_pool=None):
+        """replay ALL recorded draws of a self-play game (azg_set_random_tape): ranks int16 [B, L] as set_shuffle_tape; u float64 [B, L] -- the
+        uniform np.random.choice drew for the move made at tape counter c; noise_off int32 [B, L] + noise_pool float32 [n] -- the
+        np.random.dirichlet vector mixed into the root priors at counter c starts at noise_pool[noise_off[s, c]] (-1: none)."""
+        r = np.ascontiguousarray(ranks, np.int16)
+        assert r.ndim == 2 and r.shape[0] == self.B
+        uu = None if u is None else np.ascontiguousarray(u, np.float64)
+        no = None if noise_off is None else np.ascontiguousarray(noise_off, np.int32)
+        npool = None if noise_pool is None else np.ascontiguousarray(noise_pool, np.float32)
+        assert uu is None or uu.shape == r.shape
+        assert no is None or (no.shape == r.shape and npool is not None)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        _abi.check(self.L.azg_set_random_tape(self.h, _stream(), vp(r), vp(uu), vp(no), vp(npool), 0 if npool is None else int(npool.size), int(r.shape[1])))
+
     def set_tape_counters(self, ctr, first=0):
         arr = (C.c_uint64 * len(ctr))(*[int(c) for c in ctr])
         _abi.check(self.L.azg_set_tape_counters(self.h, _stream(), first, len(ctr), arr))
@@ -295,9 +309,9 @@ class DeviceEngine:
     def node_children(self, slot, node=-1, tree=0):
         K = max(self.gi.max_children, 1)
         idx = (C.c_int32 * K)(); a = (C.c_int32 * K)(); n = (C.c_int32 * K)()
-        q = (C.c_float * K)(); p = (C.c_float * K)(); v = (C.c_float * K)()
-        k = _abi.check(self.L.azg_node_children(self.h, _stream(), slot, tree, int(node), K, idx, a, n, q, p, v))
-        return [dict(idx=idx[i], a=a[i], n=n[i], q=q[i], p=p[i], v=v[i]) for i in range(k)]
+        q = (C.c_float * K)(); p = (C.c_float * K)(); v = (C.c_float * K)(); pl = (C.c_int32 * K)(); eb = (C.c_int32 * K)()
+        k = _abi.check(self.L.azg_node_children(self.h, _stream(), slot, tree, int(node), K, idx, a, n, q, p, v, pl, eb))
+        return [dict(idx=idx[i], a=a[i], n=n[i], q=q[i], p=p[i], v=v[i], player=pl[i], e=eb[i]) for i in range(k)]
 
     def reset_max_depth(self):
         _abi.check(self.L.azg_reset_max_depth(self.h, _stream()))

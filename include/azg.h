@@ -213,8 +213,11 @@ int  azg_slot_import(azg_engine *e, void *stream, int slot, const void *host_buf
 /* children of a slot's root in list order (Node._children): a, n, q, p, v.  blocking; returns k or <0. */
 int  azg_root_children(azg_engine *e, void *stream, int slot, int tree, int max_k, int32_t *a, int32_t *n, float *q, float *p, float *v);
 /* children of an arbitrary node (node < 0: the root) incl. their node indices, for tree walks
- * (utils.plot_mcts_tree, alphazero/utils.py:57-83). blocking; returns k or <0. */
-int  azg_node_children(azg_engine *e, void *stream, int slot, int tree, int node, int max_k, int32_t *idx, int32_t *a, int32_t *n, float *q, float *p, float *v);
+ * (utils.plot_mcts_tree, alphazero/utils.py:57-83). blocking; returns k or <0.  player / e (optional, may be NULL; ABI v6): Node.player and
+ * Node.e (MCTS.pyx:52,57) -- the player to move at the child and its win state as a bit per entry of the reference's uint8 vector, both
+ * meaningful once the child has been expanded (the reference fills them in add_children's caller, :223-226). */
+int  azg_node_children(azg_engine *e, void *stream, int slot, int tree, int node, int max_k, int32_t *idx, int32_t *a, int32_t *n, float *q, float *p, float *v,
+                       int32_t *player, int32_t *e_bits);
 /* MCTS.search resets max_depth at the start of every search (MCTS.pyx:168,179) */
 int  azg_reset_max_depth(azg_engine *e, void *stream);
 /* root header / search statistics of a slot's tree: n, q, v, player, e, depth, max_depth. blocking. */
@@ -405,8 +408,22 @@ int  azg_obs_to_nhwc8_f16(void *stream, const float *obs_dev, int boards, int ch
  * by the number of children per expansion, so a slot's recorded permutations are simply concatenated in expansion order).  The
  * fixtures under tests/golden/c4_mt19937.npz were recorded from the reference running under np.random.seed(s) with np.random.shuffle
  * observed, not replaced.  ranks_host == NULL or len == 0: back to the counter-based tape.  An expansion past the end of the tape
- * raises the sticky AZG_E_INVALID_ARG.  Root noise (np.random.dirichlet) is not replayed: use with add_root_noise = 0. */
+ * raises the sticky AZG_E_INVALID_ARG.  Ranks outside [0, max_children) are refused here; a rank >= the expansion's k raises the sticky
+ * AZG_E_INVALID_ARG on the device.  The device is drained before an old tape is freed; a hipGraph captured while a tape was set replays
+ * with the tape it captured (re-capture after changing it).  Root noise is not replayed by this call: azg_set_random_tape. */
 int  azg_set_shuffle_tape(azg_engine *e, void *stream, const int16_t *ranks_host, int len);
+
+/* ALL THREE draws of a self-play game replayed (round 6: a whole SelfPlayAgent game under np.random.seed(s), move for move): besides the
+ * shuffles, u_host double [num_slots][len] -- the uniform np.random.choice(A, p = policy) drew for the move made at tape counter c
+ * (SelfPlayAgent.pyx:160; the legacy choice draws exactly one random_sample and searches the cdf: what azg_advance does with it) -- and the
+ * Dirichlet noise of MCTS._add_root_noise (MCTS.pyx:197-206): noise_off_host int32 [num_slots][len] = offset into noise_pool_host (float32,
+ * as :198-200 casts it; noise_len entries) of the vector mixed into the root's priors at counter c, one value per child in list order (-1:
+ * no noise event at that counter).  One counter indexes all three tapes: a shuffle of k children advances it by k, a noise event and a move
+ * by 1 each -- the order the reference makes the calls in for one game slot.  NULL u_host / noise_off_host: that draw stays on the
+ * counter-based tape.  tests/golden/c4_mt19937_agent.npz was recorded from the reference's SelfPlayAgent running on numpy's own stream
+ * with the three functions observed, not replaced. */
+int  azg_set_random_tape(azg_engine *e, void *stream, const int16_t *ranks_host, const double *u_host, const int32_t *noise_off_host,
+                         const float *noise_pool_host, int noise_len, int len);
 
 #ifdef __cplusplus
 }

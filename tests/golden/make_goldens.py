@@ -266,6 +266,86 @@ def gen_c4_mt19937(n_roots=64, sims=100, seed=20250929, eval_seed=77):
     print('c4_mt19937: %d roots x %d sims under np.random.seed(%d), %d recorded shuffles' % (n_roots, sims, seed, sum(len(x) for x in lens)))
 
 
+def gen_c4_mt19937_agent(B=4, sims=20, games=6, seed=20260929, eval_seed=91):
+    """The MT19937 tier for a whole SelfPlayAgent: the reference's agent -- connect4, B concurrent games, root noise and
+    root temperature ON -- plays `games` games under np.random.seed(seed) with numpy's global stream untouched; np.random.shuffle /
+    dirichlet / choice / random_sample are OBSERVED (rh.ObservedRng), per game slot.  The fixture holds the global call order (kinds, slots,
+    lengths: tests/test_oracle_golden.py re-derives every recorded draw from np.random.RandomState(seed) alone), the per-slot tapes in the
+    engine's counter order (shuffle of k: k positions, noise event: 1, move: 1 -- azg_set_random_tape) and what the agent did: visit counts and
+    sampled action per round and slot, games_played, the samples and results it queued."""
+    import torch
+    from alphazero.envs.connect4.connect4 import Game
+    gi = ol.game_info(0)
+    A, NV = gi.action_size, gi.num_players + 1
+    args = rh.ref_args(Game, numMCTSSims=sims, gamesPerIteration=games, add_root_noise=True, add_root_temp=True)
+    obs = rh.ObservedRng()
+    np.random.seed(seed)
+    obs.install()
+    rec = dict(actions=[], counts=[], games_played=[])
+    try:
+        ag = rh.make_ref_agent(Game, 0, B, args, obs)
+        step = 0
+        for rnd in range(400):
+            if ag.games_played.value >= args.gamesPerIteration:
+                break
+            obs.stream = -1
+            ag.fast = np.random.random_sample() < args.probFastSim           # SelfPlayAgent.run :84 (one coin per round)
+            for s_ in range(sims):
+                ag.generateBatch()
+                for i in range(B):
+                    p, v = ol.fake_eval(eval_seed, i, step, A, NV)
+                    ag.policy_tensor[i] = torch.from_numpy(p); ag.value_tensor[i] = torch.from_numpy(v)
+                ag.processBatch()
+                step += 1
+            rec['counts'].append([np.asarray(ag.mcts[i].counts(ag.games[i])).astype(np.int32) for i in range(B)])
+            n0 = len(obs.calls)
+            ag.playMoves()
+            acts = [-1] * B
+            for c in obs.calls[n0:]:
+                if c[0] == 'choice':
+                    acts[c[1]] = c[3]
+            rec['actions'].append(acts)
+            rec['games_played'].append(ag.games_played.value)
+    finally:
+        obs.uninstall()
+    samples, results = ag.output_queue.items, ag.result_queue.items
+    # global call order, for the RandomState check: kind (0 shuffle, 1 dirichlet, 2 choice, 3 coin), slot, length
+    kinds = {'shuffle': 0, 'dirichlet': 1, 'choice': 2, 'coin': 3}
+    order = np.array([[kinds[c[0]], c[1], len(c[2]) if c[0] in ('shuffle', 'dirichlet') else 1] for c in obs.calls], np.int32)
+    flat_ranks = np.array([x for c in obs.calls if c[0] == 'shuffle' for x in c[2]], np.int16)
+    flat_noise = np.array([x for c in obs.calls if c[0] == 'dirichlet' for x in c[2]], np.float64)
+    flat_u = np.array([c[2] for c in obs.calls if c[0] in ('choice', 'coin')], np.float64)
+    # per-slot tapes in the engine's counter order
+    per = [[] for _ in range(B)]
+    for c in obs.calls:
+        if c[1] >= 0:
+            per[c[1]].append(c)
+    L = max(sum(len(c[2]) if c[0] == 'shuffle' else 1 for c in calls) for calls in per)
+    ranks = np.zeros((B, L), np.int16); u = np.zeros((B, L), np.float64); noff = np.full((B, L), -1, np.int32); pool = []
+    for sl, calls in enumerate(per):
+        pos = 0
+        for c in calls:
+            if c[0] == 'shuffle':
+                ranks[sl, pos:pos + len(c[2])] = c[2]; pos += len(c[2])
+            elif c[0] == 'dirichlet':
+                noff[sl, pos] = len(pool); pool.extend(np.asarray(c[2], np.float32).tolist()); pos += 1     # (:198-200 casts to float32)
+            else:
+                u[sl, pos] = c[2]; pos += 1
+    out = dict(seed=np.uint64(seed), eval_seed=np.uint64(eval_seed), B=np.int32(B), sims=np.int32(sims), games=np.int32(games), cfg=np.array([1.25, 0.2, 0.1, 1.1], np.float64),
+               call_order=order, flat_ranks=flat_ranks, flat_noise=flat_noise, flat_u=flat_u,
+               tape_ranks=ranks, tape_u=u, tape_noise_off=noff, tape_noise_pool=np.array(pool, np.float32),
+               actions=np.array(rec['actions'], np.int16), counts=np.array(rec['counts'], np.int32), games_played=np.array(rec['games_played'], np.int32),
+               s_obs=np.array([s_[0] for s_ in samples], np.float32).reshape(len(samples), gi.obs_c, gi.obs_h, gi.obs_w),
+               s_pi=np.array([s_[1] for s_ in samples], np.float32).reshape(len(samples), A),
+               s_z=np.array([s_[2] for s_ in samples], np.float32).reshape(len(samples), NV),
+               r_ws=np.array([np.asarray(r[1], np.uint8) for r in results]).reshape(len(results), NV),
+               r_turns=np.array([r[0].turns for r in results], np.int32))
+    np.savez_compressed(os.path.join(OUT, 'c4_mt19937_agent.npz'), **out)
+    nk = {k: int((order[:, 0] == v).sum()) for k, v in kinds.items()}
+    print('c4_mt19937_agent: %d slots x %d sims, %d rounds, %d games under np.random.seed(%d): %s; %d samples, %d results'
+          % (B, sims, len(rec['actions']), rec['games_played'][-1], seed, nk, len(samples), len(results)))
+
+
 # ------------------------------------------------------------------------------------------------ agent
 AGENT_CONFIGS = [
     # name, B, sims, games, kwargs
@@ -517,6 +597,8 @@ def main():
         gen_arena(C4, ol.GAME_CONNECT4, 'c4')
     if 'c4_mt19937' in which:
         gen_c4_mt19937()
+    if 'c4_mt19937_agent' in which:
+        gen_c4_mt19937_agent()
     if 'c4_net' in which:
         gen_net()
     if 'c4_ckpt' in which:

@@ -91,6 +91,59 @@ class Tape:
         return u
 
 
+class ObservedRng:
+    """The MT19937 tier: numpy's global legacy stream UNTOUCHED -- np.random.{shuffle, dirichlet, choice, random_sample} are observed (the real
+    function is called and draws from the real stream), not replaced; what each call produced is recorded with the game slot it was made
+    for (`stream`, set by TapedAgent._mcts) in global call order: ('shuffle', slot, ranks), ('dirichlet', slot, float64 vector),
+    ('choice', slot, u, index), ('coin', -1, u).  For np.random.choice the uniform it drew is recovered from a clone of the stream's state
+    (the legacy choice draws exactly ONE random_sample and searches the cdf), and the clone is checked to end where the real stream does."""
+
+    def __init__(self):
+        self.calls = []
+        self.stream = -1
+
+    def install(self):
+        self._saved = (np.random.shuffle, np.random.choice, np.random.dirichlet, np.random.random_sample)
+        np.random.shuffle, np.random.choice = self.shuffle, self.choice
+        np.random.dirichlet, np.random.random_sample = self.dirichlet, self.random_sample
+
+    def uninstall(self):
+        np.random.shuffle, np.random.choice, np.random.dirichlet, np.random.random_sample = self._saved
+
+    def shuffle(self, lst):
+        before = list(lst)
+        self._saved[0](lst)
+        pos = [-1] * len(before)
+        for new_i, obj in enumerate(lst):
+            for old_i, b in enumerate(before):
+                if b is obj:
+                    pos[old_i] = new_i
+        assert sorted(pos) == list(range(len(before)))
+        self.calls.append(('shuffle', self.stream, pos))
+
+    def dirichlet(self, alpha):
+        out = self._saved[2](alpha)
+        self.calls.append(('dirichlet', self.stream, np.array(out, np.float64)))
+        return out
+
+    def choice(self, a, p=None):
+        st = np.random.get_state()
+        idx = self._saved[1](a, p=p)
+        rs = np.random.RandomState(); rs.set_state(st)
+        u = rs.random_sample()
+        after, mine = np.random.get_state(), rs.get_state()
+        assert after[2] == mine[2] and (after[1] == mine[1]).all(), 'np.random.choice drew something else than one random_sample'
+        cdf = np.asarray(p, np.float64).cumsum(); cdf /= cdf[-1]
+        assert int(cdf.searchsorted(u, side='right')) == int(idx)
+        self.calls.append(('choice', self.stream, float(u), int(idx)))
+        return idx
+
+    def random_sample(self):
+        u = self._saved[3]()
+        self.calls.append(('coin', -1, float(u)))
+        return u
+
+
 class _Ev:
     def __init__(self):
         self._s = False

@@ -231,3 +231,36 @@ def test_max_depth_is_writable_like_the_reference():
     assert m.max_depth == 0
     run(3)
     assert 0 < m.max_depth <= deep and m.max_depth == m._engine.tree_info(0)['max_depth']
+
+
+def test_node_view_has_e_and_player_like_the_reference():
+    """Node.e / Node.player (MCTS.pyx:52,57; SURVEY.md 8b lists `_root` with `_children, a, q, n, v, p, e, player`): zeros on a node that has
+    not been expanded (Node.__init__ :59-67), the win state of the position and the player to move there once it has (find_leaf :223-226)."""
+    import numpy as np
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.MCTS import MCTS
+    args = _args(_num_players=3, numMCTSSims=60)
+    m = MCTS(args)
+    g = Game()
+    for a in (3, 3, 3, 2, 2):                                        # a position two plies from a win for player 0
+        g.play_action(a)
+    m.raw_search(g, 80, False, False)
+    root = m._root
+    assert root.player == g.player and root.e.dtype == np.uint8 and root.e.shape == (3,) and not root.e.any()
+    seen_terminal = False
+
+    def walk(node, state, depth):
+        nonlocal seen_terminal
+        for c in node._children:
+            assert c.e.dtype == np.uint8 and c.e.shape == (3,)
+            if c.n == 0:
+                assert c.player == 0 and not c.e.any()              # never reached: as constructed
+                continue
+            s = state.clone(); s.play_action(c.a)
+            assert c.player == s.player, (depth, c.a)
+            assert (c.e == np.asarray(s.win_state(), np.uint8)).all(), (depth, c.a)
+            seen_terminal |= bool(c.e.any())
+            if depth < 3 and not c.e.any():
+                walk(c, s, depth + 1)
+    walk(root, g, 0)
+    assert seen_terminal

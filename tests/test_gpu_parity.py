@@ -161,6 +161,40 @@ def test_c4_search_under_numpys_mt19937_seed(torch_mod):
     eng.close()
 
 
+@pytest.mark.parametrize('launch', ['phase', 'fused'])
+def test_c4_selfplay_agent_under_numpys_mt19937_seed(torch_mod, launch):
+    """A whole SelfPlayAgent under np.random.seed(s), move for move: tests/golden/c4_mt19937_agent.npz is the REFERENCE's
+    agent -- 4 concurrent connect4 games, root noise and root temperature on, 6 games -- on numpy's own MT19937 stream with shuffle /
+    dirichlet / choice observed per game slot (tests/test_oracle_golden.py re-derives every draw from the seed alone).  The engine replays
+    all three (azg_set_random_tape) and must reproduce: visit counts and the sampled action of every slot in every round, the games_played
+    trajectory, the (state, pi, z) samples incl. symmetries and the results in queue order, and end with its tape counters at the end of
+    each slot's recorded draws.  (Temperatures other than 1 go through powf: counts and actions are compared exactly, as in the agent
+    goldens.)"""
+    torch = torch_mod
+    d = dict(np.load(os.path.join(G, 'c4_mt19937_agent.npz')))
+    B, sims, games, eseed = int(d['B']), int(d['sims']), int(d['games']), int(d['eval_seed'])
+    cpuct, fpu, nfrac, rtemp = [float(x) for x in d['cfg']]
+    eng = engine(B=B, cpuct=cpuct, fpu_reduction=fpu, root_noise_frac=nfrac, root_policy_temp=rtemp, add_root_noise=True, add_root_temp=True,
+                 seed=987654321, games_per_iteration=games, example_capacity=4096, sims_hint=sims)
+    eng.set_random_tape(d['tape_ranks'], d['tape_u'], d['tape_noise_off'], d['tape_noise_pool'])
+    rec = run_engine_agent(torch, eng, eseed, 0, sims, games, launch=launch)
+    n = len(d['actions'])
+    assert len(rec['actions']) == n and (np.array(rec['games_played']) == d['games_played']).all()
+    for r in range(n):
+        assert (np.asarray(rec['counts'][r]) == d['counts'][r]).all(), (launch, r)
+        assert (np.asarray(rec['actions'][r]) == d['actions'][r]).all(), (launch, r)
+    eo, ep, ez = [t.cpu().numpy() for t in eng.examples()]
+    assert eo.shape == d['s_obs'].shape and (eo == d['s_obs']).all() and (ez == d['s_z']).all()
+    assert np.allclose(ep, d['s_pi'], rtol=0, atol=0) and (ep == d['s_pi']).all()         # pi at T = 1 is counts / sum: exact
+    ws, turns, _ = eng.results()
+    assert (ws == d['r_ws']).all() and (turns == d['r_turns']).all()
+    used = [int((d['call_order'][(d['call_order'][:, 1] == sl) & (d['call_order'][:, 0] == 0), 2]).sum()
+                + ((d['call_order'][:, 1] == sl) & (d['call_order'][:, 0] > 0)).sum()) for sl in range(B)]
+    assert (eng.tape_counters() == np.array(used, np.uint64)).all()
+    eng.set_shuffle_tape(None)
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ agent goldens
 AGENT_CFGS = {
     'plain': dict(),

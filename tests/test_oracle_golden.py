@@ -147,6 +147,50 @@ def test_c4_mt19937_fixture_is_numpys_own_stream():
     assert total > 3000
 
 
+def test_c4_mt19937_agent_fixture_is_numpys_own_stream():
+    """tests/golden/c4_mt19937_agent.npz (round 6): a whole reference SelfPlayAgent -- 4 concurrent connect4 games, root noise + root
+    temperature on, six games -- under np.random.seed(seed) on numpy's untouched stream, with np.random.shuffle / dirichlet / choice /
+    random_sample observed.  Replaying the recorded CALL ORDER (kind, length) on np.random.RandomState(seed) must reproduce every
+    recorded rank, noise value and uniform: the fixture is pinned to the literal seed without the reference.  Then the per-slot tapes
+    (the engine's counter order: azg_set_random_tape) must be those same draws regrouped by game slot."""
+    d = dict(np.load(os.path.join(G, 'c4_mt19937_agent.npz')))
+    rs = np.random.RandomState(int(d['seed']))
+    ri = ni = ui = 0
+    B = int(d['B'])
+    per = [[] for _ in range(B)]
+    for kind, slot, n in d['call_order'].tolist():
+        if kind == 0:                                        # np.random.shuffle(children): MCTS.pyx:79
+            x = list(range(n)); rs.shuffle(x)
+            pos = np.empty(n, np.int16); pos[np.array(x)] = np.arange(n)
+            assert (pos == d['flat_ranks'][ri:ri + n]).all(), ri
+            per[slot].append(('s', pos)); ri += n
+        elif kind == 1:                                      # np.random.dirichlet([10.83 / k] * k): MCTS.pyx:197-200
+            v = rs.dirichlet([10.83 / n] * n)
+            assert (v == d['flat_noise'][ni:ni + n]).all(), ni
+            per[slot].append(('d', v.astype(np.float32))); ni += n
+        else:                                                # np.random.choice draws ONE random_sample (SelfPlayAgent.pyx:160); the round's fast coin (:84)
+            u = rs.random_sample()
+            assert u == d['flat_u'][ui], ui
+            if kind == 2:
+                per[slot].append(('c', u))
+            ui += 1
+    assert ri == len(d['flat_ranks']) and ni == len(d['flat_noise']) and ui == len(d['flat_u']) and ri > 5000 and ni > 50 and ui > 90
+    for sl in range(B):
+        pos = 0
+        for kind, val in per[sl]:
+            if kind == 's':
+                assert (d['tape_ranks'][sl, pos:pos + len(val)] == val).all(); pos += len(val)
+            elif kind == 'd':
+                off = int(d['tape_noise_off'][sl, pos])
+                assert off >= 0 and (d['tape_noise_pool'][off:off + len(val)] == val).all(); pos += 1
+            else:
+                assert d['tape_u'][sl, pos] == val; pos += 1
+        assert (d['tape_noise_off'][sl, pos:] == -1).all()
+    # what the agent did with them: one action per slot and round, every counted game in the result queue
+    assert d['actions'].shape == d['counts'].shape[:2] and (d['actions'] >= 0).all() and int(d['games_played'][-1]) == int(d['games']) == len(d['r_turns'])
+    assert d['s_obs'].shape[0] == 2 * int(d['r_turns'].sum())                  # two symmetries per recorded position (connect4.pyx:96-99)
+
+
 TREE_CFGS = ['default', 'c4train', 'noise', 'noise_temp']
 
 
