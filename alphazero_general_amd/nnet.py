@@ -536,6 +536,9 @@ def _unpin(key):
         if ent[3] >= 8:                                        # (a registration that served many calls was worth it: an address the allocator
             _PIN_COUNT.pop(key, None)                          #  hands out again -- Coach's tensors of the next iteration -- starts afresh)
         try:
+            # (the tensor object can be collected right behind a non_blocking H2D copy of its memory -- a temporary view, a tensor from an mp
+            #  queue as in Arena.pyx:275: the DMA must have finished before the pages are unlocked)
+            torch.cuda.synchronize()
             torch.cuda.cudart().cudaHostUnregister(key)
         except Exception:                                      # noqa: BLE001 (interpreter shutdown)
             pass
@@ -558,6 +561,8 @@ def pin_shared(t):
     if ent is not None and ent[0] >= n:
         ent[3] += 1
         return ent[1] != 'no'
+    if ent is not None:                                        # a larger storage at the same address: drop the old (shorter) registration first
+        _unpin(key)
     ok = 'no'
     try:
         if t.is_pinned():

@@ -242,9 +242,9 @@ def test_node_view_has_e_and_player_like_the_reference():
     args = _args(_num_players=3, numMCTSSims=60)
     m = MCTS(args)
     g = Game()
-    for a in (3, 3, 3, 2, 2):                                        # a position two plies from a win for player 0
+    for a in (3, 0, 3, 0, 3):                                        # player 0 holds three in column 3: wins two plies on unless blocked
         g.play_action(a)
-    m.raw_search(g, 80, False, False)
+    m.raw_search(g, 300, False, False)
     root = m._root
     assert root.player == g.player and root.e.dtype == np.uint8 and root.e.shape == (3,) and not root.e.any()
     seen_terminal = False
