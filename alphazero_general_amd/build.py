@@ -29,6 +29,7 @@ VARIANTS = {                                                         # name -> (
     'tuning': ('libazg_tuning.so', ['-DAZG_TUNING']),
     'timing-tree': ('libazg_timing.so', ['-DAZG_TREE_TIMING']),
     'timing-tower': ('libazg_timing.so', ['-DAZG_TOWER_TIMING']),
+    'headline1': ('libazg_headline1.so', ['-DAZG_HEADLINE_ONE_WG']),   # experiment: the connect4 search kernel with one workgroup per CU (512 registers, no spills)
 }
 
 

@@ -566,7 +566,16 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row,
 template <int C, int PSPLIT, int KSPLIT, int BOARDS> constexpr bool wide_solo() { return (C / 32) * PSPLIT * KSPLIT < 2 * BOARDS; }
 template <class SEARCH, class = void> struct WideGameOf { using type = C4; };
 template <class SEARCH> struct WideGameOf<SEARCH, std::void_t<typename SEARCH::Game>> { using type = typename SEARCH::Game; };
-template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else { if constexpr (SEARCH::WIDE) return SEARCH::MIN_BLOCKS; else return 2; } }
+// (-DAZG_HEADLINE_ONE_WG, build.py --variant headline1: the experiment that settles "spill into the unused AGPRs" for the headline kernel --
+//  on gfx950 a wavefront's VGPRs and AGPRs come out of ONE 512-entry file per SIMD lane, so at two wavefronts per SIMD a wave owns 256
+//  registers IN TOTAL: "AGPR 0" in the resource table means all 256 are architectural, not that 256 more lie idle.  More registers per wave
+//  = one workgroup per CU; profiles/r06_headline_one_wg_ab.txt has what that costs.)
+#ifdef AZG_HEADLINE_ONE_WG
+#define AZG_SEARCH_MIN_BLOCKS 1
+#else
+#define AZG_SEARCH_MIN_BLOCKS 2
+#endif
+template <class SEARCH> constexpr int tower_min_blocks() { if constexpr (__is_same(SEARCH, NoSearch)) return 2; else { if constexpr (SEARCH::WIDE) return SEARCH::MIN_BLOCKS; else return AZG_SEARCH_MIN_BLOCKS; } }
 
 // KSPLIT = 2 (64-channel towers of one board): the two 32-channel k-steps of every tap go to two wave groups -- wave = (cout group
 // cg, pixel group ph, k group kg), every wave runs 9 k-steps over ALL its pixel group's subtiles and finishes half of them: the

