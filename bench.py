@@ -38,10 +38,10 @@ from alphazero_general_amd.iteration import ArenaIteration, SelfPlayIteration  #
 from alphazero_general_amd.utils import dotdict, default_temp_scaling  # noqa: E402
 
 HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS = 8000.0, 2500.0                                   # MI355X_MICROARCH.md
-PMC_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc.json' % r) for r in (5, 4, 3, 2)) if os.path.exists(p)),
-                os.path.join(ROOT, 'profiles', 'r05_pmc.json'))
-PHASE_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_phase_budget.json' % r) for r in (5, 4)) if os.path.exists(p)),
-                  os.path.join(ROOT, 'profiles', 'r05_phase_budget.json'))
+PMC_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_pmc.json' % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, 'profiles', 'r06_pmc.json'))
+PHASE_FILE = next((p for p in (os.path.join(ROOT, 'profiles', 'r%02d_phase_budget.json' % r) for r in (6, 5, 4)) if os.path.exists(p)),
+                  os.path.join(ROOT, 'profiles', 'r06_phase_budget.json'))
 CALIBRATION_FILE = os.path.join(ROOT, 'profiles', 'cpu_oracle_vs_reference.json')
 CLOCK_GHZ_NOMINAL = 2.4                                                               # MI355X_MICROARCH.md (peak engine clock)
 

@@ -3,9 +3,9 @@
     sh tools/build_timing.sh tower && python tools/phase_budget.py --git <short hash>
 
 Runs tools/wide_search_phases.py under the measurement build (libazg_timing.so: s_memtime stamps around the tree phase, the tower and
-the head convolutions of every simulation) and writes gpurun_out/r05_phase_budget.json -- cycles per simulation and phase, mean over
+the head convolutions of every simulation) and writes gpurun_out/r06_phase_budget.json -- cycles per simulation and phase, mean over
 the workgroups of the last launch -- stamped with the hash of the kernel sources (bench.csrc_sha), which bench.py's `phase_budget`
-block reads from profiles/r05_phase_budget.json."""
+block reads from profiles/r06_phase_budget.json."""
 import argparse
 import json
 import os
@@ -34,14 +34,16 @@ def main():
         hs = re.findall(r'helper wavefront .*?: header (\d+) masks (\d+) logits (\d+) softmax (\d+) priors (\d+)', err)
         assert ms, err[-2000:]
         n, tree, tower, hc, heads = [int(x) for x in ms[-1]]
-        gpw = (1 if B <= 512 else 2 if B <= 1024 else 3 if B <= 1536 else 4) if game == 'brandubh' else (1 if B <= 512 else 2)   # csrc/azg_engine.hip: search_wide
+        tl = re.findall(r'TILE (\d+)', r.stdout.decode(errors='replace'))
+        assert tl, r.stdout.decode(errors='replace')[-500:]
+        gpw = int(tl[-1])                                            # the tile the launch picked for this engine size (measured at set-up)
         rec = {'games': B, 'games_per_workgroup': gpw, 'search_heads': 'exact', 'workgroups_sampled': n, 'tree': tree, 'tower': tower, 'headconv': hc, 'heads': heads}
         if hs:
             rec['helper_wavefront'] = dict(zip(('header', 'masks', 'logits', 'softmax', 'priors'), [int(x) for x in hs[-1]]))
         out['workloads'][key] = rec
         print(key, rec)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    with open(os.path.join(ROOT, 'gpurun_out', 'r05_phase_budget.json'), 'w') as fh:
+    with open(os.path.join(ROOT, 'gpurun_out', 'r06_phase_budget.json'), 'w') as fh:
         json.dump(out, fh, indent=1)
 
 

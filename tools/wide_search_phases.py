@@ -14,6 +14,9 @@ net = N.NNetWrapper(Game, N.BRANDUBH_NET_ARGS if game == 'brandubh' else N.DEFAU
 B = int(sys.argv[1]) if len(sys.argv) > 1 else (512 if game == 'brandubh' else 256)
 sims = 200 if game == 'brandubh' else 50
 e = DeviceEngine(Game.AZG_GAME_ID, B, cpuct=1.25, fpu_reduction=0.2, add_root_noise=True, add_root_temp=True, seed=0, sims_hint=sims, example_capacity=B * 808 * 2)
+exact = len(sys.argv) > 3 and sys.argv[3] == 'exact'
+net._hip.search(e, 0, exact=exact)                           # one-time set-up: the tile is measured here
+print('TILE %s' % (net._hip.search_tile(e, exact=exact) or {}).get('games_per_workgroup'), flush=True)
 for mv in range(6):
-    net._hip.search(e, sims, exact=len(sys.argv) > 3 and sys.argv[3] == 'exact'); e.advance(True)
+    net._hip.search(e, sims, exact=exact); e.advance(True)
 torch.cuda.synchronize()
