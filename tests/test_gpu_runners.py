@@ -241,6 +241,26 @@ def test_wide_head_runner_graph_equals_eager_launches(game):
         assert x.shape == y.shape and (x == y).all()
 
 
+def test_pinned_heads_features_needs_no_second_switch():
+    """SelfPlayRunner(heads='features') ALONE (the default search_heads = 'exact' used to downgrade the features hand-over before
+    the pinned form was looked at, and the call raised NotImplementedError): a pinned hand-over form is taken as given, and plays the games
+    the same form plays when search_heads='sparse' is passed beside it."""
+    import torch
+    from alphazero_general_amd import nnet as N
+    from alphazero_general_amd.envs.trimok import Game
+    from alphazero_general_amd.selfplay import SelfPlayRunner
+    torch.manual_seed(19)
+    net = N.NNetWrapper(Game, N.DEFAULT_NET_ARGS, device='cuda:0', dtype=torch.float16)
+    outs = []
+    for kw in (dict(heads='features'), dict(heads='features', search_heads='sparse'), dict(heads='logits')):
+        r = SelfPlayRunner(Game, net, _args(numMCTSSims=8, cpuct=1.25, fpu_reduction=0.2), num_slots=24, seed=3, example_capacity=24 * 26 * 4, **kw)
+        assert not r.fused_search
+        for _ in range(6):
+            r.play_round()
+        outs.append((r.engine.last_actions().cpu().numpy(), r.counters()))
+    assert (outs[0][0] == outs[1][0]).all() and outs[0][1] == outs[1][1] and outs[0][1]['sims'] == 6 * 8 * 24 == outs[2][1]['sims']
+
+
 @pytest.mark.parametrize('game,heads', [('brandubh', 'exact'), ('trimok', 'exact'), ('brandubh', 'sparse'), ('trimok', 'sparse')])
 def test_wide_head_runner_persistent_launch_with_fast_rounds_and_resets(game, heads):
     """The persistent wide-head launches inside the native runner (azg_search_wide_exact_f16, the default, and azg_search_wide_f16:
