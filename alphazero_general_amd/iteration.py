@@ -21,7 +21,6 @@ same function with the same arguments; without an initialised process group it i
 import os
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -91,6 +91,74 @@ def test_exchange_and_sample_files_world2(tmp_path):
     assert int(outs[1][5]['bn1.num_batches_tracked']) == 41 and any((outs[1][6][k] != outs[0][6][k]).any() for k in outs[0][6])
 
 
+def _lead_serve_worker(rank, world, port, q):
+    """the command protocol of a Coach-driven job without a GPU: run_iteration / run_arena are replaced by recorders (the engines need a
+    device; the real thing runs on the GPU rig, tests/test_gpu_iteration.py) -- what is checked here is what TRAVELS: the picklable slice
+    of the args, the temperature table of a schedule that does not pickle, the weights (one broadcast per distinct net, shared nets sent
+    once), warm-up iterations without a net, and 'stop'."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from alphazero_general_amd import distributed as D
+    from alphazero_general_amd import iteration as I
+    from alphazero_general_amd.envs.connect4 import Game
+    from alphazero_general_amd.nnet import NNetWrapper, DEFAULT_NET_ARGS
+    from alphazero_general_amd.utils import dotdict
+    D.init_from_env(backend='gloo')
+    seen = []
+
+    def digest(n):
+        return None if n is None else float(sum(v.double().sum() for v in n.nnet.state_dict().values()))
+
+    def fake_iter(game_cls, nnet, args, iteration, folder=None, **kw):
+        seen.append(('selfplay', iteration, digest(nnet), None if nnet is None else int(nnet.args.num_channels), {k: args.get(k) for k in ('numMCTSSims', 'gamesPerIteration', 'cpuct')},
+                     list(args.get('_azg_temp_table', []))[:3] if '_azg_temp_table' in args else 'fn', sorted(kw)))
+        return {'games': 0}
+
+    def fake_arena(game_cls, nnets, args, num_games, **kw):
+        seen.append(('arena', num_games, [digest(n) for n in nnets], [nnets[1] is n for n in nnets], sorted(kw)))
+        return ([0, 0], 0, [0, 0])
+    I.run_iteration, I.run_arena = fake_iter, fake_arena
+    served = None
+    if rank == 0:
+        torch.manual_seed(5)
+        new = NNetWrapper(Game, dict(DEFAULT_NET_ARGS, num_channels=16, depth=2), device='cpu')
+        past = NNetWrapper(Game, dict(DEFAULT_NET_ARGS, num_channels=16, depth=2), device='cpu')
+        args = dotdict(numMCTSSims=33, gamesPerIteration=12, cpuct=2.5, temp_scaling_fn=lambda t, *_: t * 0.5, startTemp=1.0, baselineTester=object, workers=2)
+        I.lead('selfplay', Game, [new], args, iteration=4, folder=None, num_slots=8)
+        I.lead('arena', Game, [new, past, past], args, num_games=10, seats='slot')
+        I.lead('selfplay', Game, [None], args, iteration=1, warmup=True)
+        I.lead('stop', Game, [], args)
+        mine = [digest(new), digest(past)]
+    else:
+        torch.manual_seed(99)
+        served = I.serve(Game, device='cpu')
+        mine = None
+    D.barrier()
+    q.put((rank, seen, served, mine))
+    dist.destroy_process_group()
+
+
+def test_lead_and_serve_protocol_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_lead_serve_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    outs = sorted([q.get(timeout=240) for _ in range(2)], key=lambda o: o[0])
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, lead_seen, _, (d_new, d_past)), (_, serve_seen, served, _) = outs
+    assert served == 3 and len(serve_seen) == len(lead_seen) == 3
+    sp, ar, wu = serve_seen
+    # self-play: rank 0's weights bit for bit, the architecture, the args that matter; the schedule arrived as its table
+    assert sp[:4] == ('selfplay', 4, d_new, 16) and sp[4] == {'numMCTSSims': 33, 'gamesPerIteration': 12, 'cpuct': 2.5} and sp[5] == [0.5, 0.25, 0.125]
+    assert 'num_slots' in sp[6] and 'keep_samples' in sp[6]
+    # arena [new, past, past]: two distinct nets travelled, the shared one is ONE object on the serving rank too
+    assert ar[0] == 'arena' and ar[1] == 10 and ar[2] == [d_new, d_past, d_past] and d_new != d_past and ar[3] == [False, True, True] and 'seats' in ar[4]
+    # warm-up: no net, no weights
+    assert wu[:3] == ('selfplay', 1, None) and 'warmup' in wu[6]
+    assert lead_seen[0][2] == d_new and lead_seen[0][5] == 'fn'       # rank 0 plays its own shard with its own objects and its own callable
+
+
 def test_adopt_takes_live_weights_and_rebuilds_the_architecture():
     """NNetWrapper.adopt: a live module / wrapper / state_dict, no checkpoint file; a different architecture is rebuilt from the
     source's args like load_checkpoint(use_saved_args=True) does (NNetWrapper.py:252-276)."""
