@@ -1211,8 +1211,8 @@ static std::map<WideTileKey, WideTilePick> g_tile;
 // Set-up autotune (sims == 0, never inside a capture): every tile shape this (game, width) has is timed ONCE on a scratch engine of the same
 // size -- fresh games, a node store for the trial only -- with THIS network: a warm launch and a timed launch of 24 simulations each; the
 // fastest is the engine's tile for (B, nblocks) from then on.  Tile shape changes no result (every shape is bit-identical to the
-// launch-per-phase form: tests/test_gpu_fullsize.py), so the measurement only decides speed.  Falls back to the model when the scratch
-// engine cannot be had (memory).
+// launch-per-phase form: tests/test_gpu_fullsize.py), so the measurement only decides speed.  The model's tile is the prior: a trial has to
+// beat it by more than 3 % to replace it.  Falls back to the model when the scratch engine cannot be had (memory).
 template <bool EXACT>
 static int wide_tile_autotune(azg_engine *e, hipStream_t s, const TowerParams &P, int channels, const HeadRows &hd, const HeadsFull &hf, const int *occ,
                               WideTilePick &pick) {
@@ -1245,6 +1245,11 @@ static int wide_tile_autotune(azg_engine *e, hipStream_t s, const TowerParams &P
     azg_engine_destroy(tmp);
     (void)hipGetLastError();
     if (!best) return AZG_E_HIP;
+    // hysteresis: the model's tile (pick.bt on entry) stands unless the fastest trial beats ITS trial by more than 3 % -- near-ties (512
+    // brandubh games: one and two games per workgroup are 1 % apart) would otherwise flip with the noise of a single timing, and under a
+    // profiler, which serialises and slows the trials, the kernel a run is measured on must not depend on which pass it is
+    const int prior = pick.bt;
+    if (prior >= 1 && prior <= tmax && pick.us[prior - 1] > 0 && best_ms * 1e3f >= 0.97f * pick.us[prior - 1]) best = prior;
     pick.bt = best; pick.source = 1;
     return AZG_OK;
 }

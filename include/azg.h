@@ -320,7 +320,8 @@ int  azg_debug_bounds_site(azg_engine *e, void *stream, int32_t *site, int32_t *
 
 /* The tile the persistent wide-head launches of `e` run with -- games per workgroup, picked per (device, game, tower width, heads, engine
  * size, depth): MEASURED at the launch's one-time set-up (sims == 0: every tile shape this game / width has is timed once, 24 + 24 simulations on
- * a scratch engine of the same size with the caller's network; tile shape changes no result), else a model derived from the device (CU
+ * a scratch engine of the same size with the caller's network; a trial replaces the model's tile when it is more than 3 % faster; tile shape
+ * changes no result), else a model derived from the device (CU
  * count, the occupancy query of each tile's kernel with its LDS at this depth) and the depth.  info12 = {games per workgroup, workgroups of a
  * launch, workgroups a CU holds at once, CUs, source (0 model, 1 measured, 2 forced by a tuning build), simulations per trial launch, 0, 0,
  * ns per trial launch at 1 / 2 / 3 / 4 games per workgroup (0: not measured)}.  AZG_E_INVALID_ARG before the first call of the launch for this engine size and depth.
