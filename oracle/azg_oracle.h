@@ -58,6 +58,9 @@ int      azo_tape_choice(uint64_t seed, uint64_t stream, uint64_t ctr, const flo
 /* dirichlet([alpha]*k): one draw from the stream (event key) + per-element sub-streams              */
 void     azo_tape_dirichlet(uint64_t seed, uint64_t stream, uint64_t ctr, int k, double alpha, double *out);
 double   azo_tape_uniform(uint64_t seed, uint64_t stream, uint64_t ctr);   /* [0,1) 53-bit           */
+/* replay of recorded draws for one stream (the MT19937 tier): ranks int16[len], u double[len], noise_off int32[len] into noise_pool  */
+void     azo_tape_set_replay(uint64_t stream, const int16_t *ranks, const double *u, const int32_t *noise_off, const float *noise_pool, int len);
+void     azo_tape_clear_replay(void);
 double   azo_det_log(double x);
 double   azo_det_exp(double x);
 

@@ -32,9 +32,28 @@ static inline double u52_open(uint64_t z) { return ((double)(z >> 12) + 0.5) * (
 
 double azo_tape_uniform(uint64_t seed, uint64_t stream, uint64_t ctr) { return u53(azo_tape_u64(seed, stream, ctr)); }
 
+/* ---- replay of RECORDED draws (the MT19937 tier of "identical seeds"): a stream registered here takes its shuffles,
+ * Dirichlet vectors and choice uniforms from arrays indexed by the tape counter instead of the counter-based tape -- the draws the
+ * reference itself made on numpy's global stream under np.random.seed(s) (tests/golden/c4_mt19937_agent.npz), so that the oracle can be
+ * held to the reference move for move on the CPU.  Same layout as the product's azg_set_random_tape.  Test infrastructure. */
+typedef struct { uint64_t stream; const int16_t *ranks; const double *u; const int32_t *noise_off; const float *noise_pool; int len; } azo_replay;
+static azo_replay g_replay[256];
+static int g_nreplay = 0;
+void azo_tape_set_replay(uint64_t stream, const int16_t *ranks, const double *u, const int32_t *noise_off, const float *noise_pool, int len) {
+    for (int i = 0; i < g_nreplay; i++) if (g_replay[i].stream == stream) { g_replay[i] = (azo_replay){stream, ranks, u, noise_off, noise_pool, len}; return; }
+    if (g_nreplay < 256) g_replay[g_nreplay++] = (azo_replay){stream, ranks, u, noise_off, noise_pool, len};
+}
+void azo_tape_clear_replay(void) { g_nreplay = 0; }
+static const azo_replay *replay_of(uint64_t stream) {
+    for (int i = 0; i < g_nreplay; i++) if (g_replay[i].stream == stream) return &g_replay[i];
+    return 0;
+}
+
 /* Replaces np.random.shuffle(list) at MCTS.pyx:79: element i gets key tape(ctr+i); the new order is ascending
  * (key, i).  pos[i] = rank of element i. */
 void azo_tape_shuffle_pos(uint64_t seed, uint64_t stream, uint64_t ctr, int k, int32_t *pos) {
+    const azo_replay *rp = replay_of(stream);
+    if (rp && rp->ranks) { for (int i = 0; i < k; i++) pos[i] = ctr + (uint64_t)i < (uint64_t)rp->len ? rp->ranks[ctr + (uint64_t)i] : i; return; }
     uint64_t key[1024];
     for (int i = 0; i < k; i++) key[i] = azo_tape_u64(seed, stream, ctr + (uint64_t)i);
     for (int i = 0; i < k; i++) {
@@ -48,7 +67,8 @@ void azo_tape_shuffle_pos(uint64_t seed, uint64_t stream, uint64_t ctr, int k, i
  * (numpy/random/mtrand.pyx RandomState.choice: cdf = p.cumsum() in double; cdf /= cdf[-1];
  *  idx = cdf.searchsorted(uniform, side='right')). */
 int azo_tape_choice(uint64_t seed, uint64_t stream, uint64_t ctr, const float *p, int n) {
-    double u = u53(azo_tape_u64(seed, stream, ctr));
+    const azo_replay *rp = replay_of(stream);
+    double u = (rp && rp->u && ctr < (uint64_t)rp->len) ? rp->u[ctr] : u53(azo_tape_u64(seed, stream, ctr));
     double total = 0.0;
     for (int i = 0; i < n; i++) total += (double)p[i];
     double acc = 0.0; int idx = 0;
@@ -131,6 +151,11 @@ static double ss_gamma(substream *s, double alpha) {
 /* Replaces np.random.dirichlet([alpha]*k) at MCTS.pyx:199-201 (normalised gamma variates, numpy legacy
  * normalisation order: acc += val[i] sequentially; val[i] *= 1/acc). */
 void azo_tape_dirichlet(uint64_t seed, uint64_t stream, uint64_t ctr, int k, double alpha, double *out) {
+    const azo_replay *rp = replay_of(stream);
+    if (rp && rp->noise_off && ctr < (uint64_t)rp->len && rp->noise_off[ctr] >= 0) {      /* (float32, as MCTS.pyx:198-200 casts the vector) */
+        for (int i = 0; i < k; i++) out[i] = (double)rp->noise_pool[rp->noise_off[ctr] + i];
+        return;
+    }
     uint64_t key = azo_tape_u64(seed, stream, ctr);
     double acc = 0.0;
     for (int i = 0; i < k; i++) { substream s = { key, (uint64_t)i, 0 }; out[i] = ss_gamma(&s, alpha); }

@@ -80,6 +80,8 @@ def lib():
         'azo_tape_choice': (C.c_int, [u64, u64, u64, _fp(np.float32), C.c_int]),
         'azo_tape_dirichlet': (None, [u64, u64, u64, C.c_int, f64, _fp(np.float64)]),
         'azo_tape_uniform': (f64, [u64, u64, u64]),
+        'azo_tape_set_replay': (None, [u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+        'azo_tape_clear_replay': (None, []),
         'azo_det_log': (f64, [f64]), 'azo_det_exp': (f64, [f64]),
         'azo_np_sum_f32': (f32, [_fp(np.float32), C.c_int]),
         'azo_np_pow_f32': (f32, [f32, f64]),

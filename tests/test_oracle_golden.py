@@ -191,6 +191,47 @@ def test_c4_mt19937_agent_fixture_is_numpys_own_stream():
     assert d['s_obs'].shape[0] == 2 * int(d['r_turns'].sum())                  # two symmetries per recorded position (connect4.pyx:96-99)
 
 
+def test_c4_mt19937_agent_vs_oracle():
+    """The oracle held to the reference under numpy's OWN stream: with the draws the reference's SelfPlayAgent made under np.random.seed(s)
+    replayed per game slot (azo_tape_set_replay: shuffles, Dirichlet vectors, choice uniforms), the C restatement plays the same six games --
+    visit counts and sampled action of every slot in every round, games_played, every sample incl. symmetries, the results in queue order."""
+    import ctypes as CT
+    d = dict(np.load(os.path.join(G, 'c4_mt19937_agent.npz')))
+    B, sims, games, eseed = int(d['B']), int(d['sims']), int(d['games']), int(d['eval_seed'])
+    cpuct, fpu, nfrac, rtemp = [float(x) for x in d['cfg']]
+    keep = [np.ascontiguousarray(d['tape_ranks']), np.ascontiguousarray(d['tape_u']), np.ascontiguousarray(d['tape_noise_off']), np.ascontiguousarray(d['tape_noise_pool'])]
+    L = keep[0].shape[1]
+    ol.lib().azo_tape_clear_replay()
+    try:
+        for sl in range(B):
+            ol.lib().azo_tape_set_replay(sl, keep[0][sl].ctypes.data_as(CT.c_void_p), keep[1][sl].ctypes.data_as(CT.c_void_p), keep[2][sl].ctypes.data_as(CT.c_void_p),
+                                         keep[3].ctypes.data_as(CT.c_void_p), L)
+        ag = ol.OAgent(C4, B, sims=sims, games_per_iteration=games, seed=424242, cpuct=cpuct, fpu_reduction=fpu, root_noise_frac=nfrac, root_policy_temp=rtemp,
+                       add_root_noise=True, add_root_temp=True)
+        step = 0
+        for rnd in range(len(d['actions'])):
+            assert ag.begin_round() == sims
+            for _ in range(sims):
+                ag.generate_batch()
+                pol = np.zeros((B, 7), np.float32); val = np.zeros((B, 3), np.float32)
+                for i in range(B):
+                    pol[i], val[i] = ol.fake_eval(eseed, i, step, 7, 3)
+                ag.process_batch(pol, val); step += 1
+            for i in range(B):
+                ch = ag.root_children(i)
+                c = np.zeros(7, np.int32); c[ch['a']] = ch['n']
+                assert (c == d['counts'][rnd, i]).all(), (rnd, i)
+            ag.play_moves()
+            assert (ag.last_actions() == d['actions'][rnd]).all(), rnd
+            assert ag.games_played == d['games_played'][rnd]
+        so, sp, sz = ag.samples()
+        assert so.shape == d['s_obs'].shape and (so == d['s_obs']).all() and (sp == d['s_pi']).all() and (sz == d['s_z']).all()
+        ws, turns, _ = ag.results()
+        assert (ws == d['r_ws']).all() and (turns == d['r_turns']).all()
+    finally:
+        ol.lib().azo_tape_clear_replay()
+
+
 TREE_CFGS = ['default', 'c4train', 'noise', 'noise_temp']
 
 
