@@ -29,6 +29,8 @@ VARIANTS = {                                                         # name -> (
     'tuning': ('libazg_tuning.so', ['-DAZG_TUNING']),
     'timing-tree': ('libazg_timing.so', ['-DAZG_TREE_TIMING']),
     'timing-tower': ('libazg_timing.so', ['-DAZG_TOWER_TIMING']),
+    'exp-heads3': ('libazg_exp_heads3.so', ['-DAZG_EXP_HEADS_WAVES=3']),  # experiment: walker out of the heads phase after the value subtile, 3 / 2 wavefronts stream the policy subtiles
+    'exp-heads2': ('libazg_exp_heads2.so', ['-DAZG_EXP_HEADS_WAVES=2']),
     'headline1': ('libazg_headline1.so', ['-DAZG_HEADLINE_ONE_WG']),   # experiment: the connect4 search kernel with one workgroup per CU (512 registers, no spills)
 }
 

@@ -1153,6 +1153,17 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             // (one-game tiles only: the 100 registers the fragments wait in cost the multi-game tiles more in spills than the round trip:
             //  brandubh 512 games 7.24 -> 7.03 ms per move, 2048 games 15.19 -> 15.61 with it, same box)
             constexpr bool HEADS_EARLY = EXACT && BOARDS == 1;
+#ifdef AZG_EXP_HEADS_WAVES
+            // (experiment, build.py --variant exp-heads*: the walker leaves the heads phase after the value subtile, AZG_EXP_HEADS_WAVES
+            //  wavefronts stream the policy subtiles -- the COST side of overlapping the walk with the policy heads, measured before
+            //  anything is restructured: profiles/r06_heads_waves_ab.txt)
+            constexpr bool HEADS_EXP = HEADS_EARLY && NT / 64 == 4;
+            constexpr int OSP_ = (WideGameOf<SEARCH>::type::A + 15) / 16;   // (policy subtiles: the value subtile is number OSP_)
+            if constexpr (HEADS_EXP) {
+                if (wave == 0) heads_full_prefetch<typename SEARCH::Game, HW, 64>(sa.hf, OSP_, lane, hfirst);
+                else if (wave <= AZG_EXP_HEADS_WAVES) heads_full_prefetch<typename SEARCH::Game, HW, AZG_EXP_HEADS_WAVES>(sa.hf, wave - 1, lane, hfirst);
+            } else
+#endif
             if constexpr (HEADS_EARLY) heads_full_prefetch<typename SEARCH::Game, HW, NT / 64>(sa.hf, wave, lane, hfirst);
             if (cg == 0) {
                 int opaque = 0;
@@ -1204,6 +1215,12 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 // (second stage: the next tree phase turns the features into the logits it needs -- sparse heads, azg_kernels.h)
                 __syncthreads();                                 // the features of every board are in LDS
                 AZG_WPHASE(3);
+#ifdef AZG_EXP_HEADS_WAVES
+                if constexpr (HEADS_EXP) {
+                    if (wave == 0) heads_full_lds<typename SEARCH::Game, HW, BOARDS, 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, OSP_, lane, hfirst);
+                    else if (wave <= AZG_EXP_HEADS_WAVES) heads_full_lds<typename SEARCH::Game, HW, BOARDS, AZG_EXP_HEADS_WAVES, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave - 1, lane, hfirst);
+                } else
+#endif
                 if constexpr (HEADS_EARLY) {
                     heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave, lane, hfirst);
                 } else if constexpr (EXACT) {
