@@ -29,8 +29,10 @@ VARIANTS = {                                                         # name -> (
     'tuning': ('libazg_tuning.so', ['-DAZG_TUNING']),
     'timing-tree': ('libazg_timing.so', ['-DAZG_TREE_TIMING']),
     'timing-tower': ('libazg_timing.so', ['-DAZG_TOWER_TIMING']),
-    'exp-heads3': ('libazg_exp_heads3.so', ['-DAZG_EXP_HEADS_WAVES=3']),  # experiment: walker out of the heads phase after the value subtile, 3 / 2 wavefronts stream the policy subtiles
-    'exp-heads2': ('libazg_exp_heads2.so', ['-DAZG_EXP_HEADS_WAVES=2']),
+    'timing-w1': ('libazg_timing_w1.so', ['-DAZG_TOWER_TIMING', '-DAZG_PHASE_TID=64', '-DAZG_TUNING']),          # phase stamps of wavefront 1 (a streaming wavefront in every heads layout)
+    'timing-w1-overlap': ('libazg_timing_w1o.so', ['-DAZG_TOWER_TIMING', '-DAZG_PHASE_TID=64', '-DAZG_OVL_NW=2', '-DAZG_TUNING']),
+    'ring1': ('libazg_ring1.so', ['-DHEADS_A_RING=1', '-DAZG_TUNING']),                        # A/B of the heads' A-operand ring depth (product: 4); ring 1 = round 5's schedule
+    'overlap': ('libazg_overlap.so', ['-DAZG_OVL_NW=2', '-DAZG_TUNING']),                      # experiment (not adopted): the one-game exact tile with the walk overlapped with the policy-head stream; A/B against 'tuning'
     'headline1': ('libazg_headline1.so', ['-DAZG_HEADLINE_ONE_WG']),   # experiment: the connect4 search kernel with one workgroup per CU (512 registers, no spills)
 }
 

@@ -451,6 +451,19 @@ template <class G, int MINB = 1, bool EXACT_ = false> struct SearchWide {
     using Game = G; static constexpr bool WIDE = true; static constexpr int MIN_BLOCKS = MINB; static constexpr bool EXACT = EXACT_;
 };
 
+// OVERLAPPED one-game tile (exact heads, four wavefronts, a wide policy head: brandubh up to 512 games per GPU).  The heads phase is a
+// parameter stream through the CU's L1 miss path, not arithmetic, and only ONE wavefront of the next tree phase -- the helper -- needs
+// the policy logits; the walker needs the value row.  So AZG_OVL_NW wavefronts (waves 1 .. NW) stream the head matrix, value subtile
+// first, while wave 0 walks (backup_path, descent, expansion) and wave 3 runs the shuffle masks and the rules of the walk; the helper
+// (wave 1) turns to the priors when the last policy subtile is in LDS.  No workgroup barrier between the head convolutions and the next
+// tower: the wavefronts meet through LDS generation flags and a snapshot of the header (WideScratch::SNAP).  Same arithmetic, same
+// results as the phase-by-phase form.  0 = off (the heads phase and the tree phase take turns).
+// MEASURED AND NOT ADOPTED (profiles/r06_heads_waves_ab.txt): bit-identical results, 9-10 % slower at 512 brandubh games -- a streaming
+// wavefront moves one subtile (25 KB, all the registers hold) per ~2.3 k cycles whether two or four wavefronts stream, so the stream
+// needs all four; build.py --variant overlap (-DAZG_OVL_NW=2) builds it.
+#ifndef AZG_OVL_NW
+#define AZG_OVL_NW 0
+#endif
 // per-game LDS scratch of the wide search mode (behind the image)
 // COMPACT (solo tree phase, several games per workgroup: LDS is what limits the games a CU holds): the softmax output and the masked
 // policy of np.sum take turns in the logits' place -- every stage reads its input into registers before the next one writes (one
@@ -461,12 +474,16 @@ template <class G, int HW, bool COMPACT = false> struct WideScratch {
     // (COMPACT drops what only the multi-wavefront tree phase uses -- the shuffle masks, the walk's mailbox -- and leaves the path in HBM:
     //  its reads and writes are one coalesced access per simulation each, off the dependent chain)
     static constexpr int LG = 0, PI = COMPACT ? LG : LG + OPAD * 4, M = COMPACT ? LG : PI + A * 4, SCR = COMPACT ? LG + OPAD * 4 : M + (A < 8 ? 8 : A) * 4, ACT = SCR + 256,
-                         LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + (COMPACT ? 0 : 512), FEAT = FLAGS + 16,
+                         LESS = (ACT + ((G::MAXK + 63) / 64) * 256 + 15) / 16 * 16, FLAGS = LESS + (COMPACT ? 0 : 512), NFLAGS = (COMPACT || AZG_OVL_NW == 0) ? 4 : 8, FEAT = FLAGS + NFLAGS * 4,
                          // the game's tree state for the length of the launch (the workgroup owns the game): header, last path, tape
                          // counter + the two per-slot tallies, root state -- read and written in LDS, copied from / to HBM once
                          HDR = (FEAT + 2 * FK * 2 + 63) / 64 * 64, PATH = HDR + 64, MAXD = G::MAX_TURNS + 2, CTR = PATH + (COMPACT ? 0 : MAXD * 16),
                          STATE = CTR + 32, MAIL = (STATE + (int)sizeof(azg_state) + 15) / 16 * 16,                 // (WalkMail: azg_kernels.h)
-                         BYTES = (MAIL + (COMPACT ? 0 : (int)sizeof(WalkMail)) + 15) / 16 * 16;
+                         // SNAP: the header and the tape counter as the walker LEFT them at the end of its tree phase (overlapped one-game
+                         // tile, wide_overlap_nw: the other wavefronts of the game enter the next tree phase long after the walker has --
+                         // the helper only when the walker may have FINISHED it, so two copies take turns: phase s writes copy s & 1)
+                         SNAP = (MAIL + (COMPACT ? 0 : (int)sizeof(WalkMail)) + 15) / 16 * 16, SNAP_BYTES = 80,
+                         BYTES = (SNAP + ((COMPACT || AZG_OVL_NW == 0) ? 0 : 2 * SNAP_BYTES) + 15) / 16 * 16;
 };
 // all of the wide search mode's LDS behind the image: the per-game scratch, an error word, and the value head's P + 1 weight rows
 // + biases (the same for every game and simulation: fetched once per launch instead of once per simulation by every walker;
@@ -494,11 +511,26 @@ template <class G, int HW, int BOARDS, bool COMPACT = false> struct WideLds : Wi
 //   streams one subtile's 25 KB contiguously); wv [k-step][64]; bias f32 [A + P + 1].
 // the fragments and the bias of a wavefront's FIRST subtile: they do not depend on the evaluation, so the launch requests them before
 // the head convolutions and the barrier behind them (one L2 round trip of the stream hidden per simulation)
+// consumption order of a subtile's k-steps: the four accumulation chains (one per contiguous quarter of the k-steps) interleaved
+template <int KS, int KQ> struct HeadsOrder {
+    int ks[KS], q[KS];
+    constexpr HeadsOrder() : ks{}, q{} {
+        int n = 0;
+        for (int j = 0; j < KQ; j++)
+            for (int qq = 0; qq < HEADF_Q; qq++) { const int k = qq * KQ + j; if (k < KS && k < (qq + 1) * KQ) { ks[n] = k; q[n] = qq; n++; } }
+    }
+};
+#ifndef HEADS_A_RING
+#define HEADS_A_RING 4
+#endif
 template <class G, int HW> struct HeadsFirst { half8 b[WideScratch<G, HW>::FK / 32]; float bias; };
-template <class G, int HW, int NW>
+// VFIRST (the overlapped one-game tile): the wavefronts take ITEMS instead of subtiles -- item 0 is the value subtile, item j > 0
+// the policy subtile j - 1 -- so that the first thing streaming wavefront 0 finishes is the value row the walker is waiting for
+template <int OSP, bool VFIRST> __device__ __forceinline__ int heads_item_subtile(int j) { return VFIRST ? (j == 0 ? OSP : min(j - 1, OSP)) : min(j, OSP); }
+template <class G, int HW, int NW, bool VFIRST = false>
 __device__ __forceinline__ void heads_full_prefetch(const HeadsFull &hf, int wave, int lane, HeadsFirst<G, HW> &pf) {
     constexpr int A = G::A, NV = G::P + 1, KS = WideScratch<G, HW>::FK / 32, KQ = (KS + HEADF_Q - 1) / HEADF_Q, OSP = (A + 15) / 16;
-    const int i16 = lane & 15, s0 = min(wave, OSP);
+    const int i16 = lane & 15, s0 = heads_item_subtile<OSP, VFIRST>(wave);
     const half8 *w0 = s0 == OSP ? hf.wv + lane : hf.wps + (size_t)s0 * (KS * 64) + lane;
     pf.bias = hf.bias[min(s0 == OSP ? A + i16 : s0 * 16 + i16, A + NV - 1)];
 #pragma unroll
@@ -506,8 +538,9 @@ __device__ __forceinline__ void heads_full_prefetch(const HeadsFull &hf, int wav
 #pragma unroll
         for (int q = 0; q < HEADF_Q; q++) { const int ks = q * KQ + j; if (ks < KS && ks < (q + 1) * KQ) pf.b[ks] = w0[(size_t)ks * 64]; }
 }
-template <class G, int HW, int BOARDS, int NW, bool COMPACT>
-__device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row, const HeadsFull &hf, int wave, int lane, HeadsFirst<G, HW> &pf) {
+template <class G, int HW, int BOARDS, int NW, bool COMPACT, bool VFIRST = false>
+__device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row, const HeadsFull &hf, int wave, int lane, HeadsFirst<G, HW> &pf,
+                                               [[maybe_unused]] int *vflag = nullptr, [[maybe_unused]] int vgen = 0) {
     using WS = WideScratch<G, HW, COMPACT>;
     constexpr int A = G::A, NV = G::P + 1, FK = WS::FK, KS = FK / 32, KQ = (KS + HEADF_Q - 1) / HEADF_Q, OSP = (A + 15) / 16;
     constexpr int NIT = (OSP + 1 + NW - 1) / NW;                             // subtiles per wavefront (the last one may be a repeat)
@@ -518,34 +551,48 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row,
     const int vhalf = live ? FK * 2 : 0;
     auto frags = [&](int s_) { return s_ == OSP ? hf.wv + lane : hf.wps + (size_t)s_ * (KS * 64) + lane; };
     // consumption order of the k-steps: the four chains interleaved
+    constexpr HeadsOrder<KS, KQ> ord;
     half8 (&b)[KS] = pf.b;                                                   // (heads_full_prefetch)
     float bias_cur = pf.bias, bias_nxt = 0.f;
+    // The A operand (the boards' features) comes out of LDS through a ring of AR registers that runs AR steps ahead of the MFMAs,
+    // across subtile boundaries.  Left to the register allocator every step's ds_read_b128 landed in ONE register quad, issued behind
+    // the previous MFMA and waited for with lgkmcnt(0) in front of the next: 25 exposed LDS round trips per subtile (~2.3 k cycles,
+    // the same whether two or four wavefronts streamed -- what looked like the pace of the fragment stream was this).
+    constexpr int AR = HEADS_A_RING;
+    static_assert(AR >= 1 && AR <= KS, "A ring depth");
+    half8 ar[AR];
+    {
+        const int s0 = heads_item_subtile<OSP, VFIRST>(wave);
+        const char *f0 = fb + (s0 == OSP ? vhalf : 0);
+#pragma unroll
+        for (int p = 0; p < AR; p++) ar[p] = *reinterpret_cast<const half8 *>(f0 + ord.ks[p] * 64);
+    }
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-        const int s_ = wave + it * NW;                                       // (scalar)
-        const int sc = min(s_, OSP), sn = min(s_ + NW, OSP);                 // (past the end: the value subtile once more, not stored)
+        const int s_ = wave + it * NW;                                       // (scalar; VFIRST: the item number)
+        const int sc = heads_item_subtile<OSP, VFIRST>(s_), sn = heads_item_subtile<OSP, VFIRST>(s_ + NW);   // (past the end: the value subtile once more, not stored)
         const bool is_v = sc == OSP;
         const half8 *wn = frags(sn);
-        const char *f = fb + (is_v ? vhalf : 0);
+        const char *f = fb + (is_v ? vhalf : 0), *fn = fb + (sn == OSP ? vhalf : 0);
         if (it + 1 < NIT) bias_nxt = hf.bias[min(sn == OSP ? A + i16 : sn * 16 + i16, A + NV - 1)];
         floatx4 acc[HEADF_Q];
 #pragma unroll
         for (int q = 0; q < HEADF_Q; q++) acc[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < KQ; j++)
-#pragma unroll
-            for (int q = 0; q < HEADF_Q; q++) {
-                const int ks = q * KQ + j;
-                if (ks < KS && ks < (q + 1) * KQ) {
-                    const half8 a = *reinterpret_cast<const half8 *>(f + ks * 64);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[ks], acc[q], 0, 0, 0);
-                    if (it + 1 < NIT) b[ks] = wn[(size_t)ks * 64];
-                    // (pin the interleave: one fragment request behind every MFMA, in consumption order -- left alone the scheduler
-                    //  bunches the requests at the end of the subtile and the next one starts by draining them)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (it + 1 < NIT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-            }
+        for (int p = 0; p < KS; p++) {
+            const int ks = ord.ks[p], q = ord.q[p];
+            const int slot = (it * KS + p) % AR;                             // (compile-time: both loops are unrolled)
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[slot], b[ks], acc[q], 0, 0, 0);
+            if (it + 1 < NIT) b[ks] = wn[(size_t)ks * 64];
+            const bool refill = p + AR < KS || it + 1 < NIT;
+            if (p + AR < KS) ar[slot] = *reinterpret_cast<const half8 *>(f + ord.ks[p + AR] * 64);
+            else if (it + 1 < NIT) ar[slot] = *reinterpret_cast<const half8 *>(fn + ord.ks[p + AR - KS] * 64);
+            // (pin the interleave: one fragment request and one A read behind every MFMA, in consumption order -- left alone the
+            //  scheduler bunches the requests at the end of the subtile and the next one starts by draining them)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (it + 1 < NIT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (refill) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const floatx4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         const int out = is_v ? A + i16 : sc * 16 + i16, lim = is_v ? A + NV : A;
@@ -553,6 +600,16 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row,
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 if (4 * g + r < BOARDS) *reinterpret_cast<float *>(scr0 + (4 * g + r) * WS::BYTES + WS::LG + out * 4) = sum[r] + bias_cur;
+        }
+        if constexpr (VFIRST) {
+            // the value row is complete: tell the walker.  A RELAXED store behind s_waitcnt lgkmcnt(0) (the row's ds_writes have executed;
+            // the flag may go out as a flat store, which is not ordered with them otherwise) -- a release here would be s_waitcnt
+            // vmcnt(0) too, i.e. drain the fragment stream this loop keeps in flight
+            if (it == 0 && wave == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(vflag, vgen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+            }
         }
         bias_cur = bias_nxt;
     }
@@ -564,6 +621,14 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row,
 // process_results and find_leaf itself -- policy logits, softmax, priors, value, path, walk with the rules, shuffle ranks --, the
 // one-wave functions of k_select / k_backup in the order of k_backup_select2; waves past BOARDS only take part in the tower
 template <int C, int PSPLIT, int KSPLIT, int BOARDS> constexpr bool wide_solo() { return (C / 32) * PSPLIT * KSPLIT < 2 * BOARDS; }
+template <class SEARCH, int BOARDS, int NWAVES> constexpr int wide_overlap_nw() {
+    if constexpr (__is_same(SEARCH, NoSearch)) return 0;
+    else if constexpr (!SEARCH::WIDE) return 0;
+    else return (SEARCH::EXACT && BOARDS == 1 && NWAVES == 4 && SEARCH::Game::A > 64) ? AZG_OVL_NW : 0;
+}
+template <class SEARCH> __device__ __forceinline__ int sa_error_word(const SEARCH &sa) {
+    if constexpr (__is_same(SEARCH, NoSearch)) return 0; else return sa.ev.gcount[GC_ERROR];
+}
 template <class SEARCH, class = void> struct WideGameOf { using type = C4; };
 template <class SEARCH> struct WideGameOf<SEARCH, std::void_t<typename SEARCH::Game>> { using type = typename SEARCH::Game; };
 // (-DAZG_HEADLINE_ONE_WG, build.py --variant headline1: the experiment that settles "spill into the unused AGPRs" for the headline kernel --
@@ -605,6 +670,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
     static_assert(!IS_WIDE || (C / 32) * PSPLIT * KSPLIT >= BOARDS, "wide search mode: at least one wavefront per game");
     constexpr bool SOLO = IS_WIDE && wide_solo<C, PSPLIT, KSPLIT, BOARDS>();
     constexpr bool EXACT = []() { if constexpr (IS_WIDE) return SEARCH::EXACT; else return false; }();
+    constexpr int OVL_NW = wide_overlap_nw<SEARCH, BOARDS, C * 2 * PSPLIT * KSPLIT / 64>();
+    constexpr bool OVL = OVL_NW > 0;
+    static_assert(OVL_NW == 0 || OVL_NW == 2, "overlapped tile: waves 1 and 2 stream, wave 3 follows the walk");
     TowerParams P = Pin;
     constexpr int NT = C * 2 * PSPLIT * KSPLIT, KS = C / 32, CPR = C / 8;   // threads, k-steps per tap, 16-B chunks per row
     constexpr bool KHALF = tower_khalf_order<H, W, C>();
@@ -763,8 +831,9 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             float *lg = reinterpret_cast<float *>(ws + WS::LG);
             int *flags = reinterpret_cast<int *>(ws + WS::FLAGS);
             int *errw = reinterpret_cast<int *>(smem + TILE + WideLds<G, HW, BOARDS, SOLO>::ERR);
-            if (sim == 0 && tid < 2 * BOARDS) reinterpret_cast<int *>(smem + TILE + (tid >> 1) * WS::BYTES + WS::FLAGS)[tid & 1] = 0;
-            if ((sim & 15) == 0) {                                   // sticky device error: stop, uniformly over the workgroup
+            if (sim == 0 && tid < WS::NFLAGS * BOARDS) reinterpret_cast<int *>(smem + TILE + (tid / WS::NFLAGS) * WS::BYTES + WS::FLAGS)[tid % WS::NFLAGS] = 0;
+            // (overlapped tile: the wavefronts reach this point at different times -- later checks sit behind the head convolutions' barrier)
+            if (OVL ? sim == 0 : (sim & 15) == 0) {                  // sticky device error: stop, uniformly over the workgroup
                 if (tid == 0) *errw = sa.ev.gcount[GC_ERROR];
                 __syncthreads();
                 const int err = *errw;
@@ -806,8 +875,20 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 __syncthreads();
             }
             HdrR hr; uint64_t ctr0 = 0;
+            if constexpr (OVL) {
+                // the walker reads the live header (it is its only writer); the others the snapshot the walker took when its last tree
+                // phase ended -- by the time they get here the walker may be several levels into THIS phase
+                if (livegame) {
+                    const bool snap = sim > 0 && role != 0;
+                    const char *sp = ws + WS::SNAP + ((sim - 1) & 1) * WS::SNAP_BYTES;
+                    load_hdr(snap ? reinterpret_cast<const TreeHdr *>(sp) : evl.hdr + tree, hr);
+                    ctr0 = snap ? *reinterpret_cast<const uint64_t *>(sp + 64) : evl.tape_ctr[slot];
+                }
+                if (sim == 0) __syncthreads();
+            } else {
             if (livegame) { load_hdr(evl.hdr + tree, hr); ctr0 = evl.tape_ctr[slot]; }
             __syncthreads();                                     // both wavefronts of a game hold the header as the last launch / phase left it
+            }
             const bool has_policy = livegame && sim > 0 && !hr.leaf_e && hr.leaf_fc >= 0;
             const bool root_noise = has_policy && hr.leaf == LEAF_IS_ROOT && sa.ev.add_noise;
             auto sink = [&](const typename G::S &ls, int ln) {       // leaf observation -> the image rows of board bd (32 stem channels)
@@ -852,6 +933,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                             leaf_value_logits<G>(hv, reinterpret_cast<const _Float16 *>(ws + WS::FEAT) + sa.hd.fk, lg + A, lane);
                             wave_sync();
                         }
+                        if constexpr (OVL) flag_wait_gen(sa.ev, &flags[3], sim);     // (the streaming wavefront's first subtile)
                         pv = value_softmax(lg + A, lane, NV);
                     }
 #pragma unroll
@@ -883,10 +965,22 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                         }, RULES_WAVE ? mail : nullptr, sim);
                     }
                 }
+                if constexpr (OVL) {                                 // the header and the counter as this tree phase leaves them
+                    wave_sync();
+                    char *sp = ws + WS::SNAP + (sim & 1) * WS::SNAP_BYTES;
+                    if (lane < 4) reinterpret_cast<uint4 *>(sp)[lane] = reinterpret_cast<const uint4 *>(ws + WS::HDR)[lane];
+                    if (lane == 0) *reinterpret_cast<uint64_t *>(sp + 64) = *reinterpret_cast<const uint64_t *>(ws + WS::CTR);
+                }
             } else if (RULES_WAVE && livegame && role == 3) {        // the rules of the walk: play_action per level, then the leaf
-                if (sim > 0 && sim < sa.sims) follow_tree<G>(evl, slot, G::load(&evl.states[slot], lane), mail, sim, lane, act, sink);
-            } else if (MASK_WAVE && livegame && role == 2) {         // the shuffle of the next expansion (every expansion waits for it)
                 if (sim > 0 && sim < sa.sims) {
+                    if constexpr (OVL) {                             // (overlapped tile: the mask wavefront is streaming the policy head)
+                        reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
+                        flag_set_gen(&flags[1], sim, lane);
+                    }
+                    follow_tree<G>(evl, slot, G::load(&evl.states[slot], lane), mail, sim, lane, act, sink);
+                }
+            } else if (MASK_WAVE && livegame && role == 2) {         // the shuffle of the next expansion (every expansion waits for it)
+                if (!OVL && sim > 0 && sim < sa.sims) {
                     reinterpret_cast<unsigned long long *>(ws + WS::LESS)[lane] = shuffle_less_mask<(G::MAXK < 64 ? G::MAXK : 64)>(sa.ev, slot, ctr0 + (root_noise ? 1 : 0), lane);
                     flag_set_gen(&flags[1], sim, lane);
                 }
@@ -910,6 +1004,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                         leaf_policy_logits<G, tower_min_blocks<SEARCH>() == 1>(sa.hd, nodes, hr.leaf_fc, hr.leaf_k, reinterpret_cast<const _Float16 *>(ws + WS::FEAT), lg, lane);
                         wave_sync();
                     }
+                    if constexpr (OVL) flag_wait_gen(sa.ev, &flags[2], sim);         // (the other streaming wavefront's policy subtiles)
                     AZG_HSTAMP(3);
                     policy_softmax_row<A>(lg, lane, A, pi);
                     wave_sync();
@@ -1153,17 +1248,13 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             // (one-game tiles only: the 100 registers the fragments wait in cost the multi-game tiles more in spills than the round trip:
             //  brandubh 512 games 7.24 -> 7.03 ms per move, 2048 games 15.19 -> 15.61 with it, same box)
             constexpr bool HEADS_EARLY = EXACT && BOARDS == 1;
-#ifdef AZG_EXP_HEADS_WAVES
-            // (experiment, build.py --variant exp-heads*: the walker leaves the heads phase after the value subtile, AZG_EXP_HEADS_WAVES
-            //  wavefronts stream the policy subtiles -- the COST side of overlapping the walk with the policy heads, measured before
-            //  anything is restructured: profiles/r06_heads_waves_ab.txt)
-            constexpr bool HEADS_EXP = HEADS_EARLY && NT / 64 == 4;
-            constexpr int OSP_ = (WideGameOf<SEARCH>::type::A + 15) / 16;   // (policy subtiles: the value subtile is number OSP_)
-            if constexpr (HEADS_EXP) {
-                if (wave == 0) heads_full_prefetch<typename SEARCH::Game, HW, 64>(sa.hf, OSP_, lane, hfirst);
-                else if (wave <= AZG_EXP_HEADS_WAVES) heads_full_prefetch<typename SEARCH::Game, HW, AZG_EXP_HEADS_WAVES>(sa.hf, wave - 1, lane, hfirst);
+            if constexpr (OVL) {                                 // (the streaming wavefronts; items instead of subtiles: value first)
+                if (wave >= 1 && wave <= OVL_NW) heads_full_prefetch<typename SEARCH::Game, HW, OVL_NW, true>(sa.hf, wave - 1, lane, hfirst);
+                if (IS_WIDE && tid == 0 && (sim & 15) == 15) {   // (the sticky-error look, every 16th simulation: read behind the barrier below)
+                    using WLE = WideLds<typename WideGameOf<SEARCH>::type, HW, BOARDS, SOLO>;
+                    *reinterpret_cast<int *>(smem + TILE + WLE::ERR) = sa_error_word(sa);
+                }
             } else
-#endif
             if constexpr (HEADS_EARLY) heads_full_prefetch<typename SEARCH::Game, HW, NT / 64>(sa.hf, wave, lane, hfirst);
             if (cg == 0) {
                 int opaque = 0;
@@ -1215,13 +1306,18 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 // (second stage: the next tree phase turns the features into the logits it needs -- sparse heads, azg_kernels.h)
                 __syncthreads();                                 // the features of every board are in LDS
                 AZG_WPHASE(3);
-#ifdef AZG_EXP_HEADS_WAVES
-                if constexpr (HEADS_EXP) {
-                    if (wave == 0) heads_full_lds<typename SEARCH::Game, HW, BOARDS, 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, OSP_, lane, hfirst);
-                    else if (wave <= AZG_EXP_HEADS_WAVES) heads_full_lds<typename SEARCH::Game, HW, BOARDS, AZG_EXP_HEADS_WAVES, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave - 1, lane, hfirst);
-                } else
-#endif
-                if constexpr (HEADS_EARLY) {
+                if constexpr (OVL) {
+                    // no barrier from here to the next tower: wave 0 goes straight on to walk (it waits for the value row by flag), wave 3
+                    // to the masks and the rules, waves 1 .. NW stream the head matrix; wave 2 then reports its policy subtiles
+                    using WSO = WideScratch<typename SEARCH::Game, HW, SOLO>;
+                    using WLO = WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>;
+                    if ((sim & 15) == 15 && *reinterpret_cast<const int *>(smem + TILE + WLO::ERR)) break;   // (uniform: every wavefront reads the word behind the barrier)
+                    int *flags_ = reinterpret_cast<int *>(smem + TILE + WSO::FLAGS);
+                    if (wave >= 1 && wave <= OVL_NW) {
+                        heads_full_lds<typename SEARCH::Game, HW, BOARDS, OVL_NW, SOLO, true>(smem + TILE, smem + TILE + WLO::ZERO, sa.hf, wave - 1, lane, hfirst, &flags_[3], sim + 1);
+                        if (wave == 2) flag_set_gen(&flags_[2], sim + 1, lane);
+                    }
+                } else if constexpr (HEADS_EARLY) {
                     heads_full_lds<typename SEARCH::Game, HW, BOARDS, NT / 64, SOLO>(smem + TILE, smem + TILE + WideLds<typename SEARCH::Game, HW, BOARDS, SOLO>::ZERO, sa.hf, wave, lane, hfirst);
                 } else if constexpr (EXACT) {
                     HeadsFirst<typename SEARCH::Game, HW> hl;
@@ -1230,7 +1326,10 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
                 }
                 AZG_WPHASE(4);
 #ifdef AZG_TOWER_TIMING
-                if (P.dbg && tid == 0 && blockIdx.x < 512 && sim >= 8)      // tree (incl. the sparse heads), tower, head conv (cycles, summed over simulations)
+#ifndef AZG_PHASE_TID
+#define AZG_PHASE_TID 0                                              // (the thread whose stamps are summed: 64 = wavefront 1, which streams policy subtiles in every heads layout)
+#endif
+                if (P.dbg && tid == AZG_PHASE_TID && blockIdx.x < 512 && sim >= 8)      // tree (incl. the sparse heads), tower, head conv (cycles, summed over simulations)
                     for (int i = 0; i < 4; i++) P.dbg[2048 + 4096 * 4 + (size_t)blockIdx.x * 4 + i] += wt_[i + 1] - wt_[i];
 #endif
             }
@@ -1332,7 +1431,7 @@ __global__ __launch_bounds__(C * 2 * PSPLIT * KSPLIT, tower_min_blocks<SEARCH>()
             if (tid < 256) reinterpret_cast<uint4 *>(img)[tid] = make_uint4(0, 0, 0, 0);
             if constexpr (IS_SEARCH) { if (tid < 16) reinterpret_cast<uint4 *>(img + SCRATCH_PV)[tid] = make_uint4(0, 0, 0, 0); }
         }
-        __syncthreads();
+        if constexpr (!OVL) __syncthreads();                    // (overlapped tile: the next barrier is the one in front of the next tower)
         }                                                        // sims
         if constexpr (IS_WIDE) {
             // LDS -> HBM: header, tape counter, tallies and the last path of every game, as the launch-per-phase path leaves them
