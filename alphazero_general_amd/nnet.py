@@ -560,6 +560,7 @@ def pin_shared(t):
     ent = _PINNED.get(key)
     if ent is not None and ent[0] >= n:
         ent[3] += 1
+        _PIN_STATS['dma' if ent[1] != 'no' else 'staged'] += 1
         return ent[1] != 'no'
     if ent is not None:                                        # a larger storage at the same address: drop the old (shorter) registration first
         _unpin(key)
@@ -574,10 +575,30 @@ def pin_shared(t):
     except Exception:                                          # noqa: BLE001 (a runtime without host registration: the pageable path stays)
         ok = 'no'
     _PINNED[key] = [n, ok, weakref.ref(t, lambda _r, key=key: _unpin(key)), 1]
+    _PIN_STATS['dma' if ok != 'no' else 'staged'] += 1
+    if ok == 'registered':
+        _PIN_STATS['registrations'] += 1
+    elif ok == 'no' and not _PIN_STATS['warned']:              # the fall-back is never silent: say once why this tensor stays pageable
+        _PIN_STATS['warned'] = 1
+        import warnings
+        warnings.warn('alphazero_general_amd: a shared batch tensor (%d bytes) is copied through the pageable (staged) path: %s -- pin_stats() counts them'
+                      % (n, 'smaller than a page' if n < 4096 else 'its address was registered and dropped %d times (a new tensor object per call?)'
+                         % _PIN_COUNT.get(key, 0) if _PIN_COUNT.get(key, 0) >= 4 else 'hipHostRegister refused it'), RuntimeWarning, stacklevel=3)
     return ok != 'no'
 
 
 _PIN_COUNT = {}
+_PIN_STATS = {'dma': 0, 'staged': 0, 'registrations': 0, 'warned': 0}
+
+
+def pin_stats(reset=False):
+    """How the shared CPU batches handed to NNetWrapper.process travelled: 'dma' (page-locked in place: registered or already pinned),
+    'staged' (pageable: the runtime stages the copy synchronously), 'registrations' (hipHostRegister calls that succeeded)."""
+    out = {k: _PIN_STATS[k] for k in ('dma', 'staged', 'registrations')}
+    if reset:
+        for k in out:
+            _PIN_STATS[k] = 0
+    return out
 
 
 class NNetWrapper:

@@ -561,6 +561,8 @@ def compat_run(W, net, seconds=12.0, workers=2, games_per_worker=None):
         agents[i].daemon = True
         agents[i].start()
     served, nsamples, t_first, t_end = 0, 0, None, None
+    from alphazero_general_amd.nnet import pin_stats
+    pin_stats(reset=True)                                            # (how the shared batches travel: page-locked in place, or staged -- never silently)
     t_wait = t_net = t_copy = 0.0                                    # the parent's own time per batch: idle, evaluation (H2D + net + D2H), hand-back
     deadline = time.time() + float(os.environ.get("AZG_COMPAT_DEADLINE", "240"))
 
@@ -623,6 +625,7 @@ def compat_run(W, net, seconds=12.0, workers=2, games_per_worker=None):
             # nnet.process incl. H2D of the batch and D2H of policy / value, copying into the shared tensors + batch_ready.set()
             'parent_us_per_batch': {'wait_for_agent': round(t_wait * 1e6 / served, 1), 'evaluate_h2d_net_d2h': round(t_net * 1e6 / served, 1),
                                     'hand_back': round(t_copy * 1e6 / served, 1)},
+            'host_batches': pin_stats(),                             # 'dma': page-locked in place (hipHostRegister); 'staged': pageable copies
             'path': 'alphazero_general_amd.SelfPlayAgent (reference constructor / queue protocol) x %d processes, parent serves batches like '
                     'Coach.processSelfPlayBatches with the GPU net: per simulation two process hops + H2D + D2H of the batch' % workers}
 

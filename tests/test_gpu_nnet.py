@@ -367,12 +367,21 @@ def test_shared_batch_tensors_are_page_locked_for_their_lifetime():
     keep = base.clone().share_memory_()
     k2 = keep.untyped_storage().data_ptr()
     N._PIN_COUNT.pop(k2, None)
-    for i in range(8):
-        view = keep[:]                                            # same storage, new tensor object
-        p4, _ = net.process(view)
-        assert torch.equal(p4, p0)
-        del view
-        gc.collect()
+    import warnings
+    N._PIN_STATS['warned'] = 0
+    N.pin_stats(reset=True)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        for i in range(8):
+            view = keep[:]                                        # same storage, new tensor object
+            p4, _ = net.process(view)
+            assert torch.equal(p4, p0)
+            del view
+            gc.collect()
     assert N._PIN_COUNT.get(k2, 0) == 4 and N._PINNED.get(k2, [0, 'no'])[1] == 'no'
+    # ... and the fall-back is not silent: counted, and announced once
+    st = N.pin_stats()
+    assert st['registrations'] == 4 and st['dma'] == 4 and st['staged'] == 4, st
+    assert sum('pageable (staged) path' in str(w.message) for w in caught) == 1, [str(w.message) for w in caught]
     del keep
     gc.collect()
