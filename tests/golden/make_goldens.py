@@ -6,6 +6,8 @@ Outputs (small .npz fixtures, committed):
   c4_tree.npz    single-tree MCTS traces (find_leaf paths, per-sim root stats, counts / probs / value)
   c4_agent.npz   SelfPlayAgent lock-step self-play traces (actions, leaf-obs checksums, samples, results)
   c4_mt19937.npz MCTS.search under np.random.seed(s) on numpy's own MT19937 stream: recorded child shuffles + counts / pi (second tier)
+  c4_mt19937_agent.npz, br_mt19937_agent.npz   a whole SelfPlayAgent (noise + temperature on) under np.random.seed(s): every shuffle /
+                 dirichlet / choice draw observed per game slot + what the agent did (connect4: 6 games; brandubh: 4 games, 53 rounds)
 Every run of the reference is under the random tape (refharness.Tape) and the synthetic evaluator
 (oracle azo_fake_eval), so the fixtures hold seeds + expected outputs only.
 """
@@ -266,7 +268,7 @@ def gen_c4_mt19937(n_roots=64, sims=100, seed=20250929, eval_seed=77):
     print('c4_mt19937: %d roots x %d sims under np.random.seed(%d), %d recorded shuffles' % (n_roots, sims, seed, sum(len(x) for x in lens)))
 
 
-def gen_c4_mt19937_agent(B=4, sims=20, games=6, seed=20260929, eval_seed=91):
+def gen_c4_mt19937_agent(B=4, sims=20, games=6, seed=20260929, eval_seed=91, Game=None, gid=0, name='c4'):
     """The MT19937 tier for a whole SelfPlayAgent: the reference's agent -- connect4, B concurrent games, root noise and
     root temperature ON -- plays `games` games under np.random.seed(seed) with numpy's global stream untouched; np.random.shuffle /
     dirichlet / choice / random_sample are OBSERVED (rh.ObservedRng), per game slot.  The fixture holds the global call order (kinds, slots,
@@ -274,8 +276,9 @@ def gen_c4_mt19937_agent(B=4, sims=20, games=6, seed=20260929, eval_seed=91):
     engine's counter order (shuffle of k: k positions, noise event: 1, move: 1 -- azg_set_random_tape) and what the agent did: visit counts and
     sampled action per round and slot, games_played, the samples and results it queued."""
     import torch
-    from alphazero.envs.connect4.connect4 import Game
-    gi = ol.game_info(0)
+    if Game is None:
+        from alphazero.envs.connect4.connect4 import Game
+    gi = ol.game_info(gid)
     A, NV = gi.action_size, gi.num_players + 1
     args = rh.ref_args(Game, numMCTSSims=sims, gamesPerIteration=games, add_root_noise=True, add_root_temp=True)
     obs = rh.ObservedRng()
@@ -283,7 +286,7 @@ def gen_c4_mt19937_agent(B=4, sims=20, games=6, seed=20260929, eval_seed=91):
     obs.install()
     rec = dict(actions=[], counts=[], games_played=[])
     try:
-        ag = rh.make_ref_agent(Game, 0, B, args, obs)
+        ag = rh.make_ref_agent(Game, gid, B, args, obs)
         step = 0
         for rnd in range(400):
             if ag.games_played.value >= args.gamesPerIteration:
@@ -340,9 +343,9 @@ def gen_c4_mt19937_agent(B=4, sims=20, games=6, seed=20260929, eval_seed=91):
                s_z=np.array([s_[2] for s_ in samples], np.float32).reshape(len(samples), NV),
                r_ws=np.array([np.asarray(r[1], np.uint8) for r in results]).reshape(len(results), NV),
                r_turns=np.array([r[0].turns for r in results], np.int32))
-    np.savez_compressed(os.path.join(OUT, 'c4_mt19937_agent.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, '%s_mt19937_agent.npz' % name), **out)
     nk = {k: int((order[:, 0] == v).sum()) for k, v in kinds.items()}
-    print('c4_mt19937_agent: %d slots x %d sims, %d rounds, %d games under np.random.seed(%d): %s; %d samples, %d results'
+    print(name + '_mt19937_agent: %d slots x %d sims, %d rounds, %d games under np.random.seed(%d): %s; %d samples, %d results'
           % (B, sims, len(rec['actions']), rec['games_played'][-1], seed, nk, len(samples), len(results)))
 
 
@@ -599,6 +602,8 @@ def main():
         gen_c4_mt19937()
     if 'c4_mt19937_agent' in which:
         gen_c4_mt19937_agent()
+    if 'br_mt19937_agent' in which:                            # the same tier for the reference's second game: child lists of 40-100 moves
+        gen_c4_mt19937_agent(B=4, sims=16, games=4, seed=20260930, eval_seed=93, Game=br_game_cls(), gid=ol.GAME_BRANDUBH, name='br')
     if 'c4_net' in which:
         gen_net()
     if 'c4_ckpt' in which:

@@ -161,21 +161,23 @@ def test_c4_search_under_numpys_mt19937_seed(torch_mod):
     eng.close()
 
 
+@pytest.mark.parametrize('name', ['c4', 'br'])
 @pytest.mark.parametrize('launch', ['phase', 'fused'])
-def test_c4_selfplay_agent_under_numpys_mt19937_seed(torch_mod, launch):
+def test_c4_selfplay_agent_under_numpys_mt19937_seed(torch_mod, launch, name):
     """A whole SelfPlayAgent under np.random.seed(s), move for move: tests/golden/c4_mt19937_agent.npz is the REFERENCE's
     agent -- 4 concurrent connect4 games, root noise and root temperature on, 6 games -- on numpy's own MT19937 stream with shuffle /
     dirichlet / choice observed per game slot (tests/test_oracle_golden.py re-derives every draw from the seed alone).  The engine replays
     all three (azg_set_random_tape) and must reproduce: visit counts and the sampled action of every slot in every round, the games_played
     trajectory, the (state, pi, z) samples incl. symmetries and the results in queue order, and end with its tape counters at the end of
     each slot's recorded draws.  (Temperatures other than 1 go through powf: counts and actions are compared exactly, as in the agent
-    goldens.)"""
+    goldens.)  name = 'br': the same for the reference's second game -- br_mt19937_agent.npz, 4 brandubh games over 53 rounds, 3 329 recorded
+    shuffles of 40-100 children (lists longer than a wavefront), 8-fold symmetries in the samples."""
     torch = torch_mod
-    d = dict(np.load(os.path.join(G, 'c4_mt19937_agent.npz')))
+    d = dict(np.load(os.path.join(G, name + '_mt19937_agent.npz')))
     B, sims, games, eseed = int(d['B']), int(d['sims']), int(d['games']), int(d['eval_seed'])
     cpuct, fpu, nfrac, rtemp = [float(x) for x in d['cfg']]
-    eng = engine(B=B, cpuct=cpuct, fpu_reduction=fpu, root_noise_frac=nfrac, root_policy_temp=rtemp, add_root_noise=True, add_root_temp=True,
-                 seed=987654321, games_per_iteration=games, example_capacity=4096, sims_hint=sims)
+    eng = engine(game={'c4': C4, 'br': ol.GAME_BRANDUBH}[name], B=B, cpuct=cpuct, fpu_reduction=fpu, root_noise_frac=nfrac, root_policy_temp=rtemp,
+                 add_root_noise=True, add_root_temp=True, seed=987654321, games_per_iteration=games, example_capacity=4096, sims_hint=sims)
     eng.set_random_tape(d['tape_ranks'], d['tape_u'], d['tape_noise_off'], d['tape_noise_pool'])
     rec = run_engine_agent(torch, eng, eseed, 0, sims, games, launch=launch)
     n = len(d['actions'])

@@ -147,13 +147,21 @@ def test_c4_mt19937_fixture_is_numpys_own_stream():
     assert total > 3000
 
 
-def test_c4_mt19937_agent_fixture_is_numpys_own_stream():
-    """tests/golden/c4_mt19937_agent.npz (round 6): a whole reference SelfPlayAgent -- 4 concurrent connect4 games, root noise + root
-    temperature on, six games -- under np.random.seed(seed) on numpy's untouched stream, with np.random.shuffle / dirichlet / choice /
+MT_AGENT_FIXTURES = ['c4', 'br']                               # connect4: 6 games, 19 rounds; brandubh: 4 games, 53 rounds, child lists of 40-100 moves
+
+
+def _mt_game(name):
+    return {'c4': C4, 'br': ol.GAME_BRANDUBH}[name]
+
+
+@pytest.mark.parametrize('name', MT_AGENT_FIXTURES)
+def test_c4_mt19937_agent_fixture_is_numpys_own_stream(name):
+    """tests/golden/{c4,br}_mt19937_agent.npz (round 6): a whole reference SelfPlayAgent -- 4 concurrent games of connect4 / brandubh,
+    root noise + root temperature on -- under np.random.seed(seed) on numpy's untouched stream, with np.random.shuffle / dirichlet / choice /
     random_sample observed.  Replaying the recorded CALL ORDER (kind, length) on np.random.RandomState(seed) must reproduce every
     recorded rank, noise value and uniform: the fixture is pinned to the literal seed without the reference.  Then the per-slot tapes
     (the engine's counter order: azg_set_random_tape) must be those same draws regrouped by game slot."""
-    d = dict(np.load(os.path.join(G, 'c4_mt19937_agent.npz')))
+    d = dict(np.load(os.path.join(G, name + '_mt19937_agent.npz')))
     rs = np.random.RandomState(int(d['seed']))
     ri = ni = ui = 0
     B = int(d['B'])
@@ -188,15 +196,19 @@ def test_c4_mt19937_agent_fixture_is_numpys_own_stream():
         assert (d['tape_noise_off'][sl, pos:] == -1).all()
     # what the agent did with them: one action per slot and round, every counted game in the result queue
     assert d['actions'].shape == d['counts'].shape[:2] and (d['actions'] >= 0).all() and int(d['games_played'][-1]) == int(d['games']) == len(d['r_turns'])
-    assert d['s_obs'].shape[0] == 2 * int(d['r_turns'].sum())                  # two symmetries per recorded position (connect4.pyx:96-99)
+    assert d['s_obs'].shape[0] == ol.game_info(_mt_game(name)).num_symmetries * int(d['r_turns'].sum())   # every recorded position x symmetries (connect4.pyx:96-99; brandubh: 8)
 
 
-def test_c4_mt19937_agent_vs_oracle():
+@pytest.mark.parametrize('name', MT_AGENT_FIXTURES)
+def test_c4_mt19937_agent_vs_oracle(name):
     """The oracle held to the reference under numpy's OWN stream: with the draws the reference's SelfPlayAgent made under np.random.seed(s)
-    replayed per game slot (azo_tape_set_replay: shuffles, Dirichlet vectors, choice uniforms), the C restatement plays the same six games --
+    replayed per game slot (azo_tape_set_replay: shuffles, Dirichlet vectors, choice uniforms), the C restatement plays the same games --
     visit counts and sampled action of every slot in every round, games_played, every sample incl. symmetries, the results in queue order."""
     import ctypes as CT
-    d = dict(np.load(os.path.join(G, 'c4_mt19937_agent.npz')))
+    d = dict(np.load(os.path.join(G, name + '_mt19937_agent.npz')))
+    GID = _mt_game(name)
+    gi = ol.game_info(GID)
+    A, NV = gi.action_size, gi.num_players + 1
     B, sims, games, eseed = int(d['B']), int(d['sims']), int(d['games']), int(d['eval_seed'])
     cpuct, fpu, nfrac, rtemp = [float(x) for x in d['cfg']]
     keep = [np.ascontiguousarray(d['tape_ranks']), np.ascontiguousarray(d['tape_u']), np.ascontiguousarray(d['tape_noise_off']), np.ascontiguousarray(d['tape_noise_pool'])]
@@ -206,20 +218,20 @@ def test_c4_mt19937_agent_vs_oracle():
         for sl in range(B):
             ol.lib().azo_tape_set_replay(sl, keep[0][sl].ctypes.data_as(CT.c_void_p), keep[1][sl].ctypes.data_as(CT.c_void_p), keep[2][sl].ctypes.data_as(CT.c_void_p),
                                          keep[3].ctypes.data_as(CT.c_void_p), L)
-        ag = ol.OAgent(C4, B, sims=sims, games_per_iteration=games, seed=424242, cpuct=cpuct, fpu_reduction=fpu, root_noise_frac=nfrac, root_policy_temp=rtemp,
+        ag = ol.OAgent(GID, B, sims=sims, games_per_iteration=games, seed=424242, cpuct=cpuct, fpu_reduction=fpu, root_noise_frac=nfrac, root_policy_temp=rtemp,
                        add_root_noise=True, add_root_temp=True)
         step = 0
         for rnd in range(len(d['actions'])):
             assert ag.begin_round() == sims
             for _ in range(sims):
                 ag.generate_batch()
-                pol = np.zeros((B, 7), np.float32); val = np.zeros((B, 3), np.float32)
+                pol = np.zeros((B, A), np.float32); val = np.zeros((B, NV), np.float32)
                 for i in range(B):
-                    pol[i], val[i] = ol.fake_eval(eseed, i, step, 7, 3)
+                    pol[i], val[i] = ol.fake_eval(eseed, i, step, A, NV)
                 ag.process_batch(pol, val); step += 1
             for i in range(B):
                 ch = ag.root_children(i)
-                c = np.zeros(7, np.int32); c[ch['a']] = ch['n']
+                c = np.zeros(A, np.int32); c[ch['a']] = ch['n']
                 assert (c == d['counts'][rnd, i]).all(), (rnd, i)
             ag.play_moves()
             assert (ag.last_actions() == d['actions'][rnd]).all(), rnd
