@@ -537,6 +537,10 @@ __device__ __forceinline__ void heads_full_prefetch(const HeadsFull &hf, int wav
     for (int j = 0; j < KQ; j++)
 #pragma unroll
         for (int q = 0; q < HEADF_Q; q++) { const int ks = q * KQ + j; if (ks < KS && ks < (q + 1) * KQ) pf.b[ks] = w0[(size_t)ks * 64]; }
+    // (nothing may sink these requests towards their uses: where the heads loop follows at once -- the multi-game tiles -- the scheduler had
+    //  moved every one of them down to just in front of its MFMA, into ONE register quad: the first subtile of every evaluation waited for 25
+    //  L2 round trips one after the other, `s_waitcnt vmcnt(0)` in front of each MFMA -- about 20 k of the phase's 25 k cycles)
+    __builtin_amdgcn_sched_barrier(0);
 }
 template <class G, int HW, int BOARDS, int NW, bool COMPACT, bool VFIRST = false>
 __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row, const HeadsFull &hf, int wave, int lane, HeadsFirst<G, HW> &pf,
