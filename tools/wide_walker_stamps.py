@@ -1,7 +1,8 @@
 """Where the walker wavefront of the persistent wide-head search launch spends a tree phase (s_memtime stamps of every slot's LAST
 simulation of a move; needs the tree-timing build: tools/build_timing.sh tree, AZG_LIB_PATH=.../libazg_timing.so).
 Stamps: 8 phase start, 1 value logits + softmax done, 3 path backed up, 4 descent starts, [9 -> 0 waited for the previous leaf's
-priors], 5 descent done, [2 -> 15 waited for the shuffle masks], 6 expansion done, 7 leaf stored.   usage: [brandubh|trimok]"""
+priors], 5 descent done, [2 -> 15 waited for the shuffle masks], 6 expansion done, 7 leaf stored.   usage: [brandubh|trimok] [games] [exact]
+(tiles of several games per workgroup: ONE wavefront does a game's whole tree phase -- its softmax + priors sit between stamps 8 and 1)"""
 import ctypes as C
 import importlib
 import os
@@ -13,6 +14,9 @@ from alphazero_general_amd import _abi, nnet as N
 from alphazero_general_amd.engine import DeviceEngine
 game = sys.argv[1] if len(sys.argv) > 1 else 'brandubh'
 B, sims, netargs = {'brandubh': (512, 200, N.BRANDUBH_NET_ARGS), 'trimok': (256, 50, N.DEFAULT_NET_ARGS)}[game]
+if len(sys.argv) > 2:
+    B = int(sys.argv[2])
+exact = len(sys.argv) > 3 and sys.argv[3] == 'exact'
 Game = importlib.import_module('alphazero_general_amd.envs.' + game).Game
 torch.manual_seed(0)
 net = N.NNetWrapper(Game, netargs, device='cuda:0', dtype=torch.float16); net.refresh()
@@ -23,7 +27,7 @@ seg = [('value logits + softmax', 8, 1), ('path backup', 1, 3), ('to descent sta
 acc = {k: 0.0 for k, _, _ in seg}; n = 0; wp = wm = 0.0; np_ = nm = 0
 for mv in range(10):
     for s in (sims - 6, 2, 2, 2):                    # the move in pieces: the last backup + select of each piece leaves its stamps
-        net._hip.search(e, s)
+        net._hip.search(e, s, exact=exact)
         buf = np.zeros((B, 16), np.uint64)
         _abi.check(L.azg_debug_tree_timing(e.h, buf.ctypes.data_as(C.c_void_p)))
         b = buf.astype(np.int64)
