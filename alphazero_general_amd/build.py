@@ -30,9 +30,11 @@ VARIANTS = {                                                         # name -> (
     'timing-tree': ('libazg_timing.so', ['-DAZG_TREE_TIMING']),
     'timing-tower': ('libazg_timing.so', ['-DAZG_TOWER_TIMING']),
     'timing-w1': ('libazg_timing_w1.so', ['-DAZG_TOWER_TIMING', '-DAZG_PHASE_TID=64', '-DAZG_TUNING']),          # phase stamps of wavefront 1 (a streaming wavefront in every heads layout)
-    'timing-w1-overlap': ('libazg_timing_w1o.so', ['-DAZG_TOWER_TIMING', '-DAZG_PHASE_TID=64', '-DAZG_OVL_NW=2', '-DAZG_TUNING']),
+    'timing-w1-overlap': ('libazg_timing_w1o.so', ['-DAZG_TOWER_TIMING', '-DAZG_PHASE_TID=64', '-DAZG_OVL_NW=2', '-DHEADS_A_RING=1', '-DAZG_TUNING']),
     'ring1': ('libazg_ring1.so', ['-DHEADS_A_RING=1', '-DAZG_TUNING']),                        # A/B of the heads' A-operand ring depth (product: 4); ring 1 = round 5's schedule
-    'overlap': ('libazg_overlap.so', ['-DAZG_OVL_NW=2', '-DAZG_TUNING']),                      # experiment (not adopted): the one-game exact tile with the walk overlapped with the policy-head stream; A/B against 'tuning'
+    # experiment (not adopted): the one-game exact tile with the walk overlapped with the policy-head stream.  A/B against 'ring1': the
+    # 19-subtile unrolled stream of the two streaming wavefronts only compiles sanely with the A-operand ring at depth 1 (depth 4: 22 k spilled SGPRs)
+    'overlap': ('libazg_overlap.so', ['-DAZG_OVL_NW=2', '-DHEADS_A_RING=1', '-DAZG_TUNING']),
     'headline1': ('libazg_headline1.so', ['-DAZG_HEADLINE_ONE_WG']),   # experiment: the connect4 search kernel with one workgroup per CU (512 registers, no spills)
 }
 

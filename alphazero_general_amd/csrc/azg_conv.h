@@ -573,7 +573,10 @@ __device__ __forceinline__ void heads_full_lds(char *scr0, const char *zero_row,
     }
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-        const int s_ = wave + it * NW;                                       // (scalar; VFIRST: the item number)
+        int s_ = wave + it * NW;                                             // (scalar; VFIRST: the item number)
+        // (opaque: what an iteration derives from its subtile number -- fragment and feature addresses, the bias index -- is computed in
+        //  the iteration, not hoisted for all of them in front of the unrolled loop, where it sat in registers across the whole phase)
+        asm volatile("" : "+s"(s_));
         const int sc = heads_item_subtile<OSP, VFIRST>(s_), sn = heads_item_subtile<OSP, VFIRST>(s_ + NW);   // (past the end: the value subtile once more, not stored)
         const bool is_v = sc == OSP;
         const half8 *wn = frags(sn);
