@@ -2,6 +2,8 @@
 (csrc/azg_conv.h) against the plain fp32 PyTorch reference of the same architecture (NNetArchitecture.py:69-120).
 Tolerance: probabilities within 3e-3 absolute (fp16 activations/weights, fp32 accumulation) -- the parity bar for the
 floating-point network; the tree itself is checked bit-exactly with the SAME (p, v) fed to oracle and engine."""
+import os
+
 import numpy as np
 import pytest
 
@@ -385,3 +387,19 @@ def test_shared_batch_tensors_are_page_locked_for_their_lifetime():
     assert sum('pageable (staged) path' in str(w.message) for w in caught) == 1, [str(w.message) for w in caught]
     del keep
     gc.collect()
+
+
+def test_hip_network_bits_are_pinned():
+    """The HIP network's OUTPUT BITS on deterministic weights and inputs (tests/net_pins.py; pins generated on an MI355X by
+    tests/golden/make_hip_net_pins.py): the tree tests compare the engine with an oracle fed by this same network, and the network is held
+    to fp32 PyTorch only within a tolerance -- a change of its arithmetic (summation order, a fused epilogue, a different tile's rounding)
+    would move both sides of every tree test together.  This is the test that sees it: every BASELINE network on its game, batch sizes that
+    walk through the tile shapes."""
+    import json
+    import net_pins
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'hip_net_pins.json')))['pins']
+    got = net_pins.compute()
+    assert set(got) == set(want)
+    for key in sorted(want):
+        for B in sorted(want[key], key=int):
+            assert list(got[key][B]) == list(want[key][B]), (key, B, got[key][B], want[key][B])
