@@ -6,7 +6,8 @@ close that gap: for deterministic weights (integer hashing only: no libm, no tor
 `NNetWrapper.process`'s float32 policy and value rows is recorded per (game, network, batch size) in tests/golden/hip_net_pins.json -- the
 batch sizes walk through the tower's tile shapes (1 / 2 / 4 boards per workgroup, pixel- and k-split), whose outputs are identical per board.
 Generated ON an MI355X by tests/golden/make_hip_net_pins.py (MFMA arithmetic is a property of the hardware: the pins are gfx950's);
-checked by tests/test_gpu_nnet.py::test_hip_network_bits_are_pinned.  A deliberate change of the summation order regenerates them."""
+checked by tests/test_gpu_nnet.py::test_hip_network_bits_are_pinned (seen to hold on four different GPUs of the pool: unique ids 0x3efe7164df93d021,
+0x41930ee287244ba2, 0xbe04e15bd387da5f, 0x7e7f52cea602aca9).  A deliberate change of the summation order regenerates them."""
 import zlib
 
 import numpy as np
